@@ -1,0 +1,172 @@
+/*
+ * mms.h -- C ABI of the MI355X-native multi-agent physics + rollout engine ("mms").
+ *
+ * This is the INNER drop-in boundary: what the reference's task files obtain
+ * today from the closed Isaac Gym binary through `self.gym.*` calls.  The reference has no FFI of
+ * its own for this path (it is Python calling a vendor binary), so each entry point cites the
+ * reference call sites it replaces.  Plain pointers and sizes only; no torch types.
+ *
+ *   reference call site (under /root/reference)                         replaced by
+ *   ------------------------------------------------------------------  -----------------------
+ *   gymapi.acquire_gym / create_sim / add_ground / create_env /          mms_create
+ *     load_asset / create_box / create_actor / prepare_sim
+ *     (agents/tasks/agent_base/base_task.py:25,83,122;
+ *      agents/tasks/ten_ant.py:205-633; one_ant.py:150-312;
+ *      multi_ingenuity.py:120-226)
+ *   acquire_actor_root_state_tensor / acquire_dof_state_tensor /         mms_get_tensor
+ *     acquire_force_sensor_tensor + gymtorch.wrap_tensor
+ *     (ten_ant.py:84-104; one_ant.py:78-103; multi_ingenuity.py:77-95)
+ *   pre_physics_step + gym.simulate + fetch_results +                    mms_step
+ *     post_physics_step (refresh_*, reset_idx, compute_observations,
+ *     compute_reward)  (base_task.py:129-149; ten_ant.py:886-926)
+ *   set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed   mms_set_state (tests),
+ *     (ten_ant.py:856-868)                                               in-kernel reset
+ *   RolloutStorage.compute_returns (algorithms/rl/ppo/storage.py:51-65)  mms_gae_ppo
+ *   SeparatedReplayBuffer.compute_returns                                mms_gae_marl
+ *     (algorithms/marl/utils/separated_buffer.py:153-164)
+ *   MultiVecTaskPython.step slicing (agent_base/multi_vec_task.py:       mms_marl_views
+ *     105-142)
+ *
+ * Ownership: the engine owns every buffer it reports through mms_get_tensor for the lifetime of the
+ * handle; callers wrap them as NON-owning views and must keep the handle alive while any view exists.
+ * Threading: a handle is not thread-safe; one handle per process / GPU.  All work is enqueued on the
+ * caller's HIP stream; no entry point synchronises the device except mms_create / mms_destroy.
+ * Status: 0 = ok; non-zero = error, text from mms_last_error().
+ * There is NO CPU fallback: mms_create fails when no HIP device is usable.
+ */
+#ifndef MMS_H
+#define MMS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMS_ABI_VERSION 1
+
+enum mms_task { MMS_TASK_TEN_ANT = 0, MMS_TASK_ONE_ANT = 1, MMS_TASK_MULTI_INGENUITY = 2 };
+enum mms_dtype { MMS_F32 = 0, MMS_I64 = 1, MMS_I32 = 2, MMS_U8 = 3 };
+
+/* Physical model (numbers are produced by massive_marl_benchmark_amd/model.py
+ * from the MJCF geometry).  All SI units, float32. */
+typedef struct mms_model {
+    /* ant: torso + 4 x (leg, foot); body frames are aligned at q = 0 */
+    float torso_mass, torso_ixx, torso_izz, torso_radius;
+    float leg_mass, leg_ia, leg_it;      /* capsule axial / transverse inertia about its COM */
+    float foot_mass, foot_ia, foot_it;
+    float limb_radius, leg_len, foot_len; /* capsule radius and segment lengths */
+    float hip_pos[4][3];                 /* hip joint position in the torso frame */
+    float limb_dir[4][3];                /* unit capsule direction of leg and foot at q = 0 */
+    float ankle_axis[4][3];              /* unit ankle axis in the leg frame */
+    float dof_lower[8], dof_upper[8], dof_init[8], gear[8];
+    float armature, joint_damping, limit_k, limit_c;
+    /* contact (compliant, linearly-implicit) */
+    float gnd_k, gnd_c, gnd_mu, slip_eps;
+    float antbox_k, antbox_c;
+    float boxgnd_k, boxgnd_c;
+    /* box */
+    float box_half[3], box_mass, box_inertia[3];
+    /* helicopter (MultiIngenuity): one rigid body */
+    float heli_mass, heli_inertia[3], heli_com_z, heli_rotor_z[2], heli_half, heli_max_angvel;
+    float heli_gnd_k, heli_gnd_c;
+    float gravity;                       /* positive magnitude along -z */
+} mms_model;
+
+typedef struct mms_config {
+    int32_t abi_version;                 /* MMS_ABI_VERSION */
+    int32_t task;                        /* enum mms_task */
+    int32_t num_envs;                    /* envs owned by this handle (this GPU's shard) */
+    int32_t num_agents;                  /* ants (10 / 1) or helicopters (4) per env */
+    int32_t device;                      /* HIP device ordinal (>= 0) */
+    int32_t substeps;                    /* physics substeps per control step (cfg sim.substeps = 2) */
+    int32_t max_episode_length;          /* cfg env.episodeLength */
+    int32_t external_noise;              /* 1: reset noise is read from the "reset_noise" tensor */
+    int64_t env_offset;                  /* global index of local env 0 (multi-GPU sharding) */
+    int64_t total_envs;                  /* global env count: env-grid row length = (int)sqrt(total) */
+    uint64_t seed;
+    float env_spacing;                   /* cfg env.envSpacing */
+    float dt;                            /* cfg sim.dt */
+    float clip_actions, clip_obs;        /* wrapper clamps (vec_task.py:18,127,131) */
+    float dof_vel_scale, contact_force_scale, power_scale;
+    float heading_weight, up_weight, actions_cost, energy_cost, joints_at_limit_cost;
+    float death_cost, termination_height;
+    float quat_reward_scale, ant_dist_reward_scale, goal_dist_reward_scale;
+    float ant_start_x, ant_start_z;      /* ant k starts at (x, s_k*(1.5+3*(k/2)), z), s = -,+,-,+ ... */
+    float box_start[3];
+    mms_model model;
+} mms_config;
+
+typedef struct mms_tensor {
+    void*   ptr;                         /* device pointer */
+    int64_t shape[4];
+    int32_t ndim;
+    int32_t dtype;                       /* enum mms_dtype */
+    int32_t device;                      /* HIP device ordinal */
+    int32_t reserved;
+} mms_tensor;
+
+typedef struct mms_engine* mms_handle;
+
+/* Builds the scene for cfg->num_envs environments on cfg->device and allocates all state.
+ * Replaces create_sim ... prepare_sim (see table above). */
+int mms_create(const mms_config* cfg, mms_handle* out);
+int mms_destroy(mms_handle h);
+
+/* Named buffers.  Common: "actions" [N,num_actions] f32 (input of mms_step), "obs" [N,obs_dim] f32,
+ * "obs_clipped" [N,obs_dim] f32 (clamped to +-clip_obs), "rew" [N] f32, "reset" [N] i64,
+ * "progress" [N] i64, "root_states" [N*actors,13] f32 (env-local frame), "dof_state" [N*dofs,2] f32,
+ * "env_origin" [N,3] f32, "prev" [N,prev_dim] f32 (pos_before / goal_before / box_before caches),
+ * "reset_noise" [N,16] f32, "foot_sensors" [N*A,24] f32, "initial_root_states" [N*actors,13] f32. */
+int mms_get_tensor(mms_handle h, const char* name, mms_tensor* out);
+
+/* One VecTask step: clamp actions, physics substeps, progress += 1, reset flagged envs,
+ * observations, reward / reset flags, cache update -- one fused launch, stream ordered.
+ * Replaces BaseTask.step (base_task.py:129-149). */
+int mms_step(mms_handle h, void* hip_stream);
+
+/* Same protocol with the physics skipped: the post-physics glue applied to whatever state the
+ * buffers hold.  Used by the parity tests that supply state per step (fixture tenant_step_glue). */
+int mms_post_step(mms_handle h, void* hip_stream);
+
+/* Flags every env for reset (reset_buf := 1), as at construction (base_task.py:62-63). */
+int mms_reset_all(mms_handle h, void* hip_stream);
+
+/* Copies caller data (device or host pointer, `src_is_host`) into a named buffer.  env_ids == NULL
+ * copies the whole buffer; otherwise `src` holds n rows (one per listed env) that are scattered.
+ * Tests / fixtures only. */
+int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_host,
+                  const int64_t* env_ids, int64_t n, void* hip_stream);
+
+/* Optional extra destination for the clamped observation row, e.g. slot t of a rollout buffer
+ * [T,N,obs_dim]; NULL disables.  The pointer must stay valid until the next bind. */
+int mms_bind_obs_out(mms_handle h, void* dst);
+
+/* MARL wrapper views (multi_vec_task.py:105-142): obs_all [N,A,per_agent+shared] from a clamped
+ * observation buffer [N, A*per_agent+shared]. */
+int mms_marl_views(int device, const float* obs_clipped, float* obs_all, int64_t n, int32_t agents,
+                   int32_t per_agent, int32_t shared, void* hip_stream);
+
+/* PPO GAE (storage.py:51-65).  rewards/values/returns/advantages are [T,N] f32, dones [T,N] u8,
+ * last_values [N].  Writes returns and UN-normalised advantages, and stats[0..2] =
+ * {sum(adv), sum(adv^2), count} as float64 so that ranks can all-reduce them.  */
+int mms_gae_ppo(int device, const float* rewards, const uint8_t* dones, const float* values,
+                const float* last_values, float* returns, float* advantages, double* stats,
+                int32_t T, int64_t N, float gamma, float lam, void* hip_stream);
+/* advantages := (advantages - mean) / (std + 1e-8) with the unbiased std from stats. */
+int mms_adv_normalize(int device, float* advantages, const double* stats, int64_t count, void* hip_stream);
+
+/* MARL GAE (separated_buffer.py:153-164, use_proper_time_limits=False): value_preds [T+1,N]
+ * (row T already holds next_value), masks [T+1,N], rewards [T,N], returns [T+1,N];
+ * denormalisation x*sqrt(var)+mean when use_norm (PopArt / ValueNorm). */
+int mms_gae_marl(int device, const float* rewards, const float* value_preds, const float* masks,
+                 float* returns, int32_t T, int64_t N, float gamma, float lam,
+                 int32_t use_norm, const float* norm_mean, const float* norm_var, void* hip_stream);
+
+const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
+int mms_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMS_H */

@@ -402,6 +402,7 @@ def main():
         env = mvt.MultiVecTaskPython(_Task(), "cpu")
     acts = [1.5 * (torch.rand(N, 8, generator=g) * 2 - 1) for _ in range(10)]
     obs_all, state_all, reward_all, done_all, info_all, _ = env.step(acts)
+    seen_step = env.task.seen_actions.clone()
     r_obs, r_state, _ = env.reset()
     with contextlib.redirect_stdout(io.StringIO()):
         t1 = _Task()
@@ -412,7 +413,7 @@ def main():
     _save("vec_wrappers", meta_common + "; MultiVecTaskPython.step/reset (multi_vec_task.py:94-175), "
           "VecTaskPython.step (vec_task.py:126-131) on a dummy task; np.Inf shim applied",
           obs_buf=obs_buf, rew_buf=rew_buf, reset_buf=reset_buf, actions=torch.stack(acts, 1),
-          seen_actions=env.task.seen_actions, obs_all=obs_all, state_all=state_all, reward_all=reward_all,
+          seen_actions=seen_step, reset_seen_actions=env.task.seen_actions, obs_all=obs_all, state_all=state_all, reward_all=reward_all,
           done_all=done_all, reset_obs=r_obs, reset_state=r_state,
           single_actions=a80, single_seen_actions=t1.seen_actions, single_obs=o1, single_rew=r1, single_done=d1)
 
@@ -435,7 +436,11 @@ def main():
         for k, x in zip(rec, (o, a, r, d, v, lp, mu, sg)):
             rec[k].append(x)
     last_values = torch.randn(NE, 1, generator=g)
-    stats_len, stats_rew = st.get_statistics()
+    # get_statistics() does `done = self.dones.cpu(); done[-1] = 1` (storage.py:68-69): with the storage on the
+    # CPU `.cpu()` is not a copy, so it would overwrite the last row of dones.  The reference runs with the
+    # storage on the GPU, where it is a copy -- reproduce that by taking the statistics from a deep copy.
+    import copy
+    stats_len, stats_rew = copy.deepcopy(st).get_statistics()
     st.compute_returns(last_values, 0.96, 0.95)
     _save("ppo_gae", meta_common + "; RolloutStorage.add_transitions/compute_returns/get_statistics "
           "(algorithms/rl/ppo/storage.py:32-72), gamma=0.96 lam=0.95",

@@ -1,0 +1,221 @@
+"""The CPU oracle against the golden vectors produced by the reference's own functions
+(tests/golden/make_fixtures.py).  Tolerance: 1e-4 abs fp32, angles modulo 2*pi;
+integer outputs (reset flags) bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import angle_close, load_golden
+from oracle.oracle import F, I64, U8, OracleEngine, f32, fp, i64, ip
+
+TOL = 1e-4
+REW_TOL = 5e-4
+REWARD_SCAL = np.array([0.1, 0.5, 0.005, 0.05, 0.1, 0.31, -2.0, 0.0, 500.0, 500.0, 1000], np.float32)
+
+
+def test_helpers_golden(olib):
+    g = load_golden("helpers_kat")
+    n = g["q"].shape[0]
+    q, q2, v = f32(g["q"]), f32(g["q2"]), f32(g["v"])
+    out = {k: np.zeros((n, d), np.float32) for k, d in
+           (("quat_mul", 4), ("quat_conjugate", 4), ("quat_rotate", 3), ("quat_rotate_inverse", 3), ("normalize", 3),
+            ("quat_axis0", 3), ("quat_axis2", 3))}
+    ang = {k: np.zeros(n, np.float32) for k in ("roll", "pitch", "yaw")}
+    olib.mo_helpers_batch(n, fp(q), fp(q2), fp(v), fp(out["quat_mul"]), fp(out["quat_conjugate"]),
+                          fp(out["quat_rotate"]), fp(out["quat_rotate_inverse"]), fp(ang["roll"]), fp(ang["pitch"]),
+                          fp(ang["yaw"]), fp(out["normalize"]), fp(out["quat_axis0"]), fp(out["quat_axis2"]))
+    for k, a in out.items():
+        assert np.max(np.abs(a - g[k])) < 1e-6, k
+    # near gimbal lock the asin branch amplifies rounding: 2e-3 there, 1e-5 elsewhere
+    sinp = 2.0 * (q[:, 3] * q[:, 1] - q[:, 2] * q[:, 0])
+    ok = np.abs(sinp) < 0.999
+    for k, a in ang.items():
+        assert angle_close(a[ok], g[k][ok], 0) < 1e-5, k
+        assert angle_close(a[~ok], g[k][~ok], 0) < 5e-3, k
+        assert np.all(a >= 0) and np.all(a < 2 * np.pi + 1e-6)
+
+
+def test_helpers_closed_form(olib):
+    """KATs independent of the stub: identity and 90-degree rotations about each axis."""
+    s = np.float32(np.sqrt(0.5))
+    q = f32([[0, 0, 0, 1], [s, 0, 0, s], [0, s, 0, s], [0, 0, s, s]])
+    v = f32([[1, 2, 3]] * 4)
+    n = 4
+    z4, z3, z1 = (lambda: np.zeros((n, 4), np.float32)), (lambda: np.zeros((n, 3), np.float32)), (lambda: np.zeros(n, np.float32))
+    qm, qc, r, ri, nm, a0, a2 = z4(), z4(), z3(), z3(), z3(), z3(), z3()
+    ro, pi_, ya = z1(), z1(), z1()
+    olib.mo_helpers_batch(n, fp(q), fp(q), fp(v), fp(qm), fp(qc), fp(r), fp(ri), fp(ro), fp(pi_), fp(ya), fp(nm), fp(a0), fp(a2))
+    np.testing.assert_allclose(r, [[1, 2, 3], [1, -3, 2], [3, 2, -1], [-2, 1, 3]], atol=1e-6)
+    np.testing.assert_allclose(ri, [[1, 2, 3], [1, 3, -2], [-3, 2, 1], [2, -1, 3]], atol=1e-6)
+    np.testing.assert_allclose(qm[1], [1, 0, 0, 0], atol=1e-6)          # 90deg o 90deg = 180deg about x
+    np.testing.assert_allclose(ro, [0, np.pi / 2, 0, 0], atol=1e-6)
+    np.testing.assert_allclose(ya, [0, 0, 0, np.pi / 2], atol=1e-6)
+    np.testing.assert_allclose(pi_[2], np.pi / 2, atol=1e-3)
+    np.testing.assert_allclose(nm, v / np.linalg.norm(v, axis=1, keepdims=True), atol=1e-6)
+
+
+def test_tenant_obs_golden(olib):
+    g = load_golden("tenant_obs")
+    n = g["root"].shape[0]
+    obs = np.zeros((n, 38), np.float32)
+    olib.mo_tenant_obs_batch(n, fp(f32(g["root"])), fp(f32(g["dof_pos"])), fp(f32(g["dof_vel"])), fp(f32(g["lower"])),
+                             fp(f32(g["upper"])), float(0.2), fp(f32(g["actions"])), fp(obs))
+    ref = g["obs"]
+    ang_idx = [9, 10, 11]
+    rest = [i for i in range(38) if i not in ang_idx]
+    assert np.max(np.abs(obs[:, rest] - ref[:, rest])) < TOL
+    q = g["root"][:, 3:7]
+    sinp = 2.0 * (q[:, 3] * q[:, 1] - q[:, 2] * q[:, 0])
+    ok = np.abs(sinp) < 0.999
+    for i in ang_idx:
+        assert angle_close(obs[ok, i], ref[ok, i], 0) < TOL, i
+        assert angle_close(obs[~ok, i], ref[~ok, i], 0) < 5e-3, i      # gimbal-lock rows: ill-conditioned
+
+
+def test_tenant_goals_golden(olib):
+    g = load_golden("tenant_goals")
+    n = g["box_root"].shape[0]
+    bp, bq, goals = np.zeros((n, 2), np.float32), np.zeros((n, 4), np.float32), np.zeros((n, 10, 2), np.float32)
+    ang, qd = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    olib.mo_tenant_goals_batch(n, fp(f32(g["box_root"])), fp(bp), fp(bq), fp(goals), fp(ang), fp(qd))
+    assert np.max(np.abs(bp - g["box_pos"])) == 0 and np.max(np.abs(bq - g["box_quat"])) == 0
+    assert np.max(np.abs(goals - g["goals"])) < TOL
+    assert np.max(np.abs(ang - g["angle"])) < 1e-5
+    assert np.max(np.abs(qd - g["quat_dist"])) < 1e-5
+
+
+def test_tenant_reward_golden(olib):
+    g = load_golden("tenant_reward")
+    n = g["obs"].shape[0]
+    rew, reset = np.zeros(n, np.float32), np.zeros(n, np.int64)
+    olib.mo_tenant_reward_batch(n, fp(f32(g["obs"])), ip(i64(g["reset_in"])), ip(i64(g["progress"])),
+                                fp(f32(g["actions"])), fp(f32(g["pos_before"])), fp(f32(g["goal_before"])),
+                                fp(f32(g["goals"])), fp(f32(g["box_quat"])), fp(REWARD_SCAL), fp(rew), ip(reset))
+    np.testing.assert_array_equal(reset, g["reset"])
+    # The reward multiplies differences of sqrt() values by 500 (ten_ant.py:58-59).  torch's CPU sqrt is
+    # 1 ulp off the correctly rounded result on some inputs (observed: sqrt(8.854785f)), i.e. 2.4e-7 at
+    # distances of 2..4 m -> 1.2e-4 per term after the x500.  REW_TOL = 5e-4 abs covers a few such terms;
+    # the O(1) terms themselves agree to 1e-6.
+    assert np.max(np.abs(rew - g["rew"])) < REW_TOL
+    assert len(np.unique(g["reset"])) == 2 and (g["rew"] == -2.0).any() and (g["rew"] > 100).any()
+
+
+def test_oneant_golden(olib):
+    g = load_golden("oneant_obs")
+    n = g["root"].shape[0]
+    obs, pot, ppot = np.zeros((n, 60), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    olib.mo_oneant_obs_batch(n, fp(f32(g["root"])), fp(f32(g["box_root"])), fp(f32(g["dof_pos"])), fp(f32(g["dof_vel"])),
+                             fp(f32(g["lower"])), fp(f32(g["upper"])), fp(f32(g["sensors"])), fp(f32(g["actions"])),
+                             fp(f32(g["potentials_in"])), fp(obs), fp(pot), fp(ppot))
+    q = g["root"][:, 3:7]
+    ok = np.abs(2.0 * (q[:, 3] * q[:, 1] - q[:, 2] * q[:, 0])) < 0.999
+    rest = [i for i in range(60) if i not in (7, 8, 9)]
+    assert np.max(np.abs(obs[:, rest] - g["obs"][:, rest])) < TOL
+    for i in (7, 8, 9):
+        assert angle_close(obs[ok, i], g["obs"][ok, i], 0) < TOL
+    assert np.max(np.abs(pot - g["potentials"]) / np.maximum(1, np.abs(g["potentials"]))) < 1e-6
+    np.testing.assert_array_equal(ppot, g["prev_potentials"])
+
+    g = load_golden("oneant_reward")
+    n = g["obs"].shape[0]
+    scal = REWARD_SCAL.copy()
+    scal[7] = 1.0                                                       # quat_reward_scale (one_ant.py:58)
+    rew, reset = np.zeros(n, np.float32), np.zeros(n, np.int64)
+    olib.mo_oneant_reward_batch(n, fp(f32(g["obs"])), ip(i64(g["reset_in"])), ip(i64(g["progress"])), fp(f32(g["actions"])),
+                                fp(f32(g["pos_before"])), fp(f32(g["box_before"])), fp(f32(g["ant_pos"])),
+                                fp(f32(g["box_pos"])), fp(f32(g["box_quat"])), fp(scal), fp(rew), ip(reset))
+    np.testing.assert_array_equal(reset, g["reset"])
+    assert np.max(np.abs(rew - g["rew"])) < REW_TOL
+
+
+def test_ingenuity_golden(olib):
+    g = load_golden("ingenuity_thrust")
+    n = g["actions"].shape[0]
+    thr = np.zeros((n, 8, 3), np.float32)
+    olib.mo_ingenuity_thrust_batch(n, fp(f32(g["actions"])), float(g["dt"]), fp(thr))
+    assert np.max(np.abs(thr - g["thrusts"])) < 1e-4                    # thrusts reach 33 N
+    g = load_golden("ingenuity_reward")
+    n = g["roots"].shape[0]
+    rew, reset = np.zeros(n, np.float32), np.zeros(n, np.int64)
+    olib.mo_ingenuity_reward_batch(n, fp(f32(g["roots"])), ip(i64(g["progress"])), fp(rew), ip(reset))
+    np.testing.assert_array_equal(reset, g["reset"])
+    assert np.max(np.abs(rew - g["rew"])) < TOL
+
+
+def test_vec_wrappers_golden(olib):
+    g = load_golden("vec_wrappers")
+    n = g["obs_buf"].shape[0]
+    out = np.zeros((n, 10, 46), np.float32)
+    olib.mo_marl_views(n, 10, 38, 8, float(7.0), fp(f32(g["obs_buf"])), fp(out))
+    np.testing.assert_array_equal(out, g["obs_all"])
+    np.testing.assert_array_equal(np.clip(g["obs_buf"], -7, 7)[:, None, :].repeat(10, 1), g["state_all"])
+    np.testing.assert_array_equal(g["reward_all"][:, :, 0], g["rew_buf"][:, None].repeat(10, 1))
+    np.testing.assert_array_equal(g["done_all"], g["reset_buf"][:, None].repeat(10, 1))
+    np.testing.assert_array_equal(np.clip(g["actions"].reshape(n, 80), -1, 1), g["seen_actions"])
+    np.testing.assert_array_equal(np.clip(g["obs_buf"], -5, 5), g["single_obs"])
+
+
+def test_ppo_gae_golden(olib):
+    g = load_golden("ppo_gae")
+    T, N = g["rewards"].shape
+    ret, adv = np.zeros((T, N), np.float32), np.zeros((T, N), np.float32)
+    dones = np.ascontiguousarray(g["dones"], np.uint8)
+    olib.mo_gae_ppo(T, N, fp(f32(g["rewards"])), dones.ctypes.data_as(U8), fp(f32(g["values"][..., 0])),
+                    fp(f32(g["last_values"][:, 0])), float(g["gamma"]), float(g["lam"]),
+                    fp(ret), fp(adv), 1)
+    assert np.max(np.abs(ret - g["returns"][..., 0])) < TOL
+    assert np.max(np.abs(adv - g["advantages"][..., 0])) < 1e-5
+
+
+def test_marl_gae_golden(olib):
+    g = load_golden("marl_gae")
+    T, N = g["rewards"].shape[:2]
+    for tag, use in (("popart", 1), ("valuenorm", 1), ("plain", 0)):
+        ret = np.zeros((T + 1, N), np.float32)
+        vp = f32(g["value_preds_" + tag][..., 0])
+        olib.mo_gae_marl(T, N, fp(f32(g["rewards"][..., 0])), fp(vp), fp(f32(g["masks_" + tag][..., 0])),
+                         float(g["gamma"]), float(g["gae_lambda"]), use,
+                         float(g["norm_mean_" + tag][0]), float(g["norm_var_" + tag][0]), fp(ret))
+        assert np.max(np.abs(ret[:T] - g["returns_" + tag][:T, :, 0])) < TOL, tag
+
+
+def test_tenant_step_glue_golden():
+    """post_physics_step sequence incl. resets: oracle engine with the fixture's state injected per step."""
+    g = load_golden("tenant_step_glue")
+    S, n = g["actions"].shape[0], g["actions"].shape[1]
+    eng = OracleEngine("TenAnt", num_envs=n, clip_obs=5.0, external_noise=True)
+    np.testing.assert_allclose(eng.tensor("env_origin"), g["env_origin"], atol=0)
+    init_local = g["init_root"].reshape(n, 11, 13).copy()
+    init_local[:, :, 0:3] -= g["env_origin"][:, None, :]
+    np.testing.assert_allclose(eng.tensor("initial_root_states").reshape(n, 11, 13), init_local, atol=1e-6)
+    for t in range(S):
+        loc = g["sim_root"][t].reshape(n, 11, 13).copy()
+        loc[:, :, 0:3] -= g["env_origin"][:, None, :]
+        eng.tensor("root_states")[...] = loc.reshape(n * 11, 13)
+        eng.tensor("dof_state")[...] = g["sim_dof"][t]
+        eng.tensor("reset_noise")[:, :8] = g["noise_pos"][t]
+        eng.tensor("reset_noise")[:, 8:] = g["noise_vel"][t]
+        np.testing.assert_array_equal(eng.tensor("reset"), g["reset_in"][t])
+        if t == 2:
+            eng.tensor("progress")[7] = 998                              # the fixture forces a timeout here
+        eng.step(g["actions"][t], physics=False)
+        np.testing.assert_array_equal(eng.tensor("reset"), g["reset"][t])
+        np.testing.assert_array_equal(eng.tensor("progress"), g["progress"][t])
+        obs, ref = eng.tensor("obs"), g["obs"][t]
+        ang = np.zeros(388, bool)
+        for k in range(10):
+            ang[38 * k + 9:38 * k + 12] = True
+        # global coordinates up to 240 m: fp32 ulp there is 1.5e-5; local + origin vs stored global
+        assert np.max(np.abs(obs[:, ~ang] - ref[:, ~ang])) < 2e-4, t
+        assert angle_close(obs[:, ang], ref[:, ang], 0) < 2e-4, t
+        rew_tol = 500.0 * 4e-5 * 20                                      # 500 x (position rounding) x 20 terms
+        assert np.max(np.abs(eng.tensor("rew") - g["rew"][t])) < rew_tol, t
+        prev = eng.tensor("prev")
+        assert np.max(np.abs(prev[:, :20] - g["pos_before"][t].reshape(n, 20))) < 2e-4
+        assert np.max(np.abs(prev[:, 20:40] - g["goal_before"][t].reshape(n, 20))) < 2e-4
+        assert np.max(np.abs(prev[:, 40:42] - g["box_before"][t])) < 2e-4
+        # state after the step (reset rows rewritten)
+        ra = g["root_after"][t].reshape(n, 11, 13).copy()
+        ra[:, :, 0:3] -= g["env_origin"][:, None, :]
+        assert np.max(np.abs(eng.tensor("root_states").reshape(n, 11, 13) - ra)) < 2e-5
+        assert np.max(np.abs(eng.tensor("dof_state") - g["dof_after"][t])) < 1e-6
+    eng.close()
