@@ -196,7 +196,7 @@ def build_model(task, num_agents, dt, substeps, gravity):
     fill_ant(m)
     h = dt / substeps
     # --- compliance parameters (this build's model) ---
-    m.limit_k, m.limit_c = 2000.0, 10.0
+    m.limit_k, m.limit_c = 5000.0, 20.0
     m.gnd_k, m.gnd_c, m.gnd_mu, m.slip_eps = 2.0e4, 300.0, 1.0, 1.0e-2
     if task == "OneAnt":
         bx, by, bz = 1.0, 1.0, 1.0                                         # one_ant.py:264

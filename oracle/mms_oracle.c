@@ -649,6 +649,12 @@ static void contact_force(contact_t* c, float h, const float a[6]) {
 
 typedef struct { float pos[3]; float R[3][3]; float v[3]; float w[3]; float half[3]; } box_pose;
 
+/* A contact is ACTIVE while the pair penetrates (d > 0) or would penetrate by the end of the substep at
+ * the current normal velocity (d - h v_n > 0); pairs farther apart than CONTACT_MARGIN are not examined.
+ * While active the force k d - (h k + c) v_n(new) is applied two-sidedly: no chatter at rest, no rebound;
+ * the price is a viscous adhesion that lasts only while the shapes still overlap. */
+#define CONTACT_MARGIN 0.1f
+
 /* Sphere (centre xs relative to O, O at world position Ow, radius rad) on a body with spatial velocity vb:
  * contact against the ground plane z = 0 -> cg, and against the box -> cb. */
 static void sphere_contacts(const mms_model* M, float h, const float Ow[3], const float xs[3], float rad,
@@ -658,14 +664,14 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
     {
         float zc = Ow[2] + xs[2];
         float d = rad - zc;
-        if (d > 0.f) {
+        if (d > -CONTACT_MARGIN) {
             float xc[3] = {xs[0], xs[1], xs[2] - rad};
             float vp[3], wx[3];
             cross3(vb, xc, wx);
             for (int i = 0; i < 3; i++) vp[i] = vb[3 + i] + wx[i];
             float gn = h * M->gnd_k + M->gnd_c;
-            float fn = M->gnd_k * d - gn * vp[2];
-            if (fn > 0.f) {
+            float fn = fmaxf(M->gnd_k * d - gn * vp[2], 0.f);   /* explicit estimate: friction bound only */
+            if (d > 0.f || d - h * vp[2] > 0.f) {               /* penetrating now or at the end of the step */
                 cg->active = 1;
                 memcpy(cg->xc, xc, sizeof(xc));
                 cg->n[0] = 0.f; cg->n[1] = 0.f; cg->n[2] = 1.f;
@@ -689,11 +695,12 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
             if (q[i] != xb[i]) inside = 0;
         }
         float nb[3] = {0.f, 0.f, 0.f}, d;
+        const int inside_far = 0;
         if (!inside) {
             float dl[3] = {xb[0] - q[0], xb[1] - q[1], xb[2] - q[2]};
             float dist = sqrtf(dot3(dl, dl));
             d = rad - dist;
-            if (d > 0.f) { nb[0] = dl[0] / dist; nb[1] = dl[1] / dist; nb[2] = dl[2] / dist; }
+            if (d > -CONTACT_MARGIN) { nb[0] = dl[0] / dist; nb[1] = dl[1] / dist; nb[2] = dl[2] / dist; }
         } else {
             int ax = 0;
             float best = box->half[0] - fabsf(xb[0]);
@@ -704,7 +711,7 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
             nb[ax] = (xb[ax] >= 0.f) ? 1.f : -1.f;
             d = rad + best;
         }
-        if (d > 0.f) {
+        if (d > -CONTACT_MARGIN && !inside_far) {
             float n[3];
             matvec3(box->R, nb, n);
             float xc[3] = {xs[0] - rad * n[0], xs[1] - rad * n[1], xs[2] - rad * n[2]};
@@ -714,8 +721,7 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
             cross3(box->w, rb, vbx);
             float vrel[3] = {vp[0] - box->v[0] - vbx[0], vp[1] - box->v[1] - vbx[1], vp[2] - box->v[2] - vbx[2]};
             float gn = h * M->antbox_k + M->antbox_c;
-            float fn = M->antbox_k * d - gn * dot3(n, vrel);
-            if (fn > 0.f) {
+            if (d > 0.f || d - h * dot3(n, vrel) > 0.f) {
                 cb->active = 1;
                 memcpy(cb->xc, xc, sizeof(xc));
                 memcpy(cb->n, n, sizeof(n));
@@ -818,8 +824,8 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
             float t = tau_motor[d] - M->joint_damping * qd;
             float De = M->armature + h * M->joint_damping;
             float ehi = q - M->dof_upper[d], elo = M->dof_lower[d] - q;
-            if (M->limit_k * ehi + gl * qd > 0.f) { t += -M->limit_k * ehi - gl * qd; De += h * gl; }
-            else if (M->limit_k * elo - gl * qd > 0.f) { t += M->limit_k * elo - gl * qd; De += h * gl; }
+            if (ehi > 0.f || ehi + h * qd > 0.f) { t += -M->limit_k * ehi - gl * qd; De += h * gl; }
+            else if (elo > 0.f || elo - h * qd > 0.f) { t += M->limit_k * elo - gl * qd; De += h * gl; }
             tau[j] = t; Dextra[j] = De;
         }
         /* inward: foot */
@@ -945,13 +951,12 @@ static void box_substep(const mms_model* M, float h, float root[13], const float
         float xc[3];
         matvec3(R, loc, xc);
         float d = -(root[2] + xc[2]);
-        if (d <= 0.f) continue;
+        if (d <= -CONTACT_MARGIN) continue;
         float wx[3], vp[3];
         cross3(w, xc, wx);
         for (int i = 0; i < 3; i++) vp[i] = v[i] + wx[i];
         float gn = h * M->boxgnd_k + M->boxgnd_c;
-        float fn = M->boxgnd_k * d - gn * vp[2];
-        if (fn <= 0.f) continue;
+        if (!(d > 0.f || d - h * vp[2] > 0.f)) continue;
         contact_t ct;
         ct.active = 1;
         memcpy(ct.xc, xc, sizeof(xc));
@@ -1001,13 +1006,13 @@ static void heli_substep(const mms_model* M, float h, float root[13], const floa
         float xc[3];
         matvec3(R, loc, xc);
         float d = -(root[2] + xc[2]);
-        if (d <= 0.f) continue;
+        if (d <= -CONTACT_MARGIN) continue;
         float wx[3], vp[3];
         cross3(v0, xc, wx);
         for (int i = 0; i < 3; i++) vp[i] = v0[3 + i] + wx[i];
         float gn = h * M->heli_gnd_k + M->heli_gnd_c;
-        float fn = M->heli_gnd_k * d - gn * vp[2];
-        if (fn <= 0.f) continue;
+        float fn = fmaxf(M->heli_gnd_k * d - gn * vp[2], 0.f);
+        if (!(d > 0.f || d - h * vp[2] > 0.f)) continue;
         contact_t ct;
         ct.active = 1;
         memcpy(ct.xc, xc, sizeof(xc));
@@ -1307,6 +1312,63 @@ MO_EXPORT void mo_ant_substep(const mms_model* M, float h, float* root, float* d
 MO_EXPORT void mo_box_substep(const mms_model* M, float h, float* root, const float* wrench) { box_substep(M, h, root, wrench); }
 MO_EXPORT void mo_heli_substep(const mms_model* M, float h, float* root, const float* thrust) {
     heli_substep(M, h, root, (const float(*)[3])thrust);
+}
+/* Diagnostics for the physics invariants: total momentum of one ant about the WORLD origin
+ * out[0..2] angular, out[3..5] linear, out[6] kinetic energy (incl. armature), out[7] potential energy. */
+MO_EXPORT void mo_ant_momentum(const mms_model* M, const float* root, const float* dofp, float* out) {
+    const float(*dof)[2] = (const float(*)[2])dofp;
+    float Rt[3][3];
+    quat_to_mat(root + 3, Rt);
+    float v0[6] = {root[10], root[11], root[12], root[7], root[8], root[9]};
+    const float zero3[3] = {0.f, 0.f, 0.f};
+    double hsum[6] = {0, 0, 0, 0, 0, 0}, ke = 0.0, pe = 0.0;
+    m66 I;
+    float Ic[3][3], h[6];
+    float ez[3] = {Rt[0][2], Rt[1][2], Rt[2][2]};
+    axisym_inertia(M->torso_izz, M->torso_ixx, ez, Ic);
+    spatial_inertia(M->torso_mass, zero3, Ic, I);
+    m66_mulv(I, v0, h);
+    for (int i = 0; i < 6; i++) { hsum[i] += h[i]; ke += 0.5 * h[i] * v0[i]; }
+    pe += (double)M->torso_mass * M->gravity * root[2];
+    for (int l = 0; l < 4; l++) {
+        float q1 = dof[2 * l][0], qd1 = dof[2 * l][1], q2 = dof[2 * l + 1][0], qd2 = dof[2 * l + 1][1];
+        float J1[3], a1[3] = {Rt[0][2], Rt[1][2], Rt[2][2]}, J2[3];
+        matvec3(Rt, M->hip_pos[l], J1);
+        float Rz[3][3], Rl[3][3], Ra[3][3], Rf[3][3];
+        const float zax[3] = {0.f, 0.f, 1.f};
+        axis_angle_to_mat(zax, q1, Rz);
+        matmul3(Rt, Rz, Rl);
+        float ul[3], a2[3], uf[3], cl[3], cf[3], t3[3], s1[6], s2[6], vl[6], vf[6];
+        matvec3(Rl, M->limb_dir[l], ul);
+        matvec3(Rl, M->ankle_axis[l], a2);
+        for (int i = 0; i < 3; i++) J2[i] = J1[i] + M->leg_len * ul[i];
+        axis_angle_to_mat(M->ankle_axis[l], q2, Ra);
+        matmul3(Rl, Ra, Rf);
+        matvec3(Rf, M->limb_dir[l], uf);
+        for (int i = 0; i < 3; i++) { cl[i] = J1[i] + 0.5f * M->leg_len * ul[i]; cf[i] = J2[i] + 0.5f * M->foot_len * uf[i]; }
+        cross3(J1, a1, t3);
+        for (int i = 0; i < 3; i++) { s1[i] = a1[i]; s1[3 + i] = t3[i]; }
+        cross3(J2, a2, t3);
+        for (int i = 0; i < 3; i++) { s2[i] = a2[i]; s2[3 + i] = t3[i]; }
+        for (int i = 0; i < 6; i++) { vl[i] = v0[i] + s1[i] * qd1; vf[i] = vl[i] + s2[i] * qd2; }
+        axisym_inertia(M->leg_ia, M->leg_it, ul, Ic);
+        spatial_inertia(M->leg_mass, cl, Ic, I);
+        m66_mulv(I, vl, h);
+        for (int i = 0; i < 6; i++) { hsum[i] += h[i]; ke += 0.5 * h[i] * vl[i]; }
+        axisym_inertia(M->foot_ia, M->foot_it, uf, Ic);
+        spatial_inertia(M->foot_mass, cf, Ic, I);
+        m66_mulv(I, vf, h);
+        for (int i = 0; i < 6; i++) { hsum[i] += h[i]; ke += 0.5 * h[i] * vf[i]; }
+        ke += 0.5 * M->armature * ((double)qd1 * qd1 + (double)qd2 * qd2);
+        pe += (double)M->leg_mass * M->gravity * (root[2] + cl[2]) + (double)M->foot_mass * M->gravity * (root[2] + cf[2]);
+    }
+    /* shift the angular momentum from the torso origin to the world origin: L_w = L_O + r x p */
+    double r[3] = {root[0], root[1], root[2]};
+    out[0] = (float)(hsum[0] + r[1] * hsum[5] - r[2] * hsum[4]);
+    out[1] = (float)(hsum[1] + r[2] * hsum[3] - r[0] * hsum[5]);
+    out[2] = (float)(hsum[2] + r[0] * hsum[4] - r[1] * hsum[3]);
+    out[3] = (float)hsum[3]; out[4] = (float)hsum[4]; out[5] = (float)hsum[5];
+    out[6] = (float)ke; out[7] = (float)pe;
 }
 MO_EXPORT int mo_abi_version(void) { return MMS_ABI_VERSION; }
 MO_EXPORT int mo_sizeof_config(void) { return (int)sizeof(mms_config); }

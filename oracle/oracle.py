@@ -54,6 +54,7 @@ def lib():
         _lib.mo_ant_substep.argtypes = [ctypes.POINTER(MmsModel), cf, F, F, F, F, F, F]
         _lib.mo_box_substep.argtypes = [ctypes.POINTER(MmsModel), cf, F, F]
         _lib.mo_heli_substep.argtypes = [ctypes.POINTER(MmsModel), cf, F, F]
+        _lib.mo_ant_momentum.argtypes = [ctypes.POINTER(MmsModel), F, F, F]
         assert _lib.mo_sizeof_config() == ctypes.sizeof(MmsConfig), "mms_config layout mismatch"
     return _lib
 

@@ -1,0 +1,251 @@
+"""Physics invariants of the build's own rigid-body model (oracle/mms_oracle.c).  There is no
+physics oracle in this pipeline (Isaac Gym is absent: parity unpinned), so the model is checked
+against first principles: free fall, momentum conservation, dissipation, joint limits, resting
+contact, friction, action-reaction with the box."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from massive_marl_benchmark_amd.model import make_config
+from oracle.oracle import OracleEngine, f32, fp, lib
+
+H = 0.0166 / 2
+
+
+def model(task="TenAnt", gravity=None):
+    c = make_config(task, num_envs=1)
+    if gravity is not None:
+        c.model.gravity = gravity
+    return c.model
+
+
+def ant_state(z=2.0, seed=0, qvel=0.0, vel=None, angvel=None):
+    rng = np.random.default_rng(seed)
+    m = model()
+    root = np.zeros(13, np.float32)
+    root[2] = z
+    root[6] = 1.0
+    if vel is not None:
+        root[7:10] = vel
+    if angvel is not None:
+        root[10:13] = angvel
+    dof = np.zeros((8, 2), np.float32)
+    lo, hi = np.array(m.dof_lower[:]), np.array(m.dof_upper[:])
+    dof[:, 0] = lo + (hi - lo) * (0.3 + 0.4 * rng.random(8))
+    dof[:, 1] = qvel * rng.standard_normal(8)
+    return root, dof
+
+
+def substep(m, root, dof, tau=None, box=None, n=1, h=H):
+    tau = f32(np.zeros(8) if tau is None else tau)
+    wrench = np.zeros(6, np.float32)
+    sens = np.zeros((4, 6), np.float32)
+    for _ in range(n):
+        lib().mo_ant_substep(ctypes.byref(m), h, fp(root), fp(dof), fp(tau), None if box is None else fp(box), fp(wrench), fp(sens))
+    return wrench, sens
+
+
+def momentum(m, root, dof):
+    out = np.zeros(8, np.float32)
+    lib().mo_ant_momentum(ctypes.byref(m), fp(root), fp(dof), fp(out))
+    return out
+
+
+def test_model_masses():
+    m = model()
+    assert abs(m.torso_mass - 0.48388) < 1e-4 and abs(m.leg_mass - 0.03916) < 1e-4 and abs(m.foot_mass - 0.06759) < 1e-4
+    total = m.torso_mass + 4 * (m.leg_mass + m.foot_mass)
+    assert abs(total - 0.91088) < 2e-4
+    assert abs(m.box_mass - 28.0) < 1e-6 and abs(model("OneAnt").box_mass - 1.0) < 1e-6
+    np.testing.assert_allclose(np.array(m.dof_init[:]), [0, 0.5236, 0, -0.5236, 0, -0.5236, 0, 0.5236], atol=1e-4)
+    np.testing.assert_allclose(np.degrees(np.array(m.dof_lower[:])), [-40, 30, -40, -100, -40, -100, -40, 30], atol=1e-3)
+
+
+def test_free_fall_and_linear_momentum():
+    m = model()
+    total = m.torso_mass + 4 * (m.leg_mass + m.foot_mass)
+    # no internal motion: a rigid falling ant; semi-implicit Euler is exact for a constant force
+    root, dof = ant_state(z=5.0, vel=[0.3, -0.2, 0.1])
+    dof[:, 1] = 0
+    p0 = momentum(m, root, dof)
+    n = 40
+    substep(m, root, dof, n=n)
+    p1 = momentum(m, root, dof)
+    np.testing.assert_allclose(p1[3:5], p0[3:5], atol=2e-5)
+    np.testing.assert_allclose(p1[5] - p0[5], -total * 9.81 * n * H, rtol=2e-4)
+    np.testing.assert_allclose(root[2], 5.0 + 0.1 * n * H - 0.5 * 9.81 * (n * H) ** 2 * (1 + 1.0 / n), rtol=1e-4)
+
+
+def test_momentum_error_is_first_order():
+    """With internal motion the reduced-coordinate first-order integrator conserves momentum only to O(h):
+    halving h halves the drift (this is what distinguishes integrator error from a wrong Coriolis term)."""
+    errs = []
+    for h, n in ((H, 40), (H / 2, 80), (H / 4, 160)):
+        m = model(gravity=0.0)
+        root, dof = ant_state(z=5.0, qvel=2.0, vel=[0.3, -0.2, 0.1], angvel=[0.5, -0.4, 0.3])
+        p0 = momentum(m, root, dof)
+        substep(m, root, dof, n=n, h=h)
+        errs.append(np.linalg.norm(momentum(m, root, dof)[:6] - p0[:6]))
+    assert errs[0] < 0.03
+    assert 0.4 < errs[1] / errs[0] < 0.6 and 0.4 < errs[2] / errs[1] < 0.6
+
+
+def test_energy_dissipates_without_actuation():
+    m = model(gravity=0.0)
+    root, dof = ant_state(z=5.0, qvel=5.0, angvel=[0.3, 0.2, -0.1])
+    e = [momentum(m, root, dof)[6]]
+    for _ in range(300):
+        substep(m, root, dof)
+        e.append(momentum(m, root, dof)[6])
+    e = np.array(e)
+    assert e[-1] < 0.5 * e[0]                                            # joint damping 0.1 dissipates
+    assert np.all(np.diff(e) < 1e-3 * e[0] + 1e-6)                        # never gains energy
+
+
+def test_torque_sign_and_magnitude():
+    m = model(gravity=0.0)
+    for j in range(8):
+        root, dof = ant_state(z=5.0)
+        tau = np.zeros(8, np.float32)
+        tau[j] = 1.5
+        q0 = dof[:, 1].copy()
+        substep(m, root, dof, tau=tau, n=1)
+        dq = dof[:, 1] - q0
+        assert dq[j] > 0 and abs(dq[j]) > 3 * np.max(np.abs(np.delete(dq, j)))
+        # joint-space inertia is dominated by the armature 0.01: qdd ~ tau / (0.01 + link inertia + h*damping)
+        assert 1.5 / 0.03 < dq[j] / H < 1.5 / 0.01
+
+
+def test_joint_limits_hold_under_full_torque():
+    m = model(gravity=0.0)
+    lo, hi = np.array(m.dof_lower[:]), np.array(m.dof_upper[:])
+    for sign in (1.0, -1.0):
+        root, dof = ant_state(z=5.0)
+        tau = f32(sign * 15.0 * np.ones(8))
+        worst = 0.0
+        for _ in range(300):
+            substep(m, root, dof, tau=tau)
+            worst = max(worst, np.max(dof[:, 0] - hi), np.max(lo - dof[:, 0]))
+        assert worst < 0.03                                               # < 1.7 degrees transient overshoot
+        lim = hi if sign > 0 else lo
+        assert np.max(np.abs(dof[:, 0] - lim)) < 0.005                    # static: 15 N m / k_limit = 3 mrad
+        assert np.max(np.abs(dof[:, 1])) < 0.05
+        assert np.isfinite(root).all()
+
+
+def test_rest_on_ground():
+    m = model()
+    root, dof = ant_state(z=0.8)
+    dof[:, 0] = [0, 0.9, 0, -0.9, 0, -0.9, 0, 0.9]
+    dof[:, 1] = 0
+    # hold the pose with a stiff PD through the torque input
+    q_ref = dof[:, 0].copy()
+    zs = []
+    for t in range(600):
+        tau = np.clip(40.0 * (q_ref - dof[:, 0]) - 1.0 * dof[:, 1], -15, 15)
+        _, sens = substep(m, root, dof, tau=tau)
+        zs.append(root[2])
+    assert np.isfinite(root).all()
+    assert np.max(np.abs(root[7:13])) < 0.02 and np.max(np.abs(dof[:, 1])) < 0.05      # at rest
+    assert np.std(zs[-100:]) < 1e-4                                                     # no jitter
+    # geometric standing height: foot tips on the ground, ankles ~0.9 rad
+    tip_drop = 0.5657 * np.sin(np.mean(np.abs(dof[:, 0][1::2])))
+    assert abs(root[2] - (tip_drop + 0.08)) < 0.01
+    # the four feet carry the weight (sensor z force, foot frame is tilted: compare magnitudes)
+    total = m.torso_mass + 4 * (m.leg_mass + m.foot_mass)
+    fsum = np.sum(np.linalg.norm(sens[:, :3], axis=1))
+    assert abs(fsum - total * 9.81) < 0.15 * total * 9.81
+
+
+def test_friction_stops_sliding():
+    m = model()
+    root, dof = ant_state(z=0.8)
+    dof[:, 0] = [0, 0.9, 0, -0.9, 0, -0.9, 0, 0.9]
+    q_ref = dof[:, 0].copy()
+    for t in range(300):
+        tau = np.clip(40.0 * (q_ref - dof[:, 0]) - 1.0 * dof[:, 1], -15, 15)
+        substep(m, root, dof, tau=tau)
+    root[7] = 1.0                                                         # shove it sideways at 1 m/s
+    x0 = root[0]
+    for t in range(300):
+        tau = np.clip(40.0 * (q_ref - dof[:, 0]) - 1.0 * dof[:, 1], -15, 15)
+        substep(m, root, dof, tau=tau)
+    assert abs(root[7]) < 0.03                                            # Coulomb friction mu = 1 stops it
+    assert 0.0 < root[0] - x0 < 0.3                                       # v^2 / (2 mu g) = 5 cm, plus leg compliance
+
+
+def test_box_slides_without_friction_and_rests():
+    m = model()
+    box = np.zeros(13, np.float32)
+    box[2], box[6], box[7] = 1.0, 1.0, 0.7
+    w = np.zeros(6, np.float32)
+    for _ in range(400):
+        lib().mo_box_substep(ctypes.byref(m), H, fp(box), fp(w))
+    assert abs(box[7] - 0.7) < 1e-5                                       # frictionless: keeps its speed
+    assert abs(box[2] - 0.5) < 2e-3 and abs(box[9]) < 1e-3                 # rests on the ground, 1 m tall
+    assert np.max(np.abs(box[10:13])) < 1e-3
+
+
+def test_ant_box_action_reaction():
+    """Total linear momentum of ant + box is conserved through their contact (no gravity, no ground)."""
+    m = model(gravity=0.0)
+    root, dof = ant_state(z=5.0)
+    dof[:, 1] = 0
+    root[0:3] = [1.0, 0.0, 5.0]
+    root[7] = -1.0                                                        # flies into the box face at x = 0.5
+    box = np.zeros(13, np.float32)
+    box[0:3], box[6] = [0.0, 0.0, 5.0], 1.0
+    total = m.torso_mass + 4 * (m.leg_mass + m.foot_mass)
+    p0 = momentum(m, root, dof)[3:6]
+    touched = False
+    for _ in range(200):
+        w, _ = substep(m, root, dof, box=box)
+        touched |= bool(np.any(w != 0))
+        lib().mo_box_substep(ctypes.byref(m), H, fp(box), fp(w))
+    p1 = momentum(m, root, dof)[3:6] + m.box_mass * box[7:10]
+    assert touched
+    np.testing.assert_allclose(p1, p0, atol=2e-3 * total)
+    assert box[7] < -1e-3                                                 # the box was pushed
+    assert root[0] - 0.25 > box[0] + 0.5 - 0.02                           # torso sphere does not tunnel
+
+
+def test_tenant_engine_long_run_is_finite_and_resets():
+    eng = OracleEngine("TenAnt", num_envs=8, seed=3)
+    rng = np.random.default_rng(0)
+    resets = 0
+    for t in range(400):
+        eng.step(f32(rng.uniform(-1, 1, (8, 80))))
+        resets += int(eng.tensor("reset").sum())
+        assert np.isfinite(eng.tensor("obs")).all() and np.isfinite(eng.tensor("rew")).all()
+    r = eng.tensor("root_states").reshape(8, 11, 13)
+    assert np.all(r[:, :10, 2] > 0.0) and np.all(r[:, :10, 2] < 2.0)
+    settled = eng.tensor("progress") > 40                                  # a reset drops the box from z = 1 again
+    assert settled.any() and np.max(np.abs(r[settled, 10, 2] - 0.5)) < 0.02   # box stays on the ground
+    assert resets > 0                                                      # terminationHeight 0.31 fires under random torques
+    lo, hi = np.array(eng.config.model.dof_lower[:]), np.array(eng.config.model.dof_upper[:])
+    q = eng.tensor("dof_state").reshape(8, 10, 8, 2)[..., 0]
+    assert np.max(q - hi) < 0.05 and np.max(lo - q) < 0.05
+
+
+def test_ingenuity_hover_and_thrust():
+    c = make_config("MultiIngenuity", num_envs=1)
+    m = c.model
+    root = np.zeros(13, np.float32)
+    root[2], root[6] = 1.0, 1.0
+    hover = m.heli_mass * 3.721 / 2.0
+    thr = f32([[0, 0, hover], [0, 0, hover]])
+    for _ in range(200):
+        lib().mo_heli_substep(ctypes.byref(m), H, fp(root), fp(thr))
+    assert abs(root[2] - 1.0) < 1e-3 and np.max(np.abs(root[7:13])) < 1e-3    # thrust = weight -> hovers
+    thr = f32([[0, 0, 0], [0, 0, 0]])
+    for _ in range(20):
+        lib().mo_heli_substep(ctypes.byref(m), H, fp(root), fp(thr))
+    assert abs(root[9] + 3.721 * 20 * H) < 1e-3                               # Mars gravity free fall
+    # lateral thrust on the upper rotor tilts the body
+    root[:] = 0
+    root[2], root[6] = 1.0, 1.0
+    thr = f32([[0, 0, hover], [0.2 * hover, 0, hover]])
+    for _ in range(20):
+        lib().mo_heli_substep(ctypes.byref(m), H, fp(root), fp(thr))
+    assert root[7] > 0 and root[11] != 0
