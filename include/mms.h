@@ -60,9 +60,9 @@ typedef struct mms_model {
     float limb_dir[4][3];                /* unit capsule direction of leg and foot at q = 0 */
     float ankle_axis[4][3];              /* unit ankle axis in the leg frame */
     float dof_lower[8], dof_upper[8], dof_init[8], gear[8];
-    float armature, joint_damping, limit_k, limit_c;
+    float armature, joint_damping, limit_k, limit_c, limit_ramp;
     /* contact (compliant, linearly-implicit) */
-    float gnd_k, gnd_c, gnd_mu, slip_eps;
+    float gnd_k, gnd_c, gnd_mu, slip_eps, pen_ramp;
     float antbox_k, antbox_c;
     float boxgnd_k, boxgnd_c;
     /* box */
@@ -137,6 +137,10 @@ int mms_reset_all(mms_handle h, void* hip_stream);
  * Tests / fixtures only. */
 int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_host,
                   const int64_t* env_ids, int64_t n, void* hip_stream);
+
+/* Sets the engine's step counter (keys the reset-noise RNG; 0 also re-initialises the caches from the
+ * construction-time poses on the next step).  Tests only. */
+int mms_set_step_index(mms_handle h, uint64_t step_index);
 
 /* Optional extra destination for the clamped observation row, e.g. slot t of a rollout buffer
  * [T,N,obs_dim]; NULL disables.  The pointer must stay valid until the next bind. */

@@ -1,0 +1,289 @@
+// mms_api.hip -- the C ABI of include/mms.h: engine lifetime, named device buffers, launches.
+// Host side only allocates, fills the construction-time scene (what create_sim .. prepare_sim do in the
+// reference, agents/tasks/ten_ant.py:205-633) and enqueues kernels on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mms.h"
+#include "step_args.h"
+
+namespace mms {
+hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream);
+hipError_t launch_gae_ppo(const float*, const uint8_t*, const float*, const float*, float*, float*, double*, int, int64_t, float, float, hipStream_t);
+hipError_t launch_adv_normalize(float*, const double*, int64_t, hipStream_t);
+hipError_t launch_gae_marl(const float*, const float*, const float*, float*, int, int64_t, float, float, int, const float*, const float*, hipStream_t);
+hipError_t launch_marl_views(const float*, float*, int64_t, int, int, int, hipStream_t);
+}  // namespace mms
+
+struct mms_buffer {
+    const char* name;
+    void* ptr;
+    int64_t shape[4];
+    int ndim;
+    int dtype;
+    size_t bytes;
+    int64_t row_bytes;   // bytes per env (for indexed set_state); 0 if not per-env
+};
+
+struct mms_engine {
+    mms_config cfg;
+    mms_config* d_cfg = nullptr;
+    int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
+    uint64_t step_index = 0;
+    float* obs_out = nullptr;
+    std::vector<mms_buffer> bufs;
+    std::string err;
+};
+
+static std::string g_create_error;
+
+static size_t dtype_size(int dt) { return dt == MMS_F32 ? 4 : dt == MMS_I64 ? 8 : dt == MMS_I32 ? 4 : 1; }
+
+static int fail(mms_engine* e, const std::string& msg) {
+    if (e) e->err = msg; else g_create_error = msg;
+    return 1;
+}
+#define MMS_HIP(e, call)                                                                              \
+    do {                                                                                              \
+        hipError_t err_ = (call);                                                                     \
+        if (err_ != hipSuccess) return fail(e, std::string(#call) + ": " + hipGetErrorString(err_));  \
+    } while (0)
+
+static mms_buffer* find(mms_engine* e, const char* name) {
+    for (auto& b : e->bufs)
+        if (!strcmp(b.name, name)) return &b;
+    return nullptr;
+}
+
+static int add_buffer(mms_engine* e, const char* name, int dtype, std::initializer_list<int64_t> shape, int64_t rows_per_env) {
+    mms_buffer b{};
+    b.name = name;
+    b.dtype = dtype;
+    b.ndim = (int)shape.size();
+    size_t n = 1;
+    int i = 0;
+    for (int64_t s : shape) { b.shape[i++] = s; n *= (size_t)s; }
+    b.bytes = n * dtype_size(dtype);
+    b.row_bytes = (rows_per_env > 0) ? (int64_t)(b.bytes / (size_t)e->cfg.num_envs) : 0;
+    size_t alloc = b.bytes ? b.bytes : 16;
+    MMS_HIP(e, hipMalloc(&b.ptr, alloc));
+    MMS_HIP(e, hipMemset(b.ptr, 0, alloc));
+    e->bufs.push_back(b);
+    return 0;
+}
+
+extern "C" {
+
+int mms_abi_version(void) { return MMS_ABI_VERSION; }
+
+const char* mms_last_error(mms_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mms_create(const mms_config* cfg, mms_handle* out) {
+    if (!cfg || !out) return fail(nullptr, "mms_create: null argument");
+    if (cfg->abi_version != MMS_ABI_VERSION) return fail(nullptr, "mms_create: ABI version mismatch");
+    if (cfg->num_envs <= 0 || cfg->num_agents <= 0) return fail(nullptr, "mms_create: num_envs and num_agents must be positive");
+    if (cfg->device < 0) return fail(nullptr, "mms_create: this engine has no CPU path; device must be a HIP ordinal >= 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "mms_create: no HIP device available (no CPU fallback)");
+    if (cfg->device >= ndev) return fail(nullptr, "mms_create: device ordinal out of range");
+    if (cfg->task == MMS_TASK_MULTI_INGENUITY && cfg->num_agents != 4) return fail(nullptr, "mms_create: MultiIngenuity has 4 helicopters per env");
+    if (cfg->task == MMS_TASK_ONE_ANT && cfg->num_agents != 1) return fail(nullptr, "mms_create: OneAnt has one ant per env");
+    if (cfg->task != MMS_TASK_MULTI_INGENUITY && ((4 * cfg->num_agents + 7) & ~7) + 8 > 512)
+        return fail(nullptr, "mms_create: at most 126 ants per env");
+    MMS_HIP(nullptr, hipSetDevice(cfg->device));
+    mms_engine* e = new mms_engine();
+    e->cfg = *cfg;
+    const int N = cfg->num_envs, A = cfg->num_agents;
+    if (cfg->task == MMS_TASK_TEN_ANT) { e->actors = A + 1; e->dofs = 8 * A; e->num_actions = 8 * A; e->obs_dim = 38 * A + 8; e->prev_dim = 4 * A + 2; }
+    else if (cfg->task == MMS_TASK_ONE_ANT) { e->actors = 2; e->dofs = 8; e->num_actions = 8; e->obs_dim = 60; e->prev_dim = 6; }
+    else if (cfg->task == MMS_TASK_MULTI_INGENUITY) { e->actors = A; e->dofs = 4 * A; e->num_actions = 6 * A; e->obs_dim = 13 * A; e->prev_dim = 3 * A; }
+    else { delete e; return fail(nullptr, "mms_create: unknown task"); }
+    int rc = 0;
+    rc |= add_buffer(e, "actions", MMS_F32, {N, e->num_actions}, 1);
+    rc |= add_buffer(e, "obs", MMS_F32, {N, e->obs_dim}, 1);
+    rc |= add_buffer(e, "obs_clipped", MMS_F32, {N, e->obs_dim}, 1);
+    rc |= add_buffer(e, "rew", MMS_F32, {N}, 1);
+    rc |= add_buffer(e, "reset", MMS_I64, {N}, 1);
+    rc |= add_buffer(e, "progress", MMS_I64, {N}, 1);
+    rc |= add_buffer(e, "root_states", MMS_F32, {(int64_t)N * e->actors, 13}, 1);
+    rc |= add_buffer(e, "initial_root_states", MMS_F32, {(int64_t)N * e->actors, 13}, 1);
+    rc |= add_buffer(e, "dof_state", MMS_F32, {(int64_t)N * e->dofs, 2}, 1);
+    rc |= add_buffer(e, "env_origin", MMS_F32, {N, 3}, 1);
+    rc |= add_buffer(e, "prev", MMS_F32, {N, e->prev_dim}, 1);
+    rc |= add_buffer(e, "reset_noise", MMS_F32, {N, 16}, 1);
+    rc |= add_buffer(e, "foot_sensors", MMS_F32, {(int64_t)N * A, 24}, 1);
+    if (rc) { g_create_error = e->err; mms_destroy(e); return 1; }
+
+    // construction-time scene (host), uploaded once
+    std::vector<float> init((size_t)N * e->actors * 13, 0.f), origin((size_t)N * 3, 0.f);
+    std::vector<int64_t> ones((size_t)N, 1);
+    int64_t npr = (int64_t)sqrt((double)cfg->total_envs);
+    if (npr < 1) npr = 1;
+    for (int i = 0; i < N; i++) {
+        int64_t gi = cfg->env_offset + i;
+        origin[3 * (size_t)i + 0] = (float)(gi % npr) * 2.f * cfg->env_spacing;   // env grid: SURVEY.md B.2 convention
+        origin[3 * (size_t)i + 1] = (float)(gi / npr) * 2.f * cfg->env_spacing;
+        float* r = init.data() + (size_t)i * e->actors * 13;
+        for (int k = 0; k < e->actors; k++) r[13 * k + 6] = 1.f;
+        if (cfg->task != MMS_TASK_MULTI_INGENUITY) {
+            for (int k = 0; k < A; k++) {                                        // ten_ant.py:339-358 / one_ant.py:234
+                float off = (A == 1) ? 0.f : (1.5f + 3.f * (float)(k / 2)) * ((k % 2 == 0) ? -1.f : 1.f);
+                r[13 * k + 0] = cfg->ant_start_x; r[13 * k + 1] = off; r[13 * k + 2] = cfg->ant_start_z;
+            }
+            for (int j = 0; j < 3; j++) r[13 * A + j] = cfg->box_start[j];       // ten_ant.py:494-495
+        } else {
+            static const float hy[4] = {2.f, -2.f, 6.f, -6.f};                   // multi_ingenuity.py:157-164
+            for (int k = 0; k < A; k++) { r[13 * k + 0] = 0.f; r[13 * k + 1] = hy[k % 4]; r[13 * k + 2] = 1.f; }
+        }
+    }
+    hipError_t he = hipSuccess;
+    auto up = [&](const char* name, const void* src, size_t bytes) {
+        if (he == hipSuccess) he = hipMemcpy(find(e, name)->ptr, src, bytes, hipMemcpyHostToDevice);
+    };
+    up("initial_root_states", init.data(), init.size() * 4);
+    up("root_states", init.data(), init.size() * 4);
+    up("env_origin", origin.data(), origin.size() * 4);
+    up("reset", ones.data(), ones.size() * 8);                                   // base_task.py:62-63
+    if (he == hipSuccess) he = hipMalloc((void**)&e->d_cfg, sizeof(mms_config));
+    if (he == hipSuccess) he = hipMemcpy(e->d_cfg, &e->cfg, sizeof(mms_config), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    if (he != hipSuccess) { g_create_error = std::string("mms_create: ") + hipGetErrorString(he); mms_destroy(e); return 1; }
+    *out = e;
+    return 0;
+}
+
+int mms_destroy(mms_handle h) {
+    if (!h) return 0;
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    for (auto& b : h->bufs)
+        if (b.ptr) hipFree(b.ptr);
+    if (h->d_cfg) hipFree(h->d_cfg);
+    delete h;
+    return 0;
+}
+
+int mms_get_tensor(mms_handle h, const char* name, mms_tensor* out) {
+    if (!h || !name || !out) return fail(h, "mms_get_tensor: null argument");
+    mms_buffer* b = find(h, name);
+    if (!b) return fail(h, std::string("mms_get_tensor: unknown buffer '") + name + "'");
+    memset(out, 0, sizeof(*out));
+    out->ptr = b->ptr;
+    for (int i = 0; i < b->ndim; i++) out->shape[i] = b->shape[i];
+    out->ndim = b->ndim;
+    out->dtype = b->dtype;
+    out->device = h->cfg.device;
+    return 0;
+}
+
+static int do_step(mms_handle h, void* stream, int physics) {
+    if (!h) return fail(nullptr, "mms_step: null handle");
+    mms::StepArgs a{};
+    a.cfg = h->d_cfg;
+    a.actions = (const float*)find(h, "actions")->ptr;
+    a.obs = (float*)find(h, "obs")->ptr;
+    a.obs_clipped = (float*)find(h, "obs_clipped")->ptr;
+    a.obs_out = h->obs_out;
+    a.rew = (float*)find(h, "rew")->ptr;
+    a.reset = (int64_t*)find(h, "reset")->ptr;
+    a.progress = (int64_t*)find(h, "progress")->ptr;
+    a.root_states = (float*)find(h, "root_states")->ptr;
+    a.initial_root_states = (const float*)find(h, "initial_root_states")->ptr;
+    a.dof_state = (float*)find(h, "dof_state")->ptr;
+    a.env_origin = (const float*)find(h, "env_origin")->ptr;
+    a.prev = (float*)find(h, "prev")->ptr;
+    a.reset_noise = (const float*)find(h, "reset_noise")->ptr;
+    a.foot_sensors = (float*)find(h, "foot_sensors")->ptr;
+    a.step_index = h->step_index;
+    a.do_physics = physics;
+    a.num_envs = h->cfg.num_envs;
+    a.num_agents = h->cfg.num_agents;
+    a.obs_dim = h->obs_dim;
+    a.prev_dim = h->prev_dim;
+    MMS_HIP(h, mms::launch_step(a, h->cfg.task, (hipStream_t)stream));
+    h->step_index += 1;
+    return 0;
+}
+int mms_step(mms_handle h, void* hip_stream) { return do_step(h, hip_stream, 1); }
+int mms_post_step(mms_handle h, void* hip_stream) { return do_step(h, hip_stream, 0); }
+
+int mms_reset_all(mms_handle h, void* hip_stream) {
+    if (!h) return fail(nullptr, "mms_reset_all: null handle");
+    std::vector<int64_t> ones((size_t)h->cfg.num_envs, 1);
+    MMS_HIP(h, hipMemcpyAsync(find(h, "reset")->ptr, ones.data(), ones.size() * 8, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    MMS_HIP(h, hipStreamSynchronize((hipStream_t)hip_stream));   // `ones` is a temporary
+    return 0;
+}
+
+int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_host, const int64_t* env_ids, int64_t n, void* hip_stream) {
+    if (!h || !name || !src) return fail(h, "mms_set_state: null argument");
+    mms_buffer* b = find(h, name);
+    if (!b) return fail(h, std::string("mms_set_state: unknown buffer '") + name + "'");
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipMemcpyKind kind = src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    if (!env_ids) {
+        MMS_HIP(h, hipMemcpyAsync(b->ptr, src, b->bytes, kind, s));
+    } else {
+        if (b->row_bytes <= 0) return fail(h, "mms_set_state: buffer is not per-env");
+        for (int64_t i = 0; i < n; i++) {
+            if (env_ids[i] < 0 || env_ids[i] >= h->cfg.num_envs) return fail(h, "mms_set_state: env id out of range");
+            MMS_HIP(h, hipMemcpyAsync((char*)b->ptr + env_ids[i] * b->row_bytes, (const char*)src + i * b->row_bytes, (size_t)b->row_bytes, kind, s));
+        }
+    }
+    if (src_is_host) MMS_HIP(h, hipStreamSynchronize(s));
+    return 0;
+}
+
+int mms_bind_obs_out(mms_handle h, void* dst) {
+    if (!h) return fail(nullptr, "mms_bind_obs_out: null handle");
+    h->obs_out = (float*)dst;
+    return 0;
+}
+
+int mms_set_step_index(mms_handle h, uint64_t step_index) {
+    if (!h) return 1;
+    h->step_index = step_index;
+    return 0;
+}
+
+static int dev_guard(int device) {
+    if (device < 0) { g_create_error = "no CPU path: device must be a HIP ordinal"; return 1; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return 1; }
+    return 0;
+}
+#define MMS_FREE(call)                                                                                 \
+    do {                                                                                               \
+        hipError_t err_ = (call);                                                                      \
+        if (err_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(err_); return 1; } \
+    } while (0)
+
+int mms_marl_views(int device, const float* obs_clipped, float* obs_all, int64_t n, int32_t agents, int32_t per_agent, int32_t shared, void* s) {
+    if (dev_guard(device)) return 1;
+    MMS_FREE(mms::launch_marl_views(obs_clipped, obs_all, n, agents, per_agent, shared, (hipStream_t)s));
+    return 0;
+}
+int mms_gae_ppo(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
+                float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam, void* s) {
+    if (dev_guard(device)) return 1;
+    MMS_FREE(mms::launch_gae_ppo(rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam, (hipStream_t)s));
+    return 0;
+}
+int mms_adv_normalize(int device, float* advantages, const double* stats, int64_t count, void* s) {
+    if (dev_guard(device)) return 1;
+    MMS_FREE(mms::launch_adv_normalize(advantages, stats, count, (hipStream_t)s));
+    return 0;
+}
+int mms_gae_marl(int device, const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int64_t N,
+                 float gamma, float lam, int32_t use_norm, const float* norm_mean, const float* norm_var, void* s) {
+    if (dev_guard(device)) return 1;
+    MMS_FREE(mms::launch_gae_marl(rewards, value_preds, masks, returns, T, N, gamma, lam, use_norm, norm_mean, norm_var, (hipStream_t)s));
+    return 0;
+}
+
+}  // extern "C"

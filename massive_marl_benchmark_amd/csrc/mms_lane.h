@@ -1,0 +1,839 @@
+// mms_lane.h -- per-lane math of the step kernels (gfx950), written so that the same source also
+// compiles for the host: tests/emu builds it with g++ to check the lane decomposition against the
+// oracle on the CPU before any GPU time is spent.  No HIP builtins in this file.
+//
+// Decomposition: one workgroup per environment.  Lane (ant a, leg l) = 4a + l owns
+// one leg chain (leg + foot bodies, 2 DOF, 3 contact spheres) and a replica of its ant's torso state;
+// the 4 lanes of a quad combine their articulated inertias with two DPP quad-permutes; 8 further
+// lanes own the box corners.  Math follows oracle/mms_oracle.c (the model definition) term by term;
+// reference call sites are cited there.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mms.h"
+
+#if defined(__HIPCC__)
+#define MMS_HD __host__ __device__ __forceinline__
+#else
+#define MMS_HD inline
+#endif
+
+namespace mms {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr float kContactMargin = 0.1f;
+constexpr float kMaxAngVel = 64.f;
+
+// ---------------------------------------------------------------------------------------------
+// small vectors
+// ---------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+MMS_HD V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+MMS_HD V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MMS_HD V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MMS_HD V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+MMS_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MMS_HD V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+MMS_HD float clampf(float x, float lo, float hi) { return fmaxf(fminf(x, hi), lo); }
+// damper ramp: c(d) = c * clamp(d / r, 0, 1) keeps the contact force continuous at activation
+MMS_HD float ramp01(float d, float r) { return fminf(fmaxf(d / r, 0.f), 1.f); }
+
+struct M3 { V3 c0, c1, c2; };   // columns
+MMS_HD V3 mul(const M3& R, V3 v) { return v.x * R.c0 + v.y * R.c1 + v.z * R.c2; }
+MMS_HD V3 mulT(const M3& R, V3 v) { return V3{dot(R.c0, v), dot(R.c1, v), dot(R.c2, v)}; }
+MMS_HD M3 mul(const M3& A, const M3& B) { return M3{mul(A, B.c0), mul(A, B.c1), mul(A, B.c2)}; }
+MMS_HD M3 quat_to_mat(float x, float y, float z, float w) {
+    M3 R;
+    R.c0 = V3{1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y)};
+    R.c1 = V3{2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x)};
+    R.c2 = V3{2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y)};
+    return R;
+}
+MMS_HD M3 axis_angle_to_mat(V3 a, float ang) {
+    float c = cosf(ang), s = sinf(ang), t = 1.f - c;
+    M3 R;
+    R.c0 = V3{c + t * a.x * a.x, t * a.x * a.y + s * a.z, t * a.x * a.z - s * a.y};
+    R.c1 = V3{t * a.x * a.y - s * a.z, c + t * a.y * a.y, t * a.y * a.z + s * a.x};
+    R.c2 = V3{t * a.x * a.z + s * a.y, t * a.y * a.z - s * a.x, c + t * a.z * a.z};
+    return R;
+}
+
+// spatial 6-vector: angular part a, linear part l
+struct S6 { V3 a, l; };
+MMS_HD S6 operator+(S6 p, S6 q) { return S6{p.a + q.a, p.l + q.l}; }
+MMS_HD S6 operator*(float s, S6 p) { return S6{s * p.a, s * p.l}; }
+MMS_HD float dot(S6 p, S6 q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+MMS_HD float get(const S6& p, int i) { return i == 0 ? p.a.x : i == 1 ? p.a.y : i == 2 ? p.a.z : i == 3 ? p.l.x : i == 4 ? p.l.y : p.l.z; }
+MMS_HD S6 cross_motion(S6 a, S6 b) { return S6{cross(a.a, b.a), cross(a.a, b.l) + cross(a.l, b.a)}; }
+
+// symmetric 6x6, upper triangle row-major (21 values); every index below is a compile-time constant
+// once the loops are unrolled, so the matrix lives in registers.
+constexpr int sidx(int i, int j) { return i <= j ? i * 6 - i * (i - 1) / 2 + (j - i) : j * 6 - j * (j - 1) / 2 + (i - j); }
+struct Sym6 { float m[21]; };
+MMS_HD void sym_zero(Sym6& A) {
+#pragma unroll
+    for (int k = 0; k < 21; k++) A.m[k] = 0.f;
+}
+MMS_HD void sym_add(Sym6& A, const Sym6& B) {
+#pragma unroll
+    for (int k = 0; k < 21; k++) A.m[k] += B.m[k];
+}
+MMS_HD S6 sym_mul(const Sym6& A, S6 v) {
+    float in[6] = {v.a.x, v.a.y, v.a.z, v.l.x, v.l.y, v.l.z}, o[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; j++) s += A.m[sidx(i, j)] * in[j];
+        o[i] = s;
+    }
+    return S6{V3{o[0], o[1], o[2]}, V3{o[3], o[4], o[5]}};
+}
+// A += s * w w^T
+MMS_HD void sym_rank1(Sym6& A, float s, S6 w) {
+    float in[6] = {w.a.x, w.a.y, w.a.z, w.l.x, w.l.y, w.l.z};
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) A.m[sidx(i, j)] += s * in[i] * in[j];
+}
+
+// spatial inertia about the frame origin of an axisymmetric body: mass m, COM c, unit axis u,
+// axial / transverse inertia ia / it about the COM
+MMS_HD void spatial_inertia_axisym(float m, V3 c, V3 u, float ia, float it, Sym6& I) {
+    float cc = dot(c, c), d = ia - it;
+    float cv[3] = {c.x, c.y, c.z}, uv[3] = {u.x, u.y, u.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) {
+            float ic = (i == j ? it : 0.f) + d * uv[i] * uv[j];
+            I.m[sidx(i, j)] = ic + m * ((i == j ? cc : 0.f) - cv[i] * cv[j]);
+            I.m[sidx(3 + i, 3 + j)] = (i == j) ? m : 0.f;
+        }
+    // top-right block m [c]x
+    I.m[sidx(0, 3)] = 0.f;        I.m[sidx(0, 4)] = -m * c.z;  I.m[sidx(0, 5)] = m * c.y;
+    I.m[sidx(1, 3)] = m * c.z;    I.m[sidx(1, 4)] = 0.f;       I.m[sidx(1, 5)] = -m * c.x;
+    I.m[sidx(2, 3)] = -m * c.y;   I.m[sidx(2, 4)] = m * c.x;   I.m[sidx(2, 5)] = 0.f;
+}
+// general symmetric 3x3 rotational inertia (box, helicopter): Iw = R diag(d) R^T
+MMS_HD void spatial_inertia_diag(float m, V3 c, const M3& R, V3 d, Sym6& I) {
+    float cc = dot(c, c);
+    float cv[3] = {c.x, c.y, c.z};
+    float r0[3] = {R.c0.x, R.c1.x, R.c2.x}, r1[3] = {R.c0.y, R.c1.y, R.c2.y}, r2[3] = {R.c0.z, R.c1.z, R.c2.z};
+    const float* rows[3] = {r0, r1, r2};
+    float dv[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) {
+            float ic = rows[i][0] * dv[0] * rows[j][0] + rows[i][1] * dv[1] * rows[j][1] + rows[i][2] * dv[2] * rows[j][2];
+            I.m[sidx(i, j)] = ic + m * ((i == j ? cc : 0.f) - cv[i] * cv[j]);
+            I.m[sidx(3 + i, 3 + j)] = (i == j) ? m : 0.f;
+        }
+    I.m[sidx(0, 3)] = 0.f;        I.m[sidx(0, 4)] = -m * c.z;  I.m[sidx(0, 5)] = m * c.y;
+    I.m[sidx(1, 3)] = m * c.z;    I.m[sidx(1, 4)] = 0.f;       I.m[sidx(1, 5)] = -m * c.x;
+    I.m[sidx(2, 3)] = -m * c.y;   I.m[sidx(2, 4)] = m * c.x;   I.m[sidx(2, 5)] = 0.f;
+}
+// bias force p = v x* (I v) - (c x m g, m g),  g = (0, 0, -grav)
+MMS_HD S6 bias_force(const Sym6& I, S6 v, float m, V3 c, float grav) {
+    S6 h = sym_mul(I, v);
+    V3 fg = V3{0.f, 0.f, -m * grav};
+    V3 ng = cross(c, fg);
+    S6 p;
+    p.a = cross(v.a, h.a) + cross(v.l, h.l) - ng;
+    p.l = cross(v.a, h.l) - fg;
+    return p;
+}
+// LDL^T solve of a symmetric positive definite 6x6 system
+MMS_HD S6 solve6(const Sym6& A, S6 bv) {
+    float b[6] = {bv.a.x, bv.a.y, bv.a.z, bv.l.x, bv.l.y, bv.l.z};
+    float L[6][6], D[6], y[6], x[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        float d = A.m[sidx(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
+        D[j] = d;
+        float inv = 1.f / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            float s = A.m[sidx(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k] * D[k];
+            L[i][j] = s * inv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[i][k] * y[k];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        float s = y[i] / D[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k];
+        x[i] = s;
+    }
+    return S6{V3{x[0], x[1], x[2]}, V3{x[3], x[4], x[5]}};
+}
+
+// ---------------------------------------------------------------------------------------------
+// contacts (oracle: contact_t / sphere_contacts / contact_fold / contact_force)
+// ---------------------------------------------------------------------------------------------
+struct Contact {
+    float active;   // 0 / 1
+    V3 xc, n, vrel;
+    float kd, gn, ct;
+};
+MMS_HD Contact contact_none() { return Contact{0.f, V3{0, 0, 0}, V3{0, 0, 1}, V3{0, 0, 0}, 0.f, 0.f, 0.f}; }
+
+// I^A += h P^T G P, p^A -= P^T (kd n - G vrel);  G = (gn - ct) n n^T + ct 1
+MMS_HD void contact_fold(const Contact& c, float h, Sym6& IA, S6& pA) {
+    if (c.active == 0.f) return;
+    S6 wn = S6{cross(c.xc, c.n), c.n};
+    sym_rank1(IA, h * (c.gn - c.ct), wn);
+    if (c.ct != 0.f) {
+        float hc = h * c.ct;
+        sym_rank1(IA, hc, S6{cross(c.xc, V3{1, 0, 0}), V3{1, 0, 0}});
+        sym_rank1(IA, hc, S6{cross(c.xc, V3{0, 1, 0}), V3{0, 1, 0}});
+        sym_rank1(IA, hc, S6{cross(c.xc, V3{0, 0, 1}), V3{0, 0, 1}});
+    }
+    float vn = dot(c.n, c.vrel);
+    V3 f0 = (c.kd - (c.gn - c.ct) * vn) * c.n - c.ct * c.vrel;
+    pA.a = pA.a - cross(c.xc, f0);
+    pA.l = pA.l - f0;
+}
+// f = kd n - G (vrel + h (a_lin + alpha x xc))
+MMS_HD V3 contact_force(const Contact& c, float h, S6 acc) {
+    if (c.active == 0.f) return V3{0, 0, 0};
+    V3 u = c.vrel + h * (acc.l + cross(acc.a, c.xc));
+    float un = dot(c.n, u);
+    return (c.kd - (c.gn - c.ct) * un) * c.n - c.ct * u;
+}
+
+struct BoxPose { V3 pos; M3 R; V3 v, w, half; };
+
+// sphere at xs (relative to the spatial origin at world position Ow) on a body with spatial velocity vb
+MMS_HD Contact sphere_ground(float k, float cdamp, float mu, float slip_eps, float pen_ramp, float h, V3 Ow, V3 xs, float rad, S6 vb) {
+    Contact c = contact_none();
+    float d = rad - (Ow.z + xs.z);
+    if (d > -kContactMargin) {
+        V3 xc = V3{xs.x, xs.y, xs.z - rad};
+        V3 vp = vb.l + cross(vb.a, xc);
+        float gn = h * k + cdamp * ramp01(d, pen_ramp);
+        float fn = fmaxf(k * d - gn * vp.z, 0.f);
+        if (d > 0.f || d - h * vp.z > 0.f) {
+            c.active = 1.f;
+            c.xc = xc;
+            c.n = V3{0.f, 0.f, 1.f};
+            c.kd = k * d;
+            c.gn = gn;
+            float vt = sqrtf(vp.x * vp.x + vp.y * vp.y);
+            c.ct = mu * fn / fmaxf(vt, slip_eps);
+            c.vrel = vp;
+        }
+    }
+    return c;
+}
+MMS_HD Contact sphere_box(float k, float cdamp, float pen_ramp, float h, V3 Ow, V3 xs, float rad, S6 vb, const BoxPose& box) {
+    Contact c = contact_none();
+    V3 rel = Ow + xs - box.pos;
+    V3 xb = mulT(box.R, rel);
+    V3 q = V3{clampf(xb.x, -box.half.x, box.half.x), clampf(xb.y, -box.half.y, box.half.y), clampf(xb.z, -box.half.z, box.half.z)};
+    bool inside = (q.x == xb.x) && (q.y == xb.y) && (q.z == xb.z);
+    V3 nb = V3{0, 0, 0};
+    float d;
+    if (!inside) {
+        V3 dl = xb - q;
+        float dist = sqrtf(dot(dl, dl));
+        d = rad - dist;
+        if (d > -kContactMargin) nb = V3{dl.x / dist, dl.y / dist, dl.z / dist};
+    } else {
+        float mx = box.half.x - fabsf(xb.x), my = box.half.y - fabsf(xb.y), mz = box.half.z - fabsf(xb.z);
+        int ax = 0;
+        float best = mx;
+        if (my < best) { best = my; ax = 1; }
+        if (mz < best) { best = mz; ax = 2; }
+        float sx = (xb.x >= 0.f) ? 1.f : -1.f, sy = (xb.y >= 0.f) ? 1.f : -1.f, sz = (xb.z >= 0.f) ? 1.f : -1.f;
+        nb = V3{ax == 0 ? sx : 0.f, ax == 1 ? sy : 0.f, ax == 2 ? sz : 0.f};
+        d = rad + best;
+    }
+    if (d > -kContactMargin) {
+        V3 n = mul(box.R, nb);
+        V3 xc = xs - rad * n;
+        V3 vp = vb.l + cross(vb.a, xc);
+        V3 rb = Ow + xc - box.pos;
+        V3 vrel = vp - box.v - cross(box.w, rb);
+        float gn = h * k + cdamp * ramp01(d, pen_ramp);
+        if (d > 0.f || d - h * dot(n, vrel) > 0.f) {
+            c.active = 1.f;
+            c.xc = xc;
+            c.n = n;
+            c.kd = k * d;
+            c.gn = gn;
+            c.ct = 0.f;
+            c.vrel = vrel;
+        }
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-leg constants (loaded once per lane from the device copy of mms_config)
+// ---------------------------------------------------------------------------------------------
+struct LegConst {
+    V3 hip_pos, limb_dir, ankle_axis;
+    float lower[2], upper[2], init[2], gear[2];
+};
+MMS_HD LegConst load_leg_const(const mms_model* M, int l) {
+    LegConst L;
+    L.hip_pos = V3{M->hip_pos[l][0], M->hip_pos[l][1], M->hip_pos[l][2]};
+    L.limb_dir = V3{M->limb_dir[l][0], M->limb_dir[l][1], M->limb_dir[l][2]};
+    L.ankle_axis = V3{M->ankle_axis[l][0], M->ankle_axis[l][1], M->ankle_axis[l][2]};
+    for (int j = 0; j < 2; j++) {
+        L.lower[j] = M->dof_lower[2 * l + j];
+        L.upper[j] = M->dof_upper[2 * l + j];
+        L.init[j] = M->dof_init[2 * l + j];
+        L.gear[j] = M->gear[2 * l + j];
+    }
+    return L;
+}
+
+// replicated torso state + this lane's two joints
+struct AntLane {
+    V3 pos;
+    float qx, qy, qz, qw;
+    V3 vel, ang;
+    float q[2], qd[2];
+};
+
+MMS_HD void quat_integrate(float& qx, float& qy, float& qz, float& qw, V3 w, float h) {
+    float hx = 0.5f * h * w.x, hy = 0.5f * h * w.y, hz = 0.5f * h * w.z;
+    float nx = qx + (hx * qw + hy * qz - hz * qy);
+    float ny = qy + (hy * qw + hz * qx - hx * qz);
+    float nz = qz + (hz * qw + hx * qy - hy * qx);
+    float ns = qw - (hx * qx + hy * qy + hz * qz);
+    float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz + ns * ns);
+    qx = nx * inv; qy = ny * inv; qz = nz * inv; qw = ns * inv;
+}
+MMS_HD void clamp_angvel(V3& w, float wmax) {
+    float wn = sqrtf(dot(w, w));
+    if (wn > wmax) { float s = wmax / wn; w = s * w; }
+}
+
+// What a leg lane keeps between the inward and the outward pass
+struct LegPass {
+    S6 s1, s2, c1, c2, U1, U2;
+    float D1, D2, u1, u2;
+    Contact hip_g, hip_b, knee_g, knee_b, tip_g, tip_b, torso_g, torso_b;
+    M3 Rf;
+    V3 J2;
+    S6 v0;
+};
+
+// joint torque with linearly-implicit damping and limits: returns tau, adds to De
+MMS_HD float joint_tau(const mms_model* M, float h, float q, float qd, float lo, float hi, float motor, float& De) {
+    float t = motor - M->joint_damping * qd;
+    De = M->armature + h * M->joint_damping;
+    float ehi = q - hi, elo = lo - q;
+    if (ehi > 0.f || ehi + h * qd > 0.f) {
+        float gl = h * M->limit_k + M->limit_c * ramp01(ehi, M->limit_ramp);
+        t += -M->limit_k * ehi - gl * qd; De += h * gl;
+    } else if (elo > 0.f || elo - h * qd > 0.f) {
+        float gl = h * M->limit_k + M->limit_c * ramp01(elo, M->limit_ramp);
+        t += M->limit_k * elo - gl * qd; De += h * gl;
+    }
+    return t;
+}
+
+// Phase A (inward pass of one leg chain).  Returns this lane's contribution (Ia, pa) to the torso's
+// articulated inertia; lane l == 0 also adds the torso body itself and the torso sphere contacts.
+MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const AntLane& S, int leg, float tau1, float tau2,
+                       bool has_box, const BoxPose& box, LegPass& P, Sym6& IA0, S6& pA0) {
+    M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
+    V3 Ow = S.pos;
+    S6 v0 = S6{S.ang, S.vel};
+    P.v0 = v0;
+    // kinematics
+    V3 J1 = mul(Rt, L.hip_pos), a1 = Rt.c2;
+    M3 Rl = mul(Rt, axis_angle_to_mat(V3{0.f, 0.f, 1.f}, S.q[0]));
+    V3 ul = mul(Rl, L.limb_dir), a2 = mul(Rl, L.ankle_axis);
+    V3 J2 = J1 + M->leg_len * ul;
+    M3 Rf = mul(Rl, axis_angle_to_mat(L.ankle_axis, S.q[1]));
+    V3 uf = mul(Rf, L.limb_dir);
+    V3 cl = J1 + (0.5f * M->leg_len) * ul, cf = J2 + (0.5f * M->foot_len) * uf, tip = J2 + M->foot_len * uf;
+    P.Rf = Rf; P.J2 = J2;
+    // motion subspaces, velocities, velocity-product accelerations
+    P.s1 = S6{a1, cross(J1, a1)};
+    P.s2 = S6{a2, cross(J2, a2)};
+    S6 sq1 = S.qd[0] * P.s1;
+    S6 vl = v0 + sq1;
+    P.c1 = cross_motion(v0, sq1);
+    S6 sq2 = S.qd[1] * P.s2;
+    S6 vf = vl + sq2;
+    P.c2 = cross_motion(vl, sq2);
+    // body inertias and bias forces
+    Sym6 IAl, IAf;
+    spatial_inertia_axisym(M->leg_mass, cl, ul, M->leg_ia, M->leg_it, IAl);
+    S6 pAl = bias_force(IAl, vl, M->leg_mass, cl, M->gravity);
+    spatial_inertia_axisym(M->foot_mass, cf, uf, M->foot_ia, M->foot_it, IAf);
+    S6 pAf = bias_force(IAf, vf, M->foot_mass, cf, M->gravity);
+    // contacts
+    P.hip_g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, J1, M->limb_radius, vl);
+    P.knee_g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, J2, M->limb_radius, vl);
+    P.tip_g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, tip, M->limb_radius, vf);
+    if (has_box) {
+        P.hip_b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, J1, M->limb_radius, vl, box);
+        P.knee_b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, J2, M->limb_radius, vl, box);
+        P.tip_b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, tip, M->limb_radius, vf, box);
+    } else {
+        P.hip_b = contact_none(); P.knee_b = contact_none(); P.tip_b = contact_none();
+    }
+    contact_fold(P.hip_g, h, IAl, pAl);  contact_fold(P.hip_b, h, IAl, pAl);
+    contact_fold(P.knee_g, h, IAl, pAl); contact_fold(P.knee_b, h, IAl, pAl);
+    contact_fold(P.tip_g, h, IAf, pAf);  contact_fold(P.tip_b, h, IAf, pAf);
+    // joints
+    float De1, De2;
+    float t1 = joint_tau(M, h, S.q[0], S.qd[0], L.lower[0], L.upper[0], tau1, De1);
+    float t2 = joint_tau(M, h, S.q[1], S.qd[1], L.lower[1], L.upper[1], tau2, De2);
+    // inward: foot -> leg
+    P.U2 = sym_mul(IAf, P.s2);
+    P.D2 = De2 + dot(P.s2, P.U2);
+    P.u2 = t2 - dot(P.s2, pAf);
+    {
+        float invD = 1.f / P.D2;
+        sym_rank1(IAf, -invD, P.U2);                       // Ia = IA - U U^T / D
+        S6 Iac = sym_mul(IAf, P.c2);
+        sym_add(IAl, IAf);
+        pAl = pAl + pAf + Iac + (P.u2 * invD) * P.U2;
+    }
+    // inward: leg -> torso contribution
+    P.U1 = sym_mul(IAl, P.s1);
+    P.D1 = De1 + dot(P.s1, P.U1);
+    P.u1 = t1 - dot(P.s1, pAl);
+    {
+        float invD = 1.f / P.D1;
+        sym_rank1(IAl, -invD, P.U1);
+        S6 Iac = sym_mul(IAl, P.c1);
+        IA0 = IAl;
+        pA0 = pAl + Iac + (P.u1 * invD) * P.U1;
+    }
+    // the torso body itself (lane 0 of the quad adds it once)
+    P.torso_g = contact_none();
+    P.torso_b = contact_none();
+    if (leg == 0) {
+        Sym6 It;
+        V3 zero = V3{0, 0, 0};
+        spatial_inertia_axisym(M->torso_mass, zero, Rt.c2, M->torso_izz, M->torso_ixx, It);
+        S6 pt = bias_force(It, v0, M->torso_mass, zero, M->gravity);
+        P.torso_g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, zero, M->torso_radius, v0);
+        if (has_box) P.torso_b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, zero, M->torso_radius, v0, box);
+        contact_fold(P.torso_g, h, It, pt);
+        contact_fold(P.torso_b, h, It, pt);
+        sym_add(IA0, It);
+        pA0 = pA0 + pt;
+    }
+}
+
+// reaction of one contact on the box: (torque about the box COM, force)
+MMS_HD void acc_box(const Contact& c, V3 f, V3 Ow, const BoxPose& box, S6& w) {
+    if (c.active == 0.f) return;
+    V3 rb = Ow + c.xc - box.pos;
+    V3 nf = V3{-f.x, -f.y, -f.z};
+    w.a = w.a + cross(rb, nf);
+    w.l = w.l + nf;
+}
+
+// Phase B (after the quad reduction): root solve, outward pass, contact forces, integration.
+// `wrench` returns this lane's reaction on the box; `sens` the foot sensor (force, torque) in the foot frame.
+MMS_HD void leg_outward(const mms_model* M, float h, AntLane& S, int leg, bool has_box, const BoxPose& box, const LegPass& P,
+                        const Sym6& IA0, S6 pA0, S6& wrench, float sens[6]) {
+    S6 rhs = S6{V3{-pA0.a.x, -pA0.a.y, -pA0.a.z}, V3{-pA0.l.x, -pA0.l.y, -pA0.l.z}};
+    S6 a0 = solve6(IA0, rhs);
+    V3 Ow = S.pos;
+    wrench = S6{V3{0, 0, 0}, V3{0, 0, 0}};
+    if (leg == 0 && has_box) acc_box(P.torso_b, contact_force(P.torso_b, h, a0), Ow, box, wrench);
+    S6 al = a0 + P.c1;
+    float qdd1 = (P.u1 - dot(P.U1, al)) / P.D1;
+    al = al + qdd1 * P.s1;
+    S6 af = al + P.c2;
+    float qdd2 = (P.u2 - dot(P.U2, af)) / P.D2;
+    af = af + qdd2 * P.s2;
+    V3 f_tip_g = contact_force(P.tip_g, h, af), f_tip_b = contact_force(P.tip_b, h, af);
+    if (has_box) {
+        acc_box(P.hip_b, contact_force(P.hip_b, h, al), Ow, box, wrench);
+        acc_box(P.knee_b, contact_force(P.knee_b, h, al), Ow, box, wrench);
+        acc_box(P.tip_b, f_tip_b, Ow, box, wrench);
+    }
+    if (sens) {
+        V3 F = V3{0, 0, 0}, T = V3{0, 0, 0};
+        if (P.tip_g.active != 0.f) { F = F + f_tip_g; T = T + cross(P.tip_g.xc - P.J2, f_tip_g); }
+        if (P.tip_b.active != 0.f) { F = F + f_tip_b; T = T + cross(P.tip_b.xc - P.J2, f_tip_b); }
+        V3 Fl = mulT(P.Rf, F), Tl = mulT(P.Rf, T);
+        sens[0] = Fl.x; sens[1] = Fl.y; sens[2] = Fl.z; sens[3] = Tl.x; sens[4] = Tl.y; sens[5] = Tl.z;
+    }
+    // integrate (semi-implicit Euler)
+    S.qd[0] += h * qdd1; S.q[0] += h * S.qd[0];
+    S.qd[1] += h * qdd2; S.q[1] += h * S.qd[1];
+    V3 wxv = cross(P.v0.a, P.v0.l);
+    S.vel = S.vel + h * (a0.l + wxv);
+    S.ang = S.ang + h * a0.a;
+    clamp_angvel(S.ang, kMaxAngVel);
+    S.pos = S.pos + h * S.vel;
+    quat_integrate(S.qx, S.qy, S.qz, S.qw, S.ang, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// box: one corner lane's contribution, then the 6x6 solve (after the 8-lane reduction)
+// ---------------------------------------------------------------------------------------------
+struct RigidState { V3 pos; float qx, qy, qz, qw; V3 vel, ang; };
+
+MMS_HD void box_corner(const mms_model* M, float h, const RigidState& B, const M3& R, int corner, Sym6& A, S6& b) {
+    sym_zero(A);
+    b = S6{V3{0, 0, 0}, V3{0, 0, 0}};
+    V3 loc = V3{(corner & 1 ? 1.f : -1.f) * M->box_half[0], (corner & 2 ? 1.f : -1.f) * M->box_half[1],
+                (corner & 4 ? 1.f : -1.f) * M->box_half[2]};
+    V3 xc = mul(R, loc);
+    float d = -(B.pos.z + xc.z);
+    if (d <= -kContactMargin) return;
+    V3 vp = B.vel + cross(B.ang, xc);
+    float gn = h * M->boxgnd_k + M->boxgnd_c * ramp01(d, M->pen_ramp);
+    if (!(d > 0.f || d - h * vp.z > 0.f)) return;
+    Contact c = contact_none();
+    c.active = 1.f; c.xc = xc; c.n = V3{0, 0, 1}; c.kd = M->boxgnd_k * d; c.gn = gn; c.ct = 0.f; c.vrel = vp;
+    S6 p = S6{V3{0, 0, 0}, V3{0, 0, 0}};
+    contact_fold(c, h, A, p);
+    b = S6{V3{-p.a.x, -p.a.y, -p.a.z}, V3{-p.l.x, -p.l.y, -p.l.z}};
+}
+MMS_HD void box_finish(const mms_model* M, float h, RigidState& B, const M3& R, Sym6 A, S6 b, S6 wrench) {
+    Sym6 Ib;
+    V3 zero = V3{0, 0, 0};
+    spatial_inertia_diag(M->box_mass, zero, R, V3{M->box_inertia[0], M->box_inertia[1], M->box_inertia[2]}, Ib);
+    // gyroscopic torque w x (I w)
+    S6 hw = sym_mul(Ib, S6{B.ang, zero});
+    V3 gyro = cross(B.ang, hw.a);
+    sym_add(A, Ib);
+    b.a = b.a + wrench.a - gyro;
+    b.l = b.l + wrench.l + V3{0.f, 0.f, -M->box_mass * M->gravity};
+    S6 a = solve6(A, b);
+    B.ang = B.ang + h * a.a;
+    B.vel = B.vel + h * a.l;
+    clamp_angvel(B.ang, kMaxAngVel);
+    B.pos = B.pos + h * B.vel;
+    quat_integrate(B.qx, B.qy, B.qz, B.qw, B.ang, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// helicopter (one lane per helicopter; oracle heli_substep)
+// ---------------------------------------------------------------------------------------------
+MMS_HD void heli_substep(const mms_model* M, float h, RigidState& B, V3 thr0, V3 thr1) {
+    M3 R = quat_to_mat(B.qx, B.qy, B.qz, B.qw);
+    V3 c = mul(R, V3{0.f, 0.f, M->heli_com_z});
+    Sym6 A;
+    spatial_inertia_diag(M->heli_mass, c, R, V3{M->heli_inertia[0], M->heli_inertia[1], M->heli_inertia[2]}, A);
+    S6 v0 = S6{B.ang, B.vel};
+    S6 p = bias_force(A, v0, M->heli_mass, c, M->gravity);
+    V3 thr[2] = {thr0, thr1};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        V3 x = mul(R, V3{0.f, 0.f, M->heli_rotor_z[r]});
+        V3 f = mul(R, thr[r]);
+        p.a = p.a - cross(x, f);
+        p.l = p.l - f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        V3 loc = V3{(k & 1 ? 1.f : -1.f) * M->heli_half, (k & 2 ? 1.f : -1.f) * M->heli_half, (k & 4 ? 1.f : -1.f) * M->heli_half};
+        V3 xc = mul(R, loc);
+        float d = -(B.pos.z + xc.z);
+        if (d <= -kContactMargin) continue;
+        V3 vp = v0.l + cross(v0.a, xc);
+        float gn = h * M->heli_gnd_k + M->heli_gnd_c * ramp01(d, M->pen_ramp);
+        float fn = fmaxf(M->heli_gnd_k * d - gn * vp.z, 0.f);
+        if (!(d > 0.f || d - h * vp.z > 0.f)) continue;
+        Contact ct = contact_none();
+        ct.active = 1.f; ct.xc = xc; ct.n = V3{0, 0, 1}; ct.kd = M->heli_gnd_k * d; ct.gn = gn;
+        float vt = sqrtf(vp.x * vp.x + vp.y * vp.y);
+        ct.ct = M->gnd_mu * fn / fmaxf(vt, M->slip_eps);
+        ct.vrel = vp;
+        contact_fold(ct, h, A, p);
+    }
+    S6 a = solve6(A, S6{V3{-p.a.x, -p.a.y, -p.a.z}, V3{-p.l.x, -p.l.y, -p.l.z}});
+    V3 wxv = cross(v0.a, v0.l);
+    B.vel = B.vel + h * (a.l + wxv);
+    B.ang = B.ang + h * a.a;
+    clamp_angvel(B.ang, M->heli_max_angvel);
+    B.pos = B.pos + h * B.vel;
+    quat_integrate(B.qx, B.qy, B.qz, B.qw, B.ang, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// observation / reward helpers (oracle: ant_obs_core_compute etc.; reference citations there)
+// ---------------------------------------------------------------------------------------------
+MMS_HD V3 quat_rotate(float x, float y, float z, float w, V3 v, float sign) {
+    V3 qv = V3{x, y, z};
+    float a = 2.0f * w * w - 1.0f;
+    V3 c = cross(qv, v);
+    float d = dot(qv, v);
+    return V3{v.x * a + sign * (c.x * w * 2.0f) + x * d * 2.0f, v.y * a + sign * (c.y * w * 2.0f) + y * d * 2.0f,
+              v.z * a + sign * (c.z * w * 2.0f) + z * d * 2.0f};
+}
+MMS_HD float wrap_2pi(float a) {
+    float r = fmodf(a, kTwoPi);
+    if (r < 0.f) r += kTwoPi;
+    return r;
+}
+struct AntObsCore { V3 vel_loc, angvel_loc; float yaw, roll, angle_to_target, up_proj, heading_proj; };
+// p: GLOBAL position (local + env origin)
+MMS_HD AntObsCore ant_obs_core(V3 p, float x, float y, float z, float w, V3 vel, V3 ang) {
+    AntObsCore o;
+    V3 to_target = V3{0.f - p.x, 0.f - p.y, 0.0f};
+    float n = sqrtf(dot(to_target, to_target));
+    if (n < 1e-9f) n = 1e-9f;
+    V3 td = V3{to_target.x / n, to_target.y / n, to_target.z / n};
+    // torso_quat = quat_mul(q, conj(identity)) with the -0.0 terms of the reference kept
+    float tx = w * (-0.f) + x * 1.f + y * (-0.f) - z * (-0.f);
+    float ty = w * (-0.f) - x * (-0.f) + y * 1.f + z * (-0.f);
+    float tz = w * (-0.f) + x * (-0.f) - y * (-0.f) + z * 1.f;
+    float tw = w * 1.f - x * (-0.f) - y * (-0.f) - z * (-0.f);
+    V3 up = quat_rotate(tx, ty, tz, tw, V3{0, 0, 1}, 1.f);
+    V3 hd = quat_rotate(tx, ty, tz, tw, V3{1, 0, 0}, 1.f);
+    o.up_proj = up.z;
+    o.heading_proj = hd.x * td.x + hd.y * td.y + hd.z * td.z;
+    o.vel_loc = quat_rotate(tx, ty, tz, tw, vel, -1.f);
+    o.angvel_loc = quat_rotate(tx, ty, tz, tw, ang, -1.f);
+    float sinr = 2.0f * (tw * tx + ty * tz), cosr = tw * tw - tx * tx - ty * ty + tz * tz;
+    o.roll = wrap_2pi(atan2f(sinr, cosr));
+    float siny = 2.0f * (tw * tz + tx * ty), cosy = tw * tw + tx * tx - ty * ty - tz * tz;
+    o.yaw = wrap_2pi(atan2f(siny, cosy));
+    float walk = atan2f(0.f - p.z, 0.f - p.x);
+    o.angle_to_target = walk - o.yaw;
+    return o;
+}
+MMS_HD float unscale1(float x, float lo, float hi) { return (2.0f * x - hi - lo) / (hi - lo); }
+MMS_HD float l2_dist2(float ax, float ay, float bx, float by) {
+    float c1 = ax - bx, c2 = ay - by;
+    return sqrtf(c1 * c1 + c2 * c2);
+}
+MMS_HD float box_angle(float qz, float qw) { return atanf((2.f * qw * qz) / (1.f - 2.f * qz * qz)); }
+MMS_HD float box_quat_dist(float qx, float qy, float qz, float qw) {
+    float x = 2.f * (qx * qy + qw * qz), y = 1.f - 2.f * (qx * qx + qz * qz), z = 2.f * (qy * qz - qw * qx);
+    float x1 = x * 0.f, y1 = y * 1.f, z1 = z * 0.f;
+    return (x1 + y1 + z1) / sqrtf(x * x + y * y + z * z) / sqrtf(0.f * 0.f + 1.f * 1.f + 0.f * 0.f);
+}
+
+// counter-based RNG (oracle mo_rand_uniform)
+MMS_HD uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+MMS_HD float rand_uniform(uint64_t seed, uint64_t env_global, uint64_t step, uint32_t k) {
+    uint32_t x = mix32((uint32_t)seed ^ 0x9E3779B9U);
+    x = mix32(x ^ (uint32_t)(seed >> 32));
+    x = mix32(x ^ (uint32_t)env_global);
+    x = mix32(x ^ (uint32_t)(env_global >> 32) ^ 0x85EBCA6BU);
+    x = mix32(x ^ (uint32_t)step);
+    x = mix32(x ^ (uint32_t)(step >> 32) ^ (k * 0xC2B2AE35U));
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// epilogue of the ant tasks: reset, observation row, reward partials (per lane)
+// ---------------------------------------------------------------------------------------------
+// reward partial slots per ant in the reduction scratch
+enum { RP_ADR = 0, RP_GDR, RP_GAR, RP_UP, RP_EC, RP_LIM, RP_FALLEN, RP_ACOST, RP_STRIDE };
+
+// reset_idx for one leg lane (ten_ant.py:810-868): root <- initial, dof <- clamp(init + noise), vel <- noise
+MMS_HD void ant_reset_lane(const mms_config* C, const LegConst& L, AntLane& S, const float* init_root13, int leg,
+                           const float* ext_noise16, uint64_t env_global, uint64_t step_index) {
+    S.pos = V3{init_root13[0], init_root13[1], init_root13[2]};
+    S.qx = init_root13[3]; S.qy = init_root13[4]; S.qz = init_root13[5]; S.qw = init_root13[6];
+    S.vel = V3{init_root13[7], init_root13[8], init_root13[9]};
+    S.ang = V3{init_root13[10], init_root13[11], init_root13[12]};
+    for (int j = 0; j < 2; j++) {
+        int d = 2 * leg + j;
+        float npos, nvel;
+        if (C->external_noise) { npos = ext_noise16[d]; nvel = ext_noise16[8 + d]; }
+        else {
+            npos = 0.4f * rand_uniform(C->seed, env_global, step_index, (uint32_t)d) - 0.2f;
+            nvel = 0.2f * rand_uniform(C->seed, env_global, step_index, (uint32_t)(8 + d)) - 0.1f;
+        }
+        S.q[j] = clampf(L.init[j] + npos, L.lower[j], L.upper[j]);
+        S.qd[j] = nvel;
+    }
+}
+
+// goal of ant k (ten_ant.py:1353-1393): box + / - (1.5 + 3 (k/2)) (sin, -cos)(box yaw)
+MMS_HD void tenant_goal(int k, float bx, float by, float sv, float cv, float& gx, float& gy) {
+    float off = 1.5f + 3.0f * (float)(k / 2);
+    if (k % 2 == 0) { gx = bx + off * sv; gy = by + off * cv; }
+    else { gx = bx - off * sv; gy = by - off * cv; }
+}
+
+// TenAnt: observation pieces of one leg lane into the staged row, and the per-lane reward partials.
+// ec / lim / acost are this lane's share; the caller quad-reduces them and lane 0 stores the ant's slots.
+struct TenAntLaneOut { float adr, gdr, gar, up, fallen, ec, lim, acost; float px, py, gx, gy; };
+MMS_HD TenAntLaneOut tenant_obs_reward_lane(const mms_config* C, const LegConst& L, const AntLane& S, int ant, int leg,
+                                            V3 origin, float act0, float act1, float box_gx, float box_gy, float sv, float cv,
+                                            float pbx, float pby, float gbx, float gby, float* s_obs) {
+    TenAntLaneOut o;
+    V3 p = S.pos + origin;                                   // global frame
+    AntObsCore c = ant_obs_core(p, S.qx, S.qy, S.qz, S.qw, S.vel, S.ang);
+    float* row = s_obs + 38 * ant;
+    if (leg == 0) {
+        row[0] = p.x; row[1] = p.y; row[2] = p.z;
+        row[3] = c.vel_loc.x; row[4] = c.vel_loc.y; row[5] = c.vel_loc.z;
+        row[6] = c.angvel_loc.x; row[7] = c.angvel_loc.y; row[8] = c.angvel_loc.z;
+        row[9] = c.yaw; row[10] = c.roll; row[11] = c.angle_to_target; row[12] = c.up_proj; row[13] = c.heading_proj;
+    }
+    float act[2] = {act0, act1};
+    o.ec = 0.f; o.lim = 0.f; o.acost = 0.f;
+    for (int j = 0; j < 2; j++) {
+        float us = unscale1(S.q[j], L.lower[j], L.upper[j]);
+        float dv = S.qd[j] * C->dof_vel_scale;
+        row[14 + 2 * leg + j] = us;
+        row[22 + 2 * leg + j] = dv;
+        row[30 + 2 * leg + j] = act[j];
+        o.ec += fabsf(act[j] * dv);
+        o.lim += (us > 0.99f) ? 1.f : 0.f;
+        o.acost += act[j] * act[j];
+    }
+    float gx, gy;
+    tenant_goal(ant, box_gx, box_gy, sv, cv, gx, gy);
+    float off = 1.5f + 3.0f * (float)(ant / 2);
+    float btx = 0.f, bty = (ant % 2 == 0) ? -off : off;     // box_targets_k (ten_ant.py:172-181)
+    float d_now = l2_dist2(p.x, p.y, gx, gy);
+    float push = (d_now < 1.5f) ? 0.f : 1.f;
+    float ant_dist = l2_dist2(pbx, pby, gbx, gby) - d_now;
+    o.adr = C->ant_dist_reward_scale * ant_dist * push;
+    float gd_before = l2_dist2(btx, bty, gbx, gby);
+    float gd = l2_dist2(btx, bty, gx, gy);
+    o.gdr = C->goal_dist_reward_scale * (gd_before - gd);
+    o.gar = (gd < 0.5f) ? 1.f : 0.f;                         // arrive flag; reward adds 2 per arrival
+    o.up = (c.up_proj > 0.93f) ? (0.f + C->up_weight) : 0.f;
+    o.fallen = (p.z < C->termination_height) ? 1.f : 0.f;
+    o.px = p.x; o.py = p.y; o.gx = gx; o.gy = gy;
+    return o;
+}
+
+// TenAnt: final reduction over the ants in reference order (ten_ant.py:1173-1301); one thread.
+MMS_HD void tenant_reward_finish(const mms_config* C, int A, const float* s_red, float bqx, float bqy, float bqz, float bqw,
+                                 int64_t progress, float& rew, int64_t& reset) {
+    float quat_dist = box_quat_dist(bqx, bqy, bqz, bqw);
+    float quat_reward = C->quat_reward_scale * quat_dist;
+    float adr = 0.f, gdr = 0.f, gar = 0.f, up = 0.f, ec = 0.f, acost = 0.f;
+    float lim = 0.f;
+    bool all_arrive = true, fallen = false;
+    for (int k = 0; k < A; k++) {
+        const float* r = s_red + RP_STRIDE * k;
+        float g2 = (r[RP_GAR] != 0.f) ? 2.f : 0.f;
+        adr = (k == 0) ? r[RP_ADR] : adr + r[RP_ADR];
+        gdr = (k == 0) ? r[RP_GDR] : gdr + r[RP_GDR];
+        gar = (k == 0) ? g2 : gar + g2;
+        up = (k == 0) ? r[RP_UP] : up + r[RP_UP];
+        ec = (k == 0) ? r[RP_EC] : ec + r[RP_EC];
+        lim += r[RP_LIM];
+        acost += r[RP_ACOST];
+        all_arrive = all_arrive && (r[RP_GAR] != 0.f);
+        fallen = fallen || (r[RP_FALLEN] != 0.f);
+    }
+    up = up * 10.f;
+    float success = ((quat_dist > 0.9f) && all_arrive) ? 100.f : 0.f;
+    float total = 5.f + up + quat_reward + adr + gdr + gar + success - C->actions_cost * acost - C->energy_cost * ec -
+                  lim * C->joints_at_limit_cost;
+    if (fallen) total = C->death_cost;
+    int64_t rs = fallen ? 1 : 0;                              // reset_buf is 0 here: reset_idx cleared it
+    if (progress >= (int64_t)C->max_episode_length - 1) rs = 1;
+    rew = total;
+    reset = rs;
+}
+
+// OneAnt (one_ant.py:465-627): the four leg lanes fill the 60-wide row; lane 0 computes the reward.
+struct OneAntLaneOut { float ec, lim, acost; };
+MMS_HD OneAntLaneOut oneant_obs_lane(const mms_config* C, const LegConst& L, const AntLane& S, int leg, V3 origin,
+                                     float act0, float act1, const float sens[6], float* s_obs, AntObsCore& core, V3& pglob) {
+    OneAntLaneOut o;
+    V3 p = S.pos + origin;
+    pglob = p;
+    core = ant_obs_core(p, S.qx, S.qy, S.qz, S.qw, S.vel, S.ang);
+    if (leg == 0) {
+        s_obs[0] = p.z;
+        s_obs[1] = core.vel_loc.x; s_obs[2] = core.vel_loc.y; s_obs[3] = core.vel_loc.z;
+        s_obs[4] = core.angvel_loc.x; s_obs[5] = core.angvel_loc.y; s_obs[6] = core.angvel_loc.z;
+        s_obs[7] = core.yaw; s_obs[8] = core.roll; s_obs[9] = core.angle_to_target; s_obs[10] = core.up_proj;
+        s_obs[11] = core.heading_proj;
+    }
+    float act[2] = {act0, act1};
+    o.ec = 0.f; o.lim = 0.f; o.acost = 0.f;
+    for (int j = 0; j < 2; j++) {
+        float us = unscale1(S.q[j], L.lower[j], L.upper[j]);
+        float dv = S.qd[j] * C->dof_vel_scale;
+        s_obs[12 + 2 * leg + j] = us;
+        s_obs[20 + 2 * leg + j] = dv;
+        s_obs[52 + 2 * leg + j] = act[j];
+        o.ec += fabsf(act[j] * dv);
+        o.lim += (us > 0.99f) ? 1.f : 0.f;
+        o.acost += act[j] * act[j];
+    }
+    for (int i = 0; i < 6; i++) s_obs[28 + 6 * leg + i] = sens[i] * C->contact_force_scale;
+    return o;
+}
+MMS_HD void oneant_reward(const mms_config* C, float obs0, float up_proj, float ec, float lim, float acost, float pbx,
+                          float pby, float bbx, float bby, float ax, float ay, float bx, float by, float bqx, float bqy,
+                          float bqz, float bqw, int64_t progress, float& rew, int64_t& reset) {
+    float quat_dist = box_quat_dist(bqx, bqy, bqz, bqw);
+    float quat_reward = C->quat_reward_scale * quat_dist;
+    float d_now = l2_dist2(ax, ay, bx, by);
+    float push = (d_now < 1.5f) ? 0.f : 1.f;
+    float ant_dist = l2_dist2(pbx, pby, bbx, bby) - d_now;
+    float adr = C->ant_dist_reward_scale * ant_dist * push;
+    float gd_before = l2_dist2(0.f, 0.f, bbx, bby);
+    float gd = l2_dist2(0.f, 0.f, bx, by);
+    bool arrive = gd < 0.5f;
+    float gdr = C->goal_dist_reward_scale * (gd_before - gd);
+    float gar = arrive ? 2.f : 0.f;
+    float success = ((quat_dist > 0.9f) && arrive) ? 10.f : 0.f;
+    float up = (up_proj > 0.93f) ? (0.f + C->up_weight) : 0.f;
+    float total = 0.5f + up + quat_reward + adr + gdr + gar + success - C->actions_cost * acost - C->energy_cost * ec -
+                  lim * C->joints_at_limit_cost;
+    bool fallen = obs0 < C->termination_height;
+    if (fallen) total = C->death_cost;
+    int64_t rs = fallen ? 1 : 0;
+    if (progress >= (int64_t)C->max_episode_length - 1) rs = 1;
+    rew = total;
+    reset = rs;
+}
+
+// MultiIngenuity reward (multi_ingenuity.py:381-453) from the global-frame observation row [4][13]
+MMS_HD void ingenuity_reward(const float* roots, int32_t max_len, int64_t progress, float& rew, int64_t& reset) {
+    const float gy[4] = {2.f, -2.f, 6.f, -6.f};
+    float pos_reward = 0.f, up_reward = 0.f, spin_reward = 0.f;
+    bool die = false, low = false;
+    for (int k = 0; k < 4; k++) {
+        const float* r = roots + 13 * k;
+        float dx = 4.f - r[0], dy = gy[k] - r[1], dz = 1.f - r[2];
+        float td = sqrtf(dx * dx + dy * dy + dz * dz);
+        float pr = 1.0f / (1.0f + td * td);
+        pos_reward = (k == 0) ? pr : pos_reward + pr;
+        V3 ups = quat_rotate(r[3], r[4], r[5], r[6], V3{0, 0, 1}, 1.f);
+        float tilt = fabsf(1.f - ups.z);
+        float ur = 5.0f / (1.0f + tilt * tilt);
+        up_reward = (k == 0) ? ur : up_reward + ur;
+        float spin = fabsf(r[12]);
+        float sr = 1.0f / (1.0f + spin * spin);
+        spin_reward = (k == 0) ? sr : spin_reward + sr;
+        die = die || (td > 8.0f);
+        low = low || (r[2] < 0.5f);
+    }
+    rew = pos_reward + pos_reward * (up_reward + spin_reward);
+    int64_t d = (die || low) ? 1 : 0;
+    reset = (progress >= (int64_t)max_len - 1) ? 1 : d;
+}
+
+}  // namespace mms

@@ -1,0 +1,133 @@
+// rollout_kernels.hip -- GAE scans and MARL wrapper views for gfx950.
+//
+//   gae_ppo_kernel       RolloutStorage.compute_returns   (agents/algorithms/rl/ppo/storage.py:51-65)
+//   adv_normalize_kernel the normalisation at storage.py:64-65, split off so that data-parallel ranks can
+//                        all-reduce {sum, sum of squares, count} between the two launches
+//   gae_marl_kernel      SeparatedReplayBuffer.compute_returns, use_gae branch without proper time limits
+//                        (agents/algorithms/marl/utils/separated_buffer.py:153-164)
+//   marl_views_kernel    MultiVecTaskPython.step slicing  (agents/tasks/agent_base/multi_vec_task.py:105-142)
+//
+// All are HBM-bound streaming kernels: thread = env column, T serial steps, every load of a [T,N] plane is a
+// coalesced 256 B wave transaction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mms {
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+
+__global__ void __launch_bounds__(256) gae_ppo_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ dones,
+                                                      const float* __restrict__ values, const float* __restrict__ last_values,
+                                                      float* __restrict__ returns, float* __restrict__ advantages,
+                                                      double* __restrict__ stats, int T, int64_t N, float gamma, float lam) {
+    __shared__ double s_sum[4], s_sq[4];
+    double lsum = 0.0, lsq = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        float adv = 0.f;
+        float next_v = last_values[i];
+        for (int t = T - 1; t >= 0; t--) {
+            float v = values[t * N + i];
+            float nt = 1.0f - (float)dones[t * N + i];
+            float delta = rewards[t * N + i] + nt * gamma * next_v - v;
+            adv = delta + nt * gamma * lam * adv;
+            float ret = adv + v;
+            returns[t * N + i] = ret;
+            float a = ret - v;                        // storage.py:64: advantages = returns - values
+            advantages[t * N + i] = a;
+            lsum += (double)a;
+            lsq += (double)a * (double)a;
+            next_v = v;
+        }
+    }
+    lsum = wave_sum(lsum);
+    lsq = wave_sum(lsq);
+    int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_sum[wave] = lsum; s_sq[wave] = lsq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) { a += s_sum[w]; b += s_sq[w]; }
+        atomicAdd(&stats[0], a);
+        atomicAdd(&stats[1], b);
+        if (blockIdx.x == 0) stats[2] = (double)T * (double)N;
+    }
+}
+
+// advantages := (advantages - mean) / (std + 1e-8), std unbiased (torch.std default)
+__global__ void __launch_bounds__(256) adv_normalize_kernel(float* __restrict__ advantages, const double* __restrict__ stats, int64_t count) {
+    double n = stats[2];
+    double mean = stats[0] / n;
+    double var = (stats[1] - n * mean * mean) / (n - 1.0);
+    float inv = (float)(1.0 / (sqrt(var > 0.0 ? var : 0.0) + 1e-8));
+    float fm = (float)mean;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        advantages[i] = (advantages[i] - fm) * inv;
+}
+
+__global__ void __launch_bounds__(256) gae_marl_kernel(const float* __restrict__ rewards, const float* __restrict__ value_preds,
+                                                       const float* __restrict__ masks, float* __restrict__ returns, int T, int64_t N,
+                                                       float gamma, float lam, int use_norm, const float* __restrict__ norm_mean,
+                                                       const float* __restrict__ norm_var) {
+    float mean = 0.f, sd = 1.f;
+    if (use_norm) { mean = norm_mean[0]; sd = sqrtf(norm_var[0]); }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        float gae = 0.f;
+        float v1 = value_preds[(int64_t)T * N + i];
+        if (use_norm) v1 = v1 * sd + mean;
+        for (int t = T - 1; t >= 0; t--) {
+            float v0 = value_preds[t * N + i];
+            if (use_norm) v0 = v0 * sd + mean;
+            float m = masks[(t + 1) * N + i];
+            float delta = rewards[t * N + i] + gamma * v1 * m - v0;
+            gae = delta + gamma * lam * m * gae;
+            returns[t * N + i] = gae + v0;
+            v1 = v0;
+        }
+    }
+}
+
+// obs_all[n][k][0:per] = obs[n][k*per : (k+1)*per], obs_all[n][k][per:] = obs[n][agents*per:]; input already clamped
+__global__ void __launch_bounds__(256) marl_views_kernel(const float* __restrict__ obs, float* __restrict__ obs_all, int64_t n,
+                                                         int agents, int per, int shared) {
+    const int w = per + shared, row = agents * per + shared;
+    const int64_t total = n * agents * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e = i / ((int64_t)agents * w);
+        int r = (int)(i - e * agents * w);
+        int k = r / w, j = r - k * w;
+        int src = (j < per) ? k * per + j : agents * per + (j - per);
+        obs_all[i] = obs[e * row + src];
+    }
+}
+
+static int grid_for(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+hipError_t launch_gae_ppo(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
+                          float* advantages, double* stats, int T, int64_t N, float gamma, float lam, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(stats, 0, 3 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gae_ppo_kernel, dim3(grid_for(N)), dim3(256), 0, s, rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam);
+    return hipGetLastError();
+}
+hipError_t launch_adv_normalize(float* advantages, const double* stats, int64_t count, hipStream_t s) {
+    hipLaunchKernelGGL(adv_normalize_kernel, dim3(grid_for(count)), dim3(256), 0, s, advantages, stats, count);
+    return hipGetLastError();
+}
+hipError_t launch_gae_marl(const float* rewards, const float* value_preds, const float* masks, float* returns, int T, int64_t N, float gamma,
+                           float lam, int use_norm, const float* mean, const float* var, hipStream_t s) {
+    hipLaunchKernelGGL(gae_marl_kernel, dim3(grid_for(N)), dim3(256), 0, s, rewards, value_preds, masks, returns, T, N, gamma, lam, use_norm, mean, var);
+    return hipGetLastError();
+}
+hipError_t launch_marl_views(const float* obs, float* obs_all, int64_t n, int agents, int per, int shared, hipStream_t s) {
+    hipLaunchKernelGGL(marl_views_kernel, dim3(grid_for(n * agents * (per + shared))), dim3(256), 0, s, obs, obs_all, n, agents, per, shared);
+    return hipGetLastError();
+}
+
+}  // namespace mms

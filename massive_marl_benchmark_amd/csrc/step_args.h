@@ -1,0 +1,30 @@
+// step_args.h -- kernel argument block of the step kernels (passed by value as kernarg).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/mms.h"
+
+namespace mms {
+
+struct StepArgs {
+    const mms_config* cfg;            // device copy of the configuration (uniform loads)
+    const float* actions;             // [N, num_actions]
+    float* obs;                       // [N, obs_dim] raw
+    float* obs_clipped;               // [N, obs_dim] clamped to +-clip_obs
+    float* obs_out;                   // optional bound destination for the clamped row (may be null)
+    float* rew;                       // [N]
+    int64_t* reset;                   // [N]
+    int64_t* progress;                // [N]
+    float* root_states;               // [N * actors, 13]  env-local frame
+    const float* initial_root_states; // [N * actors, 13]
+    float* dof_state;                 // [N * dofs, 2]
+    const float* env_origin;          // [N, 3]
+    float* prev;                      // [N, prev_dim]
+    const float* reset_noise;         // [N, 16]
+    float* foot_sensors;              // [N * A, 24]
+    uint64_t step_index;
+    int32_t do_physics;
+    int32_t num_envs, num_agents, obs_dim, prev_dim;
+};
+
+}  // namespace mms

@@ -1,0 +1,410 @@
+// step_kernels.hip -- fused VecTask step for gfx950 (MI355X): physics substeps + reset_idx +
+// compute_observations + compute_reward + cache update in ONE launch per control step.
+//
+// Replaces BaseTask.step (agents/tasks/agent_base/base_task.py:129-149) together with the task hooks
+// it calls (agents/tasks/ten_ant.py:635-926, one_ant.py:314-436, multi_ingenuity.py:228-379) and the
+// `gym.simulate` call inside it.  The per-lane math lives in mms_lane.h (shared with the CPU lane
+// emulation test); this file holds only what needs the GPU: the lane -> work mapping, DPP / LDS
+// reductions, and the HBM traffic.
+//
+// Mapping.  One workgroup = one environment.  For the ant tasks:
+//   lanes 0 .. 4A-1      : (ant a = tid >> 2, leg l = tid & 3); the quad shares the torso state
+//   lanes B .. B+7       : the 8 box corners (B = 4A rounded up to a multiple of 8)
+// TenAnt at A = 10 is one wave64 per env (48 live lanes); 4096 envs = 4096 waves = 4 per SIMD.
+// HBM traffic per env-step is the env's own contiguous blocks: root_states 572 B, dof_state 640 B,
+// actions 320 B, caches 168 B in; the same state plus the 1552 B observation row(s) out.
+#include <hip/hip_runtime.h>
+
+#include "mms_lane.h"
+#include "step_args.h"
+
+namespace mms {
+
+// ---- cross-lane primitives -------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// all-reduce over the 4 lanes of a quad: (x0 + x1) + (x2 + x3) in every lane (bit-identical across the quad)
+__device__ __forceinline__ float quad_sum(float x) {
+    x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+    return x;
+}
+// all-reduce over 8 consecutive, 8-aligned lanes
+__device__ __forceinline__ float oct_sum(float x) {
+    x = quad_sum(x);
+    x += dpp_mov<0x141>(x);  // row_half_mirror: lane i <-> 7 - i within each 8
+    return x;
+}
+__device__ __forceinline__ void quad_sum(Sym6& A, S6& p) {
+#pragma unroll
+    for (int k = 0; k < 21; k++) A.m[k] = quad_sum(A.m[k]);
+    p.a.x = quad_sum(p.a.x); p.a.y = quad_sum(p.a.y); p.a.z = quad_sum(p.a.z);
+    p.l.x = quad_sum(p.l.x); p.l.y = quad_sum(p.l.y); p.l.z = quad_sum(p.l.z);
+}
+__device__ __forceinline__ void oct_sum(Sym6& A, S6& p) {
+#pragma unroll
+    for (int k = 0; k < 21; k++) A.m[k] = oct_sum(A.m[k]);
+    p.a.x = oct_sum(p.a.x); p.a.y = oct_sum(p.a.y); p.a.z = oct_sum(p.a.z);
+    p.l.x = oct_sum(p.l.x); p.l.y = oct_sum(p.l.y); p.l.z = oct_sum(p.l.z);
+}
+
+__device__ __forceinline__ RigidState load_rigid(const float* r) {
+    RigidState B;
+    B.pos = V3{r[0], r[1], r[2]};
+    B.qx = r[3]; B.qy = r[4]; B.qz = r[5]; B.qw = r[6];
+    B.vel = V3{r[7], r[8], r[9]};
+    B.ang = V3{r[10], r[11], r[12]};
+    return B;
+}
+__device__ __forceinline__ void store_rigid(float* r, const RigidState& B) {
+    r[0] = B.pos.x; r[1] = B.pos.y; r[2] = B.pos.z;
+    r[3] = B.qx; r[4] = B.qy; r[5] = B.qz; r[6] = B.qw;
+    r[7] = B.vel.x; r[8] = B.vel.y; r[9] = B.vel.z;
+    r[10] = B.ang.x; r[11] = B.ang.y; r[12] = B.ang.z;
+}
+
+// write the staged observation row: raw, clamped, and the optional bound rollout slot
+__device__ __forceinline__ void write_obs_row(const float* s_obs, int obs_dim, float clip, float* obs, float* obs_clip,
+                                              float* obs_out, int tid, int nthreads) {
+    if ((obs_dim & 3) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(s_obs);
+        for (int i = tid; i < (obs_dim >> 2); i += nthreads) {
+            float4 v = s4[i];
+            reinterpret_cast<float4*>(obs)[i] = v;
+            float4 c = make_float4(clampf(v.x, -clip, clip), clampf(v.y, -clip, clip), clampf(v.z, -clip, clip), clampf(v.w, -clip, clip));
+            reinterpret_cast<float4*>(obs_clip)[i] = c;
+            if (obs_out) reinterpret_cast<float4*>(obs_out)[i] = c;
+        }
+    } else {
+        for (int i = tid; i < obs_dim; i += nthreads) {
+            float v = s_obs[i];
+            obs[i] = v;
+            float c = clampf(v, -clip, clip);
+            obs_clip[i] = c;
+            if (obs_out) obs_out[i] = c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ant tasks.  TASK: MMS_TASK_TEN_ANT or MMS_TASK_ONE_ANT.  BLOCK: threads per env (64 for A <= 14).
+// dynamic LDS (floats): [obs_dim rounded to 4][6*(BLOCK+1) wrench partials][8 wrench total][16 box][RP_STRIDE*A]
+// ---------------------------------------------------------------------------------------------
+template <int TASK, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const mms_config* __restrict__ C = a.cfg;
+    const mms_model* __restrict__ M = &C->model;
+    const int env = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int A = a.num_agents;
+    const int n_ant_lanes = 4 * A;
+    const int box_base = (n_ant_lanes + 7) & ~7;
+    const bool is_ant = tid < n_ant_lanes;
+    const bool is_box = tid >= box_base && tid < box_base + 8;
+    const int ant = tid >> 2, leg = tid & 3;
+    const int obs_dim = a.obs_dim;
+    const int obs_pad = (obs_dim + 3) & ~3;
+
+    float* s_obs = lds;
+    float* s_wr = s_obs + obs_pad;                 // [6][BLOCK + 1]
+    float* s_wtot = s_wr + 6 * (BLOCK + 1);        // [8]
+    float* s_box = s_wtot + 8;                     // [16]
+    float* s_red = s_box + 16;                     // [A][RP_STRIDE]
+
+    const int actors = A + 1;
+    float* root_env = a.root_states + (size_t)env * actors * 13;
+    const float* init_env = a.initial_root_states + (size_t)env * actors * 13;
+    float* dof_env = a.dof_state + (size_t)env * A * 16;
+    const float* act_env = a.actions + (size_t)env * A * 8;
+    float* prev_env = a.prev + (size_t)env * a.prev_dim;
+    const V3 origin = V3{a.env_origin[3 * env], a.env_origin[3 * env + 1], a.env_origin[3 * env + 2]};
+    const int64_t reset_flag = a.reset[env];
+    int64_t progress = a.progress[env];
+    const uint64_t env_global = (uint64_t)(C->env_offset + env);
+
+    // ---- load state -------------------------------------------------------------------------
+    LegConst L = {};
+    AntLane S = {};
+    float act0 = 0.f, act1 = 0.f;
+    if (is_ant) {
+        L = load_leg_const(M, leg);
+        const float* r = root_env + 13 * ant;
+        S.pos = V3{r[0], r[1], r[2]};
+        S.qx = r[3]; S.qy = r[4]; S.qz = r[5]; S.qw = r[6];
+        S.vel = V3{r[7], r[8], r[9]};
+        S.ang = V3{r[10], r[11], r[12]};
+        float4 d = reinterpret_cast<const float4*>(dof_env)[tid];       // (q1, qd1, q2, qd2): coalesced 16 B / lane
+        S.q[0] = d.x; S.qd[0] = d.y; S.q[1] = d.z; S.qd[1] = d.w;
+        float2 ac = reinterpret_cast<const float2*>(act_env)[tid];      // this lane's two actions
+        act0 = clampf(ac.x, -C->clip_actions, C->clip_actions);         // vec_task.py:127
+        act1 = clampf(ac.y, -C->clip_actions, C->clip_actions);
+    }
+    RigidState B = load_rigid(root_env + 13 * A);
+    float sens[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (TASK == MMS_TASK_ONE_ANT && is_ant) {      // sensors of the last simulated substep persist across a skipped step
+        const float* fs = a.foot_sensors + ((size_t)env * A + ant) * 24 + 6 * leg;
+#pragma unroll
+        for (int i = 0; i < 6; i++) sens[i] = fs[i];
+    }
+
+    // ---- physics: skipped for envs flagged for reset (their state is overwritten below) ------
+    if (a.do_physics && reset_flag == 0) {
+        const float h = C->dt / (float)C->substeps;
+        const float tau1 = act0 * L.gear[0] * C->power_scale;            // ten_ant.py:889
+        const float tau2 = act1 * L.gear[1] * C->power_scale;
+        for (int s = 0; s < C->substeps; s++) {
+            BoxPose bp;
+            bp.pos = B.pos; bp.R = quat_to_mat(B.qx, B.qy, B.qz, B.qw); bp.v = B.vel; bp.w = B.ang;
+            bp.half = V3{M->box_half[0], M->box_half[1], M->box_half[2]};
+            Sym6 IA0;
+            S6 pA0;
+            LegPass P;
+            if (is_ant) leg_inward(M, L, h, S, leg, tau1, tau2, true, bp, P, IA0, pA0);
+            else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
+            quad_sum(IA0, pA0);
+            S6 wr = S6{V3{0, 0, 0}, V3{0, 0, 0}};
+            if (is_ant) leg_outward(M, h, S, leg, true, bp, P, IA0, pA0, wr, TASK == MMS_TASK_ONE_ANT ? sens : nullptr);
+            s_wr[0 * (BLOCK + 1) + tid] = wr.a.x; s_wr[1 * (BLOCK + 1) + tid] = wr.a.y; s_wr[2 * (BLOCK + 1) + tid] = wr.a.z;
+            s_wr[3 * (BLOCK + 1) + tid] = wr.l.x; s_wr[4 * (BLOCK + 1) + tid] = wr.l.y; s_wr[5 * (BLOCK + 1) + tid] = wr.l.z;
+            __syncthreads();
+            if (is_box && tid - box_base < 6) {                          // component c summed in lane order
+                const float* col = s_wr + (tid - box_base) * (BLOCK + 1);
+                float t = 0.f;
+                for (int i = 0; i < n_ant_lanes; i++) t += col[i];
+                s_wtot[tid - box_base] = t;
+            }
+            __syncthreads();
+            if (is_box) {
+                Sym6 Ab;
+                S6 bb;
+                box_corner(M, h, B, bp.R, tid - box_base, Ab, bb);
+                oct_sum(Ab, bb);
+                S6 w = S6{V3{s_wtot[0], s_wtot[1], s_wtot[2]}, V3{s_wtot[3], s_wtot[4], s_wtot[5]}};
+                box_finish(M, h, B, bp.R, Ab, bb, w);
+                if (tid == box_base) store_rigid(s_box, B);
+            }
+            __syncthreads();
+            B = load_rigid(s_box);
+        }
+    }
+
+    // ---- post_physics_step: progress, reset_idx (ten_ant.py:894-901) --------------------------
+    progress += 1;
+    if (reset_flag != 0) {
+        if (is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env, env_global, a.step_index);
+        B = load_rigid(init_env + 13 * A);
+        progress = 0;
+    }
+    // ---- write the state back ---------------------------------------------------------------
+    if (is_ant) {
+        reinterpret_cast<float4*>(dof_env)[tid] = make_float4(S.q[0], S.qd[0], S.q[1], S.qd[1]);
+        if (leg == 0) {
+            float* r = root_env + 13 * ant;
+            r[0] = S.pos.x; r[1] = S.pos.y; r[2] = S.pos.z; r[3] = S.qx; r[4] = S.qy; r[5] = S.qz; r[6] = S.qw;
+            r[7] = S.vel.x; r[8] = S.vel.y; r[9] = S.vel.z; r[10] = S.ang.x; r[11] = S.ang.y; r[12] = S.ang.z;
+        }
+    }
+    if (tid == box_base) store_rigid(root_env + 13 * A, B);
+
+    // ---- observations + reward --------------------------------------------------------------
+    const float bgx = B.pos.x + origin.x, bgy = B.pos.y + origin.y;      // global frame
+    if (TASK == MMS_TASK_TEN_ANT) {
+        const float ang = box_angle(B.qz, B.qw);
+        const float sv = sinf(ang), cv = -cosf(ang);
+        if (is_ant) {
+            float pbx, pby, gbx, gby;
+            if (a.step_index == 0) {                                     // caches = construction-time poses (ten_ant.py:870-882)
+                const float* r0 = init_env + 13 * ant;
+                const float* b0 = init_env + 13 * A;
+                pbx = r0[0] + origin.x; pby = r0[1] + origin.y;
+                float a0 = box_angle(b0[5], b0[6]);
+                tenant_goal(ant, b0[0] + origin.x, b0[1] + origin.y, sinf(a0), -cosf(a0), gbx, gby);
+            } else {
+                pbx = prev_env[2 * ant]; pby = prev_env[2 * ant + 1];
+                gbx = prev_env[2 * A + 2 * ant]; gby = prev_env[2 * A + 2 * ant + 1];
+            }
+            TenAntLaneOut o = tenant_obs_reward_lane(C, L, S, ant, leg, origin, act0, act1, bgx, bgy, sv, cv, pbx, pby, gbx, gby, s_obs);
+            float ec = quad_sum(o.ec), lim = quad_sum(o.lim), ac = quad_sum(o.acost);
+            if (leg == 0) {
+                float* r = s_red + RP_STRIDE * ant;
+                r[RP_ADR] = o.adr; r[RP_GDR] = o.gdr; r[RP_GAR] = o.gar; r[RP_UP] = o.up; r[RP_EC] = ec; r[RP_LIM] = lim;
+                r[RP_FALLEN] = o.fallen; r[RP_ACOST] = ac;
+                prev_env[2 * ant] = o.px; prev_env[2 * ant + 1] = o.py;                 // ten_ant.py:906-926
+                prev_env[2 * A + 2 * ant] = o.gx; prev_env[2 * A + 2 * ant + 1] = o.gy;
+            }
+        }
+        if (tid == box_base) {
+            float* t = s_obs + 38 * A;
+            t[0] = bgx; t[1] = bgy; t[2] = B.qx; t[3] = B.qy; t[4] = B.qz; t[5] = B.qw; t[6] = 0.f; t[7] = 0.f;
+            prev_env[4 * A] = bgx; prev_env[4 * A + 1] = bgy;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float rew;
+            int64_t rs;
+            tenant_reward_finish(C, A, s_red, B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
+            a.rew[env] = rew;
+            a.reset[env] = rs;
+            a.progress[env] = progress;
+        }
+    } else {  // OneAnt
+        float pot_in = (a.step_index == 0) ? (-4.f / C->dt) : prev_env[4];
+        if (is_ant) {
+            AntObsCore core;
+            V3 pg;
+            OneAntLaneOut o = oneant_obs_lane(C, L, S, leg, origin, act0, act1, sens, s_obs, core, pg);
+            float ec = quad_sum(o.ec), lim = quad_sum(o.lim), ac = quad_sum(o.acost);
+            if (a.do_physics && reset_flag == 0) {
+                float* fs = a.foot_sensors + ((size_t)env * A + ant) * 24 + 6 * leg;
+#pragma unroll
+                for (int i = 0; i < 6; i++) fs[i] = sens[i];
+            }
+            if (tid == 0) {
+                float pbx, pby, bbx, bby;
+                if (a.step_index == 0) {
+                    pbx = init_env[0] + origin.x; pby = init_env[1] + origin.y;
+                    bbx = init_env[13] + origin.x; bby = init_env[14] + origin.y;
+                } else { pbx = prev_env[0]; pby = prev_env[1]; bbx = prev_env[2]; bby = prev_env[3]; }
+                float tbx = 0.f - bgx, tby = 0.f - bgy;
+                float pot = -sqrtf(tbx * tbx + tby * tby + 0.f * 0.f) / C->dt;          // one_ant.py:583-587
+                float rew;
+                int64_t rs;
+                oneant_reward(C, pg.z, core.up_proj, ec, lim, ac, pbx, pby, bbx, bby, pg.x, pg.y, bgx, bgy, B.qx, B.qy, B.qz, B.qw,
+                              progress, rew, rs);
+                a.rew[env] = rew;
+                a.reset[env] = rs;
+                a.progress[env] = progress;
+                prev_env[0] = pg.x; prev_env[1] = pg.y; prev_env[2] = bgx; prev_env[3] = bgy;   // one_ant.py:432-433
+                prev_env[4] = pot; prev_env[5] = pot_in;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- coalesced observation row(s) --------------------------------------------------------
+    write_obs_row(s_obs, obs_dim, C->clip_obs, a.obs + (size_t)env * obs_dim, a.obs_clipped + (size_t)env * obs_dim,
+                  a.obs_out ? a.obs_out + (size_t)env * obs_dim : nullptr, tid, BLOCK);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MultiIngenuity: one lane per helicopter, 4 lanes per env, 16 envs per wave64.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
+    const mms_config* __restrict__ C = a.cfg;
+    const mms_model* __restrict__ M = &C->model;
+    const int A = a.num_agents;                    // 4
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid / A, k = gid - env * A;
+    const bool live = env < a.num_envs;
+    const int e = live ? env : 0;
+    float* root = a.root_states + ((size_t)e * A + k) * 13;
+    const float* init = a.initial_root_states + ((size_t)e * A + k) * 13;
+    float* dof = a.dof_state + ((size_t)e * A + k) * 8;
+    const float* act = a.actions + (size_t)e * 6 * A + 6 * k;
+    const int64_t reset_flag = a.reset[e];
+    int64_t progress = a.progress[e];
+    RigidState B = load_rigid(root);
+    float dq[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dq[j] = dof[j];
+    if (a.do_physics && reset_flag == 0) {
+        // multi_ingenuity.py:268-327: thrust = dt * clamp(2000 a) vertical, lateral fraction clamp(+-0.2)
+        V3 thr[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            float a0 = clampf(act[3 * r + 0], -C->clip_actions, C->clip_actions);
+            float a1 = clampf(act[3 * r + 1], -C->clip_actions, C->clip_actions);
+            float a2 = clampf(act[3 * r + 2], -C->clip_actions, C->clip_actions);
+            float vert = clampf(a2 * 2000.f, -2000.f, 2000.f);
+            float tz = C->dt * vert;
+            thr[r] = V3{tz * clampf(a0, -0.2f, 0.2f), tz * clampf(a1, -0.2f, 0.2f), tz};
+        }
+        const float h = C->dt / (float)C->substeps;
+        for (int s = 0; s < C->substeps; s++) {
+            heli_substep(M, h, B, thr[0], thr[1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) dq[2 * j] += h * dq[2 * j + 1];   // visual rotors: kinematic
+        }
+    }
+    progress += 1;
+    if (reset_flag != 0) {
+        B = load_rigid(init);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { dq[2 * j] = 0.f; dq[2 * j + 1] = (j == 1) ? -50.f : (j == 3 ? 50.f : 0.f); }   // :231-238
+        progress = 0;
+    }
+    if (live) {
+        store_rigid(root, B);
+#pragma unroll
+        for (int j = 0; j < 8; j++) dof[j] = dq[j];
+        // obs = raw root states in the global frame (multi_ingenuity.py:351-357)
+        float* o = a.obs + (size_t)env * 13 * A + 13 * k;
+        float* oc = a.obs_clipped + (size_t)env * 13 * A + 13 * k;
+        float* oo = a.obs_out ? a.obs_out + (size_t)env * 13 * A + 13 * k : nullptr;
+        float row[13];
+        store_rigid(row, B);
+        row[0] += a.env_origin[3 * env]; row[1] += a.env_origin[3 * env + 1]; row[2] += a.env_origin[3 * env + 2];
+#pragma unroll
+        for (int j = 0; j < 13; j++) {
+            o[j] = row[j];
+            float c = clampf(row[j], -C->clip_obs, C->clip_obs);
+            oc[j] = c;
+            if (oo) oo[j] = c;
+        }
+    }
+    // the 4 helicopters of an env are the 4 lanes of a quad: every lane receives all four rows by DPP
+    // quad broadcasts and lane 0 evaluates the team reward.
+    float rows[4][13];
+    {
+        float mine[13];
+        store_rigid(mine, B);
+        const float ox = a.env_origin[3 * e], oy = a.env_origin[3 * e + 1], oz = a.env_origin[3 * e + 2];
+        mine[0] += ox; mine[1] += oy; mine[2] += oz;
+#pragma unroll
+        for (int j = 0; j < 13; j++) {
+            rows[0][j] = dpp_mov<0x00>(mine[j]);   // quad_perm [0,0,0,0]
+            rows[1][j] = dpp_mov<0x55>(mine[j]);   // [1,1,1,1]
+            rows[2][j] = dpp_mov<0xAA>(mine[j]);   // [2,2,2,2]
+            rows[3][j] = dpp_mov<0xFF>(mine[j]);   // [3,3,3,3]
+        }
+    }
+    if (live && k == 0) {
+        float rew;
+        int64_t rs;
+        ingenuity_reward(&rows[0][0], C->max_episode_length, progress, rew, rs);
+        a.rew[env] = rew;
+        a.reset[env] = rs;
+        a.progress[env] = progress;
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------
+size_t ant_step_lds_bytes(int block, int obs_dim, int num_agents) {
+    int obs_pad = (obs_dim + 3) & ~3;
+    return sizeof(float) * (size_t)(obs_pad + 6 * (block + 1) + 8 + 16 + RP_STRIDE * num_agents);
+}
+
+hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {
+    if (task == MMS_TASK_MULTI_INGENUITY) {
+        if (a.num_agents != 4) return hipErrorInvalidValue;
+        int total = a.num_envs * a.num_agents;
+        hipLaunchKernelGGL(ingenuity_step_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
+    const int lanes = ((4 * a.num_agents + 7) & ~7) + 8;
+    if (lanes <= 64) {
+        size_t lds = ant_step_lds_bytes(64, a.obs_dim, a.num_agents);
+        if (task == MMS_TASK_TEN_ANT) hipLaunchKernelGGL((ant_step_kernel<MMS_TASK_TEN_ANT, 64>), dim3(a.num_envs), dim3(64), lds, stream, a);
+        else hipLaunchKernelGGL((ant_step_kernel<MMS_TASK_ONE_ANT, 64>), dim3(a.num_envs), dim3(64), lds, stream, a);
+    } else if (lanes <= 512 && task == MMS_TASK_TEN_ANT) {
+        size_t lds = ant_step_lds_bytes(512, a.obs_dim, a.num_agents);
+        hipLaunchKernelGGL((ant_step_kernel<MMS_TASK_TEN_ANT, 512>), dim3(a.num_envs), dim3(512), lds, stream, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mms

@@ -33,9 +33,9 @@ class MmsModel(ctypes.Structure):
         ("dof_lower", ctypes.c_float * 8), ("dof_upper", ctypes.c_float * 8),
         ("dof_init", ctypes.c_float * 8), ("gear", ctypes.c_float * 8),
         ("armature", ctypes.c_float), ("joint_damping", ctypes.c_float),
-        ("limit_k", ctypes.c_float), ("limit_c", ctypes.c_float),
+        ("limit_k", ctypes.c_float), ("limit_c", ctypes.c_float), ("limit_ramp", ctypes.c_float),
         ("gnd_k", ctypes.c_float), ("gnd_c", ctypes.c_float), ("gnd_mu", ctypes.c_float),
-        ("slip_eps", ctypes.c_float),
+        ("slip_eps", ctypes.c_float), ("pen_ramp", ctypes.c_float),
         ("antbox_k", ctypes.c_float), ("antbox_c", ctypes.c_float),
         ("boxgnd_k", ctypes.c_float), ("boxgnd_c", ctypes.c_float),
         ("box_half", ctypes.c_float * 3), ("box_mass", ctypes.c_float), ("box_inertia", ctypes.c_float * 3),
@@ -196,8 +196,8 @@ def build_model(task, num_agents, dt, substeps, gravity):
     fill_ant(m)
     h = dt / substeps
     # --- compliance parameters (this build's model) ---
-    m.limit_k, m.limit_c = 5000.0, 20.0
-    m.gnd_k, m.gnd_c, m.gnd_mu, m.slip_eps = 2.0e4, 300.0, 1.0, 1.0e-2
+    m.limit_k, m.limit_c, m.limit_ramp = 5000.0, 20.0, 5.0e-3
+    m.gnd_k, m.gnd_c, m.gnd_mu, m.slip_eps, m.pen_ramp = 2.0e4, 300.0, 1.0, 1.0e-2, 1.0e-3
     if task == "OneAnt":
         bx, by, bz = 1.0, 1.0, 1.0                                         # one_ant.py:264
     else:

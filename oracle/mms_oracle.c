@@ -654,6 +654,10 @@ typedef struct { float pos[3]; float R[3][3]; float v[3]; float w[3]; float half
  * While active the force k d - (h k + c) v_n(new) is applied two-sidedly: no chatter at rest, no rebound;
  * the price is a viscous adhesion that lasts only while the shapes still overlap. */
 #define CONTACT_MARGIN 0.1f
+/* The damper is ramped in with the penetration depth, c(d) = c * clamp(d / ramp, 0, 1), so that the contact
+ * force is a continuous function of the state at the activation boundary (a constant damper would jump by
+ * c |v_n| there, and rounding-level differences would flip it). */
+static inline float ramp01(float d, float r) { return fminf(fmaxf(d / r, 0.f), 1.f); }
 
 /* Sphere (centre xs relative to O, O at world position Ow, radius rad) on a body with spatial velocity vb:
  * contact against the ground plane z = 0 -> cg, and against the box -> cb. */
@@ -669,7 +673,7 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
             float vp[3], wx[3];
             cross3(vb, xc, wx);
             for (int i = 0; i < 3; i++) vp[i] = vb[3 + i] + wx[i];
-            float gn = h * M->gnd_k + M->gnd_c;
+            float gn = h * M->gnd_k + M->gnd_c * ramp01(d, M->pen_ramp);
             float fn = fmaxf(M->gnd_k * d - gn * vp[2], 0.f);   /* explicit estimate: friction bound only */
             if (d > 0.f || d - h * vp[2] > 0.f) {               /* penetrating now or at the end of the step */
                 cg->active = 1;
@@ -720,7 +724,7 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
             for (int i = 0; i < 3; i++) { vp[i] = vb[3 + i] + wx[i]; rb[i] = Ow[i] + xc[i] - box->pos[i]; }
             cross3(box->w, rb, vbx);
             float vrel[3] = {vp[0] - box->v[0] - vbx[0], vp[1] - box->v[1] - vbx[1], vp[2] - box->v[2] - vbx[2]};
-            float gn = h * M->antbox_k + M->antbox_c;
+            float gn = h * M->antbox_k + M->antbox_c * ramp01(d, M->pen_ramp);
             if (d > 0.f || d - h * dot3(n, vrel) > 0.f) {
                 cb->active = 1;
                 memcpy(cb->xc, xc, sizeof(xc));
@@ -820,12 +824,16 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
         for (int j = 0; j < 2; j++) {
             int d = 2 * l + j;
             float q = dof[d][0], qd = dof[d][1];
-            float gl = h * M->limit_k + M->limit_c;
             float t = tau_motor[d] - M->joint_damping * qd;
             float De = M->armature + h * M->joint_damping;
             float ehi = q - M->dof_upper[d], elo = M->dof_lower[d] - q;
-            if (ehi > 0.f || ehi + h * qd > 0.f) { t += -M->limit_k * ehi - gl * qd; De += h * gl; }
-            else if (elo > 0.f || elo - h * qd > 0.f) { t += M->limit_k * elo - gl * qd; De += h * gl; }
+            if (ehi > 0.f || ehi + h * qd > 0.f) {
+                float gl = h * M->limit_k + M->limit_c * ramp01(ehi, M->limit_ramp);
+                t += -M->limit_k * ehi - gl * qd; De += h * gl;
+            } else if (elo > 0.f || elo - h * qd > 0.f) {
+                float gl = h * M->limit_k + M->limit_c * ramp01(elo, M->limit_ramp);
+                t += M->limit_k * elo - gl * qd; De += h * gl;
+            }
             tau[j] = t; Dextra[j] = De;
         }
         /* inward: foot */
@@ -955,7 +963,7 @@ static void box_substep(const mms_model* M, float h, float root[13], const float
         float wx[3], vp[3];
         cross3(w, xc, wx);
         for (int i = 0; i < 3; i++) vp[i] = v[i] + wx[i];
-        float gn = h * M->boxgnd_k + M->boxgnd_c;
+        float gn = h * M->boxgnd_k + M->boxgnd_c * ramp01(d, M->pen_ramp);
         if (!(d > 0.f || d - h * vp[2] > 0.f)) continue;
         contact_t ct;
         ct.active = 1;
@@ -1010,7 +1018,7 @@ static void heli_substep(const mms_model* M, float h, float root[13], const floa
         float wx[3], vp[3];
         cross3(v0, xc, wx);
         for (int i = 0; i < 3; i++) vp[i] = v0[3 + i] + wx[i];
-        float gn = h * M->heli_gnd_k + M->heli_gnd_c;
+        float gn = h * M->heli_gnd_k + M->heli_gnd_c * ramp01(d, M->pen_ramp);
         float fn = fmaxf(M->heli_gnd_k * d - gn * vp[2], 0.f);
         if (!(d > 0.f || d - h * vp[2] > 0.f)) continue;
         contact_t ct;

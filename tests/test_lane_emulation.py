@@ -1,0 +1,165 @@
+"""CPU check of the kernels' lane decomposition: the per-lane functions the HIP kernels are built from
+(massive_marl_benchmark_amd/csrc/mms_lane.h) run on the host over the lanes of each env
+(tests/emu/emu_step.cpp) and are compared with the oracle, step for step on identical state
+(teacher forced) and free running.  Tolerance 1e-4 abs fp32."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from massive_marl_benchmark_amd.model import MmsConfig, make_config, task_dims
+from oracle.oracle import F, I64, OracleEngine, f32, fp, ip
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_SRC = os.path.join(HERE, "emu", "emu_step.cpp")
+EMU_LIB = os.path.join(HERE, "emu", "_libemu.so")
+NAMES = ["actions", "obs", "obs_clipped", "rew", "reset", "progress", "root_states", "initial_root_states", "dof_state",
+         "env_origin", "prev", "reset_noise", "foot_sensors"]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    hdr = os.path.join(HERE, "..", "massive_marl_benchmark_amd", "csrc", "mms_lane.h")
+    if not os.path.exists(EMU_LIB) or os.path.getmtime(EMU_LIB) < max(os.path.getmtime(EMU_SRC), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                               "-o", EMU_LIB, EMU_SRC])
+    lib = ctypes.CDLL(EMU_LIB)
+    lib.emu_step.argtypes = [ctypes.POINTER(MmsConfig), F, F, F, F, I64, I64, F, F, F, F, F, F, F, ctypes.c_int, ctypes.c_uint64,
+                             ctypes.c_int, ctypes.c_int]
+    return lib
+
+
+class EmuEngine:
+    def __init__(self, lib, task, **kw):
+        self.lib = lib
+        self.ref = OracleEngine(task, **kw)          # only used to get identically initialised buffers
+        self.config = self.ref.config
+        self.buf = {n: self.ref.tensor(n).copy() for n in NAMES}
+        self.step_index = 0
+        self.obs_dim, self.prev_dim = self.ref.obs_dim, self.ref.prev_dim
+
+    def step(self, actions, physics=True):
+        b = self.buf
+        b["actions"][...] = actions
+        self.lib.emu_step(ctypes.byref(self.config), fp(b["actions"]), fp(b["obs"]), fp(b["obs_clipped"]), fp(b["rew"]),
+                          ip(b["reset"]), ip(b["progress"]), fp(b["root_states"]), fp(b["initial_root_states"]), fp(b["dof_state"]),
+                          fp(b["env_origin"]), fp(b["prev"]), fp(b["reset_noise"]), fp(b["foot_sensors"]), 1 if physics else 0,
+                          self.step_index, self.obs_dim, self.prev_dim)
+        self.step_index += 1
+
+
+STATE = ["root_states", "dof_state", "prev", "reset", "progress", "foot_sensors"]
+
+
+# Tolerances.  Poses (positions, quaternions, joint angles) agree to 1e-4 abs per step.  Velocities cannot:
+# the compliant contacts have k = 2e4 N/m, so ONE ulp of a torso height of 0.5 m (6e-8 m) is a 1e-3 N force
+# change on a 0.07 kg foot behind a 0.011 kg m^2 joint -- the oracle's own output moves by 5e-4 (median) to
+# 2e-3 rad/s when its input is perturbed by one ulp (measured).  Two correct fp32
+# implementations therefore differ by that much per step; a wrong term shows up as O(0.1..10).
+POSE_TOL = 1e-4
+VEL_TOL_MAX = 5e-2       # any single step, any entry (relative to max(1, |v|))
+VEL_TOL_TYPICAL = 2e-3   # median over steps of the per-step maximum
+
+
+def pose_vel_split(task, root, dof):
+    pose = [root[:, 0:7].ravel()]
+    vel = [root[:, 7:13].ravel()]
+    if task == "MultiIngenuity":
+        pose.append(dof[:, 0].ravel() * 0)               # visual rotor angles grow without bound: compared via velocity only
+        vel.append(dof[:, 1].ravel())
+    else:
+        pose.append(dof[:, 0].ravel())
+        vel.append(dof[:, 1].ravel())
+    return np.concatenate(pose), np.concatenate(vel)
+
+
+def compare(o, e, what, vel_err_log):
+    po, vo = pose_vel_split(o.task, o.tensor("root_states"), o.tensor("dof_state"))
+    pe, ve = pose_vel_split(o.task, e.buf["root_states"], e.buf["dof_state"])
+    assert np.max(np.abs(po - pe)) < POSE_TOL, (what, "pose", np.max(np.abs(po - pe)))
+    verr = np.max(np.abs(vo - ve) / np.maximum(1.0, np.abs(vo)))
+    assert verr < VEL_TOL_MAX, (what, "velocity", verr)
+    vel_err_log.append(verr)
+    np.testing.assert_array_equal(o.tensor("reset"), e.buf["reset"], err_msg=what)
+    np.testing.assert_array_equal(o.tensor("progress"), e.buf["progress"], err_msg=what)
+    # observations: global coordinates (hundreds of metres) -> relative; velocity entries inherit the velocity bound
+    ob, eb = o.tensor("obs"), e.buf["obs"]
+    assert np.max(np.abs(ob - eb) / np.maximum(1.0, np.abs(ob))) < VEL_TOL_MAX, what
+    oc, ec = o.tensor("obs_clipped"), e.buf["obs_clipped"]
+    assert np.max(np.abs(oc - ec)) < VEL_TOL_MAX
+    if o.task == "OneAnt":                                 # contact forces: k * (position rounding) again
+        fo, fe = o.tensor("foot_sensors"), e.buf["foot_sensors"]
+        assert np.max(np.abs(fo - fe) / np.maximum(1.0, np.abs(fo))) < VEL_TOL_MAX, what
+    # reward: 500 x differences of GLOBAL-frame fp32 positions (reference behaviour): one ulp
+    # of a coordinate several hundred metres from the origin is 3e-5..6e-5 m -> 0.03 reward per term, 2 terms per ant
+    gmax = float(np.max(np.abs(o.tensor("env_origin")))) + 30.0
+    rew_tol = 500.0 * float(np.spacing(np.float32(gmax))) * 2 * o.num_agents + 2e-3 * np.abs(o.tensor("rew")) + 1e-3
+    assert np.all(np.abs(o.tensor("rew") - e.buf["rew"]) <= rew_tol), (what, "rew", np.max(np.abs(o.tensor("rew") - e.buf["rew"])))
+
+
+@pytest.mark.parametrize("task,n,steps", [("TenAnt", 6, 120), ("OneAnt", 8, 120), ("MultiIngenuity", 8, 120)])
+def test_teacher_forced_parity(emu, task, n, steps):
+    kw = dict(num_envs=n, seed=5, total_envs=64, env_offset=3)
+    o = OracleEngine(task, **kw)
+    e = EmuEngine(emu, task, **kw)
+    rng = np.random.default_rng(1)
+    resets, verr = 0, []
+    for t in range(steps):
+        for name in STATE:                                # identical state in
+            e.buf[name][...] = o.tensor(name)
+        act = f32(rng.uniform(-1.2, 1.2, (n, o.num_actions)))
+        if task == "MultiIngenuity":
+            act[:, 2::3] = np.abs(act[:, 2::3]) * 0.12      # near hover thrust so that episodes last
+        o.step(act)
+        e.step(act)
+        compare(o, e, "%s step %d" % (task, t), verr)
+        resets += int(o.tensor("reset").sum())
+    assert np.median(verr) < VEL_TOL_TYPICAL, np.median(verr)
+    assert resets > 0 or task != "TenAnt"
+
+
+@pytest.mark.parametrize("task,n,steps", [("TenAnt", 4, 25), ("OneAnt", 4, 25), ("MultiIngenuity", 4, 60)])
+def test_free_running_parity(emu, task, n, steps):
+    kw = dict(num_envs=n, seed=9)
+    o = OracleEngine(task, **kw)
+    e = EmuEngine(emu, task, **kw)
+    rng = np.random.default_rng(2)
+    for t in range(steps):
+        act = f32(rng.uniform(-1, 1, (n, o.num_actions)))
+        if task == "MultiIngenuity":
+            act[:, 2::3] = np.abs(act[:, 2::3]) * 0.12
+        o.step(act)
+        e.step(act)
+        # contact dynamics amplify the per-step rounding differences exponentially: free running is only a
+        # short-horizon sanity bound on the poses (the per-step gate is test_teacher_forced_parity)
+        ro, re_ = o.tensor("root_states"), e.buf["root_states"]
+        assert np.max(np.abs(ro[:, :7] - re_[:, :7])) < 2e-2, t
+        np.testing.assert_array_equal(o.tensor("progress"), e.buf["progress"])
+
+
+def test_glue_fixture_through_lanes(emu):
+    """The reference step-glue fixture through the lane code path (physics off)."""
+    from conftest import angle_close, load_golden
+    g = load_golden("tenant_step_glue")
+    S, n = g["actions"].shape[0], g["actions"].shape[1]
+    e = EmuEngine(emu, "TenAnt", num_envs=n, clip_obs=5.0, external_noise=True)
+    for t in range(S):
+        loc = g["sim_root"][t].reshape(n, 11, 13).copy()
+        loc[:, :, 0:3] -= g["env_origin"][:, None, :]
+        e.buf["root_states"][...] = loc.reshape(n * 11, 13)
+        e.buf["dof_state"][...] = g["sim_dof"][t]
+        e.buf["reset_noise"][:, :8] = g["noise_pos"][t]
+        e.buf["reset_noise"][:, 8:] = g["noise_vel"][t]
+        if t == 2:
+            e.buf["progress"][7] = 998
+        e.step(g["actions"][t], physics=False)
+        np.testing.assert_array_equal(e.buf["reset"], g["reset"][t])
+        np.testing.assert_array_equal(e.buf["progress"], g["progress"][t])
+        ang = np.zeros(388, bool)
+        for k in range(10):
+            ang[38 * k + 9:38 * k + 12] = True
+        assert np.max(np.abs(e.buf["obs"][:, ~ang] - g["obs"][t][:, ~ang])) < 2e-4
+        assert angle_close(e.buf["obs"][:, ang], g["obs"][t][:, ang], 0) < 2e-4
+        assert np.max(np.abs(e.buf["rew"] - g["rew"][t])) < 0.4
