@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec, TenAnt, 4096 envs per GPU, PPO rollout (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one PPO rollout step over this rank's 4096 envs: actor + critic inference (the reference's
+ActorCritic, agents/algorithms/rl/ppo/module.py: two MLPs [1024,1024,512], ELU, fp32), Gaussian action
+sample + log-prob, the fused VecTask step (mms_step: physics substeps + reset + obs + reward in one HIP
+launch), RolloutStorage.add_transitions, and every nsteps=8 steps the GAE scan + advantage normalisation
+(the span timed as collection_time in agents/algorithms/rl/ppo/ppo.py:123-161 plus compute_returns).
+Envs are sharded over ranks with no data-path collective (weak scaling); `value` = all ranks' env-steps
+divided by the slowest rank's time.  Inputs are synthetic and resident in HBM before the timed region.
+
+The JSON line also carries
+  sim_only      the same engine stepped with pre-drawn actions (no policy), the series the step kernel's
+                roofline is computed from,
+  roofline      step kernel: algorithmic bytes (4660 B per env-step) / measured launch
+                duration against the 8 TB/s HBM peak,
+  cpu_baseline  the CPU oracle (oracle/mms_oracle.c, OpenMP over envs) on a bounded sample of the same
+                workload -- rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 4660
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
+NSTEPS = 8                              # cfg/ppo/config.yaml:23
+GAMMA, LAM = 0.96, 0.95                 # cfg/ppo/config.yaml:30-31
+
+
+def shard_for_rank(rank, world, envs_per_gpu):
+    """(env_offset, total_envs) of rank's shard: rank r owns global envs [r*n, (r+1)*n)."""
+    return rank * envs_per_gpu, world * envs_per_gpu
+
+
+def build_policy(torch, obs_dim, act_dim, device, dtype):
+    nn = torch.nn
+
+    def mlp(out):
+        return nn.Sequential(nn.Linear(obs_dim, 1024), nn.ELU(), nn.Linear(1024, 1024), nn.ELU(), nn.Linear(1024, 512), nn.ELU(),
+                             nn.Linear(512, out))
+    actor, critic = mlp(act_dim).to(device=device, dtype=dtype), mlp(1).to(device=device, dtype=dtype)
+    log_std = torch.full((act_dim,), float(torch.log(torch.tensor(0.8))), device=device)      # init_noise_std 0.8
+    return actor, critic, log_std
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--policy-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-graph", action="store_true", help="launch the rollout step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for the CPU baseline (0 = sized for ~15 s)")
+    args = ap.parse_args()
+
+    import torch
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.storage import RolloutStorage
+    from massive_marl_benchmark_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (the engine has no CPU path)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    N = args.num_envs
+    env_offset, total_envs = shard_for_rank(rank, world, N)
+    eng = Engine("TenAnt", num_envs=N, device=local_rank, seed=0, env_offset=env_offset, total_envs=total_envs, clip_obs=5.0)
+    obs_dim, act_dim = eng.obs_dim, eng.num_actions
+    pdtype = torch.float32 if args.policy_dtype == "fp32" else torch.bfloat16
+    torch.manual_seed(1234 + rank)
+    actor, critic, log_std = build_policy(torch, obs_dim, act_dim, device, pdtype)
+    storage = RolloutStorage(N, NSTEPS, (obs_dim,), (0,), (act_dim,), device=str(device))
+    states = torch.zeros(N, 0, device=device)
+    actions_buf, rew, reset = eng.tensor("actions"), eng.tensor("rew"), eng.tensor("reset")
+    obs_clipped = eng.tensor("obs_clipped")
+    std = log_std.exp()
+    sigma = std.repeat(N, 1)
+    half_log_2pi = 0.9189385332046727
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- sim-only series: pre-drawn U(-1,1) actions, ring of 16 ---------------------
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    ring = [(torch.rand(N, act_dim, generator=g) * 2 - 1).to(device) for _ in range(16)]
+
+    def sim_step(i):
+        actions_buf.copy_(ring[i % 16])
+        eng.step()
+
+    for i in range(64):                         # reset-all + settle
+        sim_step(i)
+    barrier()
+    sim_steps = max((args.steps // 16) * 16, 256)
+    sim_graph = None
+    if not args.no_graph:                       # 16 steps (one pass over the ring) per hipGraph replay
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            sim_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(sim_graph, stream=side):
+                for i in range(16):
+                    sim_step(i)
+        torch.cuda.current_stream(device).wait_stream(side)
+        sim_graph.replay()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    if sim_graph is None:
+        for i in range(sim_steps):
+            sim_step(i)
+    else:
+        for _ in range(sim_steps // 16):
+            sim_graph.replay()
+    torch.cuda.synchronize()
+    sim_wall = time.perf_counter() - t0
+    # step-kernel launch duration: back-to-back launches with nothing else on the stream, HIP events around them
+    ev0.record()
+    for i in range(256):
+        eng.step()
+    ev1.record()
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / 256.0
+
+    # ---- PPO rollout series -----------------------------------------------------------------------------------
+    def rollout_step():
+        t = storage.step
+        cur_obs = obs_clipped                                            # current observation (clamped +-5, vec_task.py:131)
+        with torch.no_grad():
+            x = cur_obs.to(pdtype)
+            mean = actor(x).float()                                      # module.py:73-87
+            value = critic(x).float()
+            noise = torch.randn_like(mean)
+            act = mean + std * noise
+            logp = (-0.5 * noise * noise - log_std - half_log_2pi).sum(-1)
+        storage.observations[t].copy_(cur_obs)                           # the obs the action was computed from
+        actions_buf.copy_(act)
+        eng.step()
+        storage.add_transitions(storage.observations[t], states, act, rew, reset, value, logp, mean, sigma)
+        if storage.step == NSTEPS:
+            with torch.no_grad():
+                last_values = critic(obs_clipped.to(pdtype)).float()
+            storage.compute_returns(last_values, GAMMA, LAM)
+            storage.clear()
+
+    graph = None
+    for _ in range(NSTEPS):                      # eager warm-up (allocator, rocBLAS handles)
+        rollout_step()
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        # one graph = one full PPO iteration's rollout (8 steps + GAE): launch-bound inner loop -> hipGraph
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(NSTEPS):
+                    rollout_step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize()
+
+    def run_steps(k):
+        if graph is None:
+            for _ in range(k):
+                rollout_step()
+        else:
+            assert k % NSTEPS == 0
+            for _ in range(k // NSTEPS):
+                graph.replay()
+
+    K = args.steps if graph is None else max(NSTEPS, (args.steps // NSTEPS) * NSTEPS)
+    W = args.warmup if graph is None else max(NSTEPS, ((args.warmup + NSTEPS - 1) // NSTEPS) * NSTEPS)
+    run_steps(W)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(K)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed, sim_wall, kernel_ms], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed, sim_wall, kernel_ms = [float(x) for x in tmax.tolist()]
+    finite = bool(torch.isfinite(obs_clipped).all().item()) and bool(torch.isfinite(rew).all().item())
+    resets_seen = int(eng.tensor("reset_count").sum().item())
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(N, args.cpu_steps)
+
+    if rank == 0:
+        value = world * N * K / elapsed
+        sim_value = world * N * sim_steps / sim_wall
+        achieved = ALGO_BYTES_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/sec (whole node), TenAnt 4096 envs/GPU, PPO rollout",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
+                                   "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
+                       "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
+                       "hipgraph": graph is not None, "finite": finite, "resets_total": resets_seen},
+            "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
+                         "note": "engine step with pre-drawn actions (ring of 16)", "hipgraph": sim_graph is not None},
+            "roofline": {"bound": "hbm", "kernel": "mms::ant_step_kernel<TEN_ANT,64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "launch_ms": kernel_ms},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+    eng.close()
+
+
+def cpu_baseline(n_envs, steps):
+    """The CPU oracle (a port: the reference's own CPU pipeline is Isaac Gym, absent here) on the same workload:
+    TenAnt N envs, sim step with pre-drawn actions, OpenMP over envs on all host cores."""
+    import numpy as np
+    from oracle.oracle import OracleEngine
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    ora = OracleEngine("TenAnt", num_envs=n_envs, seed=0)
+    rng = np.random.default_rng(1234)
+    ring = [rng.uniform(-1, 1, (n_envs, 80)).astype(np.float32) for _ in range(16)]
+    for i in range(4):
+        ora.step(ring[i])
+    t0 = time.perf_counter()
+    ora.step(ring[4])
+    one = time.perf_counter() - t0
+    if steps <= 0:
+        steps = int(max(8, min(400, 15.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ora.step(ring[i % 16])
+    dt = time.perf_counter() - t0
+    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle engine (C, OpenMP over envs), TenAnt %d envs x %d sim steps, %.1f s" % (n_envs, steps, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -117,7 +117,9 @@ int mms_destroy(mms_handle h);
  * "obs_clipped" [N,obs_dim] f32 (clamped to +-clip_obs), "rew" [N] f32, "reset" [N] i64,
  * "progress" [N] i64, "root_states" [N*actors,13] f32 (env-local frame), "dof_state" [N*dofs,2] f32,
  * "env_origin" [N,3] f32, "prev" [N,prev_dim] f32 (pos_before / goal_before / box_before caches),
- * "reset_noise" [N,16] f32, "foot_sensors" [N*A,24] f32, "initial_root_states" [N*actors,13] f32. */
+ * "reset_noise" [N,16] f32, "foot_sensors" [N*A,24] f32, "initial_root_states" [N*actors,13] f32,
+ * "reset_count" [N] i64 (number of resets of each env so far: the counter of the reset-noise RNG, keyed with
+ * the seed and the GLOBAL env index, so results do not depend on how envs are sharded over GPUs). */
 int mms_get_tensor(mms_handle h, const char* name, mms_tensor* out);
 
 /* One VecTask step: clamp actions, physics substeps, progress += 1, reset flagged envs,
@@ -137,10 +139,6 @@ int mms_reset_all(mms_handle h, void* hip_stream);
  * Tests / fixtures only. */
 int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_host,
                   const int64_t* env_ids, int64_t n, void* hip_stream);
-
-/* Sets the engine's step counter (keys the reset-noise RNG; 0 also re-initialises the caches from the
- * construction-time poses on the next step).  Tests only. */
-int mms_set_step_index(mms_handle h, uint64_t step_index);
 
 /* Optional extra destination for the clamped observation row, e.g. slot t of a rollout buffer
  * [T,N,obs_dim]; NULL disables.  The pointer must stay valid until the next bind. */

@@ -1,0 +1,57 @@
+"""ctypes loader of the HIP engine library (csrc/ -> lib/libmms.so).  There is no CPU fallback: if the
+library is missing or no HIP device is usable the product path raises."""
+import ctypes
+import os
+
+from .model import MmsConfig, MmsTensor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmms.so")
+_lib = None
+
+# every symbol include/mms.h declares (tests check that the library exports all of them)
+SYMBOLS = ["mms_create", "mms_destroy", "mms_get_tensor", "mms_step", "mms_post_step", "mms_reset_all", "mms_set_state",
+           "mms_bind_obs_out", "mms_marl_views", "mms_gae_ppo", "mms_adv_normalize", "mms_gae_marl",
+           "mms_last_error", "mms_abi_version"]
+
+
+class MmsError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MmsError("HIP engine library not built: %s is missing (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C massive_marl_benchmark_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, c64, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    L.mms_create.argtypes = [ctypes.POINTER(MmsConfig), ctypes.POINTER(vp)]
+    L.mms_destroy.argtypes = [vp]
+    L.mms_get_tensor.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(MmsTensor)]
+    L.mms_step.argtypes = [vp, vp]
+    L.mms_post_step.argtypes = [vp, vp]
+    L.mms_reset_all.argtypes = [vp, vp]
+    L.mms_set_state.argtypes = [vp, ctypes.c_char_p, vp, ci, ctypes.POINTER(c64), c64, vp]
+    L.mms_bind_obs_out.argtypes = [vp, vp]
+    L.mms_marl_views.argtypes = [ci, vp, vp, c64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    L.mms_gae_ppo.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, c64, cf, cf, vp]
+    L.mms_adv_normalize.argtypes = [ci, vp, vp, c64, vp]
+    L.mms_gae_marl.argtypes = [ci, vp, vp, vp, vp, ctypes.c_int32, c64, cf, cf, ctypes.c_int32, vp, vp, vp]
+    L.mms_last_error.argtypes = [vp]
+    L.mms_last_error.restype = ctypes.c_char_p
+    L.mms_abi_version.restype = ci
+    _lib = L
+    return L
+
+
+def last_error(handle=None):
+    msg = lib().mms_last_error(handle)
+    return msg.decode() if msg else ""
+
+
+def check(rc, handle=None, what=""):
+    if rc != 0:
+        raise MmsError("%s failed: %s" % (what, last_error(handle)))

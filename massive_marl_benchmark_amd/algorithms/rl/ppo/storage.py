@@ -1,0 +1,95 @@
+"""RolloutStorage (agents/algorithms/rl/ppo/storage.py:5-87) with the GAE scan and the advantage
+normalisation as HIP kernels (mms_gae_ppo / mms_adv_normalize) instead of T sequential torch launches.
+
+Same fields, shapes and method names, so PPO (agents/algorithms/rl/ppo/ppo.py) uses it unchanged.
+Additions, all optional: `observation_slot(t)` hands the engine a slot to write the clamped observation
+row into directly (zero-copy rollout), and `process_group` makes the advantage statistics global over
+data-parallel ranks (two float64 all-reduced over RCCL between the two kernels)."""
+import ctypes
+
+import torch
+from torch.utils.data.sampler import BatchSampler, SequentialSampler, SubsetRandomSampler
+
+from .... import _lib
+from ....engine import current_stream_ptr
+
+
+class RolloutStorage:
+    def __init__(self, num_envs, num_transitions_per_env, obs_shape, states_shape, actions_shape, device='cpu',
+                 sampler='sequential', process_group=None):
+        self.device = device
+        self.sampler = sampler
+        T, N = num_transitions_per_env, num_envs
+        z = lambda *s, **k: torch.zeros(*s, device=self.device, **k)
+        self.observations = z(T, N, *obs_shape)
+        self.states = z(T, N, *states_shape)
+        self.rewards = z(T, N, 1)
+        self.actions = z(T, N, *actions_shape)
+        self.dones = z(T, N, 1).byte()
+        self.actions_log_prob = z(T, N, 1)
+        self.values = z(T, N, 1)
+        self.returns = z(T, N, 1)
+        self.advantages = z(T, N, 1)
+        self.mu = z(T, N, *actions_shape)
+        self.sigma = z(T, N, *actions_shape)
+        self.num_transitions_per_env = T
+        self.num_envs = N
+        self.step = 0
+        self.process_group = process_group
+        self._stats = torch.zeros(3, dtype=torch.float64, device=self.device)
+
+    def observation_slot(self, t):
+        return self.observations[t]
+
+    def add_transitions(self, observations, states, actions, rewards, dones, values, actions_log_prob, mu, sigma):
+        if self.step >= self.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        s = self.step
+        if observations.data_ptr() != self.observations[s].data_ptr():      # already written in place by the engine?
+            self.observations[s].copy_(observations)
+        self.states[s].copy_(states)
+        self.actions[s].copy_(actions)
+        self.rewards[s].copy_(rewards.view(-1, 1))
+        self.dones[s].copy_(dones.view(-1, 1))
+        self.values[s].copy_(values)
+        self.actions_log_prob[s].copy_(actions_log_prob.view(-1, 1))
+        self.mu[s].copy_(mu)
+        self.sigma[s].copy_(sigma)
+        self.step += 1
+
+    def clear(self):
+        self.step = 0
+
+    def compute_returns(self, last_values, gamma, lam):
+        """storage.py:51-65: reverse GAE scan, then advantages = (ret - V - mean) / (std + 1e-8)."""
+        dev = torch.device(self.device)
+        if dev.type != "cuda":
+            raise _lib.MmsError("RolloutStorage.compute_returns runs on the HIP device only (no CPU fallback)")
+        T, N = self.num_transitions_per_env, self.num_envs
+        L = _lib.lib()
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        stream = current_stream_ptr(dev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        last_values = last_values.contiguous().view(-1).float()
+        _lib.check(L.mms_gae_ppo(idx, p(self.rewards), p(self.dones), p(self.values), p(last_values), p(self.returns),
+                                 p(self.advantages), p(self._stats), T, N, float(gamma), float(lam), stream), None, "mms_gae_ppo")
+        if self.process_group is not None:
+            torch.distributed.all_reduce(self._stats, group=self.process_group)   # sum, sum of squares, count
+        _lib.check(L.mms_adv_normalize(idx, p(self.advantages), p(self._stats), T * N, stream), None, "mms_adv_normalize")
+
+    def get_statistics(self):
+        done = self.dones.cpu().clone()
+        done[-1] = 1
+        flat_dones = done.permute(1, 0, 2).reshape(-1, 1)
+        done_indices = torch.cat((flat_dones.new_tensor([-1], dtype=torch.int64), flat_dones.nonzero(as_tuple=False)[:, 0]))
+        trajectory_lengths = (done_indices[1:] - done_indices[:-1])
+        return trajectory_lengths.float().mean(), self.rewards.mean()
+
+    def mini_batch_generator(self, num_mini_batches):
+        batch_size = self.num_envs * self.num_transitions_per_env
+        mini_batch_size = batch_size // num_mini_batches
+        if self.sampler == "sequential":
+            subset = SequentialSampler(range(batch_size))
+        elif self.sampler == "random":
+            subset = SubsetRandomSampler(range(batch_size))
+        return BatchSampler(subset, mini_batch_size, drop_last=True)

@@ -34,7 +34,6 @@ struct mms_engine {
     mms_config cfg;
     mms_config* d_cfg = nullptr;
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
-    uint64_t step_index = 0;
     float* obs_out = nullptr;
     std::vector<mms_buffer> bufs;
     std::string err;
@@ -79,11 +78,11 @@ static int add_buffer(mms_engine* e, const char* name, int dtype, std::initializ
 
 extern "C" {
 
-int mms_abi_version(void) { return MMS_ABI_VERSION; }
+__attribute__((visibility("default"))) int mms_abi_version(void) { return MMS_ABI_VERSION; }
 
-const char* mms_last_error(mms_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+__attribute__((visibility("default"))) const char* mms_last_error(mms_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int mms_create(const mms_config* cfg, mms_handle* out) {
+__attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms_handle* out) {
     if (!cfg || !out) return fail(nullptr, "mms_create: null argument");
     if (cfg->abi_version != MMS_ABI_VERSION) return fail(nullptr, "mms_create: ABI version mismatch");
     if (cfg->num_envs <= 0 || cfg->num_agents <= 0) return fail(nullptr, "mms_create: num_envs and num_agents must be positive");
@@ -110,6 +109,7 @@ int mms_create(const mms_config* cfg, mms_handle* out) {
     rc |= add_buffer(e, "rew", MMS_F32, {N}, 1);
     rc |= add_buffer(e, "reset", MMS_I64, {N}, 1);
     rc |= add_buffer(e, "progress", MMS_I64, {N}, 1);
+    rc |= add_buffer(e, "reset_count", MMS_I64, {N}, 1);
     rc |= add_buffer(e, "root_states", MMS_F32, {(int64_t)N * e->actors, 13}, 1);
     rc |= add_buffer(e, "initial_root_states", MMS_F32, {(int64_t)N * e->actors, 13}, 1);
     rc |= add_buffer(e, "dof_state", MMS_F32, {(int64_t)N * e->dofs, 2}, 1);
@@ -120,7 +120,7 @@ int mms_create(const mms_config* cfg, mms_handle* out) {
     if (rc) { g_create_error = e->err; mms_destroy(e); return 1; }
 
     // construction-time scene (host), uploaded once
-    std::vector<float> init((size_t)N * e->actors * 13, 0.f), origin((size_t)N * 3, 0.f);
+    std::vector<float> init((size_t)N * e->actors * 13, 0.f), origin((size_t)N * 3, 0.f), prev((size_t)N * e->prev_dim, 0.f);
     std::vector<int64_t> ones((size_t)N, 1);
     int64_t npr = (int64_t)sqrt((double)cfg->total_envs);
     if (npr < 1) npr = 1;
@@ -141,6 +141,29 @@ int mms_create(const mms_config* cfg, mms_handle* out) {
             for (int k = 0; k < A; k++) { r[13 * k + 0] = 0.f; r[13 * k + 1] = hy[k % 4]; r[13 * k + 2] = 1.f; }
         }
     }
+    // caches start as the construction-time poses: what reset_idx reads from the not-yet-refreshed tensors on the
+    // first step (ten_ant.py:870-882, one_ant.py:410-411), in the global frame
+    for (int i = 0; i < N; i++) {
+        const float* r = init.data() + (size_t)i * e->actors * 13;
+        const float* o = origin.data() + 3 * (size_t)i;
+        float* pv = prev.data() + (size_t)i * e->prev_dim;
+        if (cfg->task == MMS_TASK_TEN_ANT) {
+            const float* b = r + 13 * A;
+            float bx = b[0] + o[0], by = b[1] + o[1];
+            float ang = atanf((2.f * b[6] * b[5]) / (1.f - 2.f * b[5] * b[5]));   // ten_ant.py:935-947
+            float sv = sinf(ang), cv = -cosf(ang);
+            for (int k = 0; k < A; k++) {
+                pv[2 * k] = r[13 * k] + o[0]; pv[2 * k + 1] = r[13 * k + 1] + o[1];
+                float off = 1.5f + 3.0f * (float)(k / 2);
+                pv[2 * A + 2 * k] = (k % 2 == 0) ? bx + off * sv : bx - off * sv;
+                pv[2 * A + 2 * k + 1] = (k % 2 == 0) ? by + off * cv : by - off * cv;
+            }
+            pv[4 * A] = bx; pv[4 * A + 1] = by;
+        } else if (cfg->task == MMS_TASK_ONE_ANT) {
+            pv[0] = r[0] + o[0]; pv[1] = r[1] + o[1]; pv[2] = r[13] + o[0]; pv[3] = r[14] + o[1];
+            pv[4] = -4.f / cfg->dt; pv[5] = -4.f / cfg->dt;                       // one_ant.py:143-144
+        }
+    }
     hipError_t he = hipSuccess;
     auto up = [&](const char* name, const void* src, size_t bytes) {
         if (he == hipSuccess) he = hipMemcpy(find(e, name)->ptr, src, bytes, hipMemcpyHostToDevice);
@@ -148,6 +171,7 @@ int mms_create(const mms_config* cfg, mms_handle* out) {
     up("initial_root_states", init.data(), init.size() * 4);
     up("root_states", init.data(), init.size() * 4);
     up("env_origin", origin.data(), origin.size() * 4);
+    up("prev", prev.data(), prev.size() * 4);
     up("reset", ones.data(), ones.size() * 8);                                   // base_task.py:62-63
     if (he == hipSuccess) he = hipMalloc((void**)&e->d_cfg, sizeof(mms_config));
     if (he == hipSuccess) he = hipMemcpy(e->d_cfg, &e->cfg, sizeof(mms_config), hipMemcpyHostToDevice);
@@ -157,7 +181,7 @@ int mms_create(const mms_config* cfg, mms_handle* out) {
     return 0;
 }
 
-int mms_destroy(mms_handle h) {
+__attribute__((visibility("default"))) int mms_destroy(mms_handle h) {
     if (!h) return 0;
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
@@ -168,7 +192,7 @@ int mms_destroy(mms_handle h) {
     return 0;
 }
 
-int mms_get_tensor(mms_handle h, const char* name, mms_tensor* out) {
+__attribute__((visibility("default"))) int mms_get_tensor(mms_handle h, const char* name, mms_tensor* out) {
     if (!h || !name || !out) return fail(h, "mms_get_tensor: null argument");
     mms_buffer* b = find(h, name);
     if (!b) return fail(h, std::string("mms_get_tensor: unknown buffer '") + name + "'");
@@ -199,20 +223,19 @@ static int do_step(mms_handle h, void* stream, int physics) {
     a.prev = (float*)find(h, "prev")->ptr;
     a.reset_noise = (const float*)find(h, "reset_noise")->ptr;
     a.foot_sensors = (float*)find(h, "foot_sensors")->ptr;
-    a.step_index = h->step_index;
+    a.reset_count = (int64_t*)find(h, "reset_count")->ptr;
     a.do_physics = physics;
     a.num_envs = h->cfg.num_envs;
     a.num_agents = h->cfg.num_agents;
     a.obs_dim = h->obs_dim;
     a.prev_dim = h->prev_dim;
     MMS_HIP(h, mms::launch_step(a, h->cfg.task, (hipStream_t)stream));
-    h->step_index += 1;
     return 0;
 }
-int mms_step(mms_handle h, void* hip_stream) { return do_step(h, hip_stream, 1); }
-int mms_post_step(mms_handle h, void* hip_stream) { return do_step(h, hip_stream, 0); }
+__attribute__((visibility("default"))) int mms_step(mms_handle h, void* hip_stream) { return do_step(h, hip_stream, 1); }
+__attribute__((visibility("default"))) int mms_post_step(mms_handle h, void* hip_stream) { return do_step(h, hip_stream, 0); }
 
-int mms_reset_all(mms_handle h, void* hip_stream) {
+__attribute__((visibility("default"))) int mms_reset_all(mms_handle h, void* hip_stream) {
     if (!h) return fail(nullptr, "mms_reset_all: null handle");
     std::vector<int64_t> ones((size_t)h->cfg.num_envs, 1);
     MMS_HIP(h, hipMemcpyAsync(find(h, "reset")->ptr, ones.data(), ones.size() * 8, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
@@ -220,7 +243,7 @@ int mms_reset_all(mms_handle h, void* hip_stream) {
     return 0;
 }
 
-int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_host, const int64_t* env_ids, int64_t n, void* hip_stream) {
+__attribute__((visibility("default"))) int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_host, const int64_t* env_ids, int64_t n, void* hip_stream) {
     if (!h || !name || !src) return fail(h, "mms_set_state: null argument");
     mms_buffer* b = find(h, name);
     if (!b) return fail(h, std::string("mms_set_state: unknown buffer '") + name + "'");
@@ -239,15 +262,9 @@ int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_ho
     return 0;
 }
 
-int mms_bind_obs_out(mms_handle h, void* dst) {
+__attribute__((visibility("default"))) int mms_bind_obs_out(mms_handle h, void* dst) {
     if (!h) return fail(nullptr, "mms_bind_obs_out: null handle");
     h->obs_out = (float*)dst;
-    return 0;
-}
-
-int mms_set_step_index(mms_handle h, uint64_t step_index) {
-    if (!h) return 1;
-    h->step_index = step_index;
     return 0;
 }
 
@@ -263,23 +280,23 @@ static int dev_guard(int device) {
         if (err_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(err_); return 1; } \
     } while (0)
 
-int mms_marl_views(int device, const float* obs_clipped, float* obs_all, int64_t n, int32_t agents, int32_t per_agent, int32_t shared, void* s) {
+__attribute__((visibility("default"))) int mms_marl_views(int device, const float* obs_clipped, float* obs_all, int64_t n, int32_t agents, int32_t per_agent, int32_t shared, void* s) {
     if (dev_guard(device)) return 1;
     MMS_FREE(mms::launch_marl_views(obs_clipped, obs_all, n, agents, per_agent, shared, (hipStream_t)s));
     return 0;
 }
-int mms_gae_ppo(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
+__attribute__((visibility("default"))) int mms_gae_ppo(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
                 float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam, void* s) {
     if (dev_guard(device)) return 1;
     MMS_FREE(mms::launch_gae_ppo(rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam, (hipStream_t)s));
     return 0;
 }
-int mms_adv_normalize(int device, float* advantages, const double* stats, int64_t count, void* s) {
+__attribute__((visibility("default"))) int mms_adv_normalize(int device, float* advantages, const double* stats, int64_t count, void* s) {
     if (dev_guard(device)) return 1;
     MMS_FREE(mms::launch_adv_normalize(advantages, stats, count, (hipStream_t)s));
     return 0;
 }
-int mms_gae_marl(int device, const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int64_t N,
+__attribute__((visibility("default"))) int mms_gae_marl(int device, const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int64_t N,
                  float gamma, float lam, int32_t use_norm, const float* norm_mean, const float* norm_var, void* s) {
     if (dev_guard(device)) return 1;
     MMS_FREE(mms::launch_gae_marl(rewards, value_preds, masks, returns, T, N, gamma, lam, use_norm, norm_mean, norm_var, (hipStream_t)s));

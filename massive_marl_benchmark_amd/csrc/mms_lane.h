@@ -651,7 +651,7 @@ enum { RP_ADR = 0, RP_GDR, RP_GAR, RP_UP, RP_EC, RP_LIM, RP_FALLEN, RP_ACOST, RP
 
 // reset_idx for one leg lane (ten_ant.py:810-868): root <- initial, dof <- clamp(init + noise), vel <- noise
 MMS_HD void ant_reset_lane(const mms_config* C, const LegConst& L, AntLane& S, const float* init_root13, int leg,
-                           const float* ext_noise16, uint64_t env_global, uint64_t step_index) {
+                           const float* ext_noise16, uint64_t env_global, uint64_t reset_count) {
     S.pos = V3{init_root13[0], init_root13[1], init_root13[2]};
     S.qx = init_root13[3]; S.qy = init_root13[4]; S.qz = init_root13[5]; S.qw = init_root13[6];
     S.vel = V3{init_root13[7], init_root13[8], init_root13[9]};
@@ -661,8 +661,8 @@ MMS_HD void ant_reset_lane(const mms_config* C, const LegConst& L, AntLane& S, c
         float npos, nvel;
         if (C->external_noise) { npos = ext_noise16[d]; nvel = ext_noise16[8 + d]; }
         else {
-            npos = 0.4f * rand_uniform(C->seed, env_global, step_index, (uint32_t)d) - 0.2f;
-            nvel = 0.2f * rand_uniform(C->seed, env_global, step_index, (uint32_t)(8 + d)) - 0.1f;
+            npos = 0.4f * rand_uniform(C->seed, env_global, reset_count, (uint32_t)d) - 0.2f;
+            nvel = 0.2f * rand_uniform(C->seed, env_global, reset_count, (uint32_t)(8 + d)) - 0.1f;
         }
         S.q[j] = clampf(L.init[j] + npos, L.lower[j], L.upper[j]);
         S.qd[j] = nvel;

@@ -22,7 +22,7 @@ struct StepArgs {
     float* prev;                      // [N, prev_dim]
     const float* reset_noise;         // [N, 16]
     float* foot_sensors;              // [N * A, 24]
-    uint64_t step_index;
+    int64_t* reset_count;             // [N] resets so far (RNG counter)
     int32_t do_physics;
     int32_t num_envs, num_agents, obs_dim, prev_dim;
 };

@@ -194,9 +194,11 @@ __global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
     // ---- post_physics_step: progress, reset_idx (ten_ant.py:894-901) --------------------------
     progress += 1;
     if (reset_flag != 0) {
-        if (is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env, env_global, a.step_index);
+        if (is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env, env_global, (uint64_t)a.reset_count[env]);
         B = load_rigid(init_env + 13 * A);
         progress = 0;
+        __syncthreads();                               // every lane has read reset_count before it is bumped
+        if (tid == 0) a.reset_count[env] += 1;
     }
     // ---- write the state back ---------------------------------------------------------------
     if (is_ant) {
@@ -215,17 +217,9 @@ __global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
         const float ang = box_angle(B.qz, B.qw);
         const float sv = sinf(ang), cv = -cosf(ang);
         if (is_ant) {
-            float pbx, pby, gbx, gby;
-            if (a.step_index == 0) {                                     // caches = construction-time poses (ten_ant.py:870-882)
-                const float* r0 = init_env + 13 * ant;
-                const float* b0 = init_env + 13 * A;
-                pbx = r0[0] + origin.x; pby = r0[1] + origin.y;
-                float a0 = box_angle(b0[5], b0[6]);
-                tenant_goal(ant, b0[0] + origin.x, b0[1] + origin.y, sinf(a0), -cosf(a0), gbx, gby);
-            } else {
-                pbx = prev_env[2 * ant]; pby = prev_env[2 * ant + 1];
-                gbx = prev_env[2 * A + 2 * ant]; gby = prev_env[2 * A + 2 * ant + 1];
-            }
+            // caches: previous step's values; mms_create fills them from the construction-time poses (ten_ant.py:870-882)
+            const float pbx = prev_env[2 * ant], pby = prev_env[2 * ant + 1];
+            const float gbx = prev_env[2 * A + 2 * ant], gby = prev_env[2 * A + 2 * ant + 1];
             TenAntLaneOut o = tenant_obs_reward_lane(C, L, S, ant, leg, origin, act0, act1, bgx, bgy, sv, cv, pbx, pby, gbx, gby, s_obs);
             float ec = quad_sum(o.ec), lim = quad_sum(o.lim), ac = quad_sum(o.acost);
             if (leg == 0) {
@@ -251,7 +245,7 @@ __global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
             a.progress[env] = progress;
         }
     } else {  // OneAnt
-        float pot_in = (a.step_index == 0) ? (-4.f / C->dt) : prev_env[4];
+        float pot_in = prev_env[4];
         if (is_ant) {
             AntObsCore core;
             V3 pg;
@@ -263,11 +257,7 @@ __global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
                 for (int i = 0; i < 6; i++) fs[i] = sens[i];
             }
             if (tid == 0) {
-                float pbx, pby, bbx, bby;
-                if (a.step_index == 0) {
-                    pbx = init_env[0] + origin.x; pby = init_env[1] + origin.y;
-                    bbx = init_env[13] + origin.x; bby = init_env[14] + origin.y;
-                } else { pbx = prev_env[0]; pby = prev_env[1]; bbx = prev_env[2]; bby = prev_env[3]; }
+                const float pbx = prev_env[0], pby = prev_env[1], bbx = prev_env[2], bby = prev_env[3];
                 float tbx = 0.f - bgx, tby = 0.f - bgy;
                 float pot = -sqrtf(tbx * tbx + tby * tby + 0.f * 0.f) / C->dt;          // one_ant.py:583-587
                 float rew;
@@ -334,6 +324,7 @@ __global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) { dq[2 * j] = 0.f; dq[2 * j + 1] = (j == 1) ? -50.f : (j == 3 ? 50.f : 0.f); }   // :231-238
         progress = 0;
+        if (live && k == 0) a.reset_count[env] += 1;
     }
     if (live) {
         store_rigid(root, B);

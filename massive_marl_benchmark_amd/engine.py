@@ -1,0 +1,109 @@
+"""Engine: owns one `mms_handle` and exposes its device buffers as NON-owning torch tensors (zero copy).
+
+This is what replaces `gymapi.acquire_gym() ... prepare_sim()` plus the `acquire_*_tensor` /
+`gymtorch.wrap_tensor` calls of the reference tasks (agents/tasks/ten_ant.py:84-104)."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .model import MmsTensor, make_config, task_dims
+
+_TORCH_DTYPES = {0: (torch.float32, "<f4"), 1: (torch.int64, "<i8"), 2: (torch.int32, "<i4"), 3: (torch.uint8, "|u1")}
+
+
+class _DevicePtr:
+    """Minimal __cuda_array_interface__ carrier: lets torch.as_tensor view engine memory without copying."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        self._owner = owner
+
+
+def current_stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine:
+    def __init__(self, task, cfg=None, num_envs=None, num_agents=None, device=0, seed=0, env_offset=0, total_envs=None,
+                 clip_obs=5.0, clip_actions=1.0, external_noise=False):
+        if not torch.cuda.is_available():
+            raise _lib.MmsError("no HIP device visible to torch: the engine has no CPU path")
+        self.task = task
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.config = make_config(task, cfg, num_envs=num_envs, num_agents=num_agents, device=device, seed=seed,
+                                  env_offset=env_offset, total_envs=total_envs, clip_obs=clip_obs, clip_actions=clip_actions,
+                                  external_noise=external_noise)
+        self.num_envs = self.config.num_envs
+        self.num_agents = self.config.num_agents
+        self.actors, self.dofs, self.num_actions, self.obs_dim, self.prev_dim = task_dims(task, self.num_agents)
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        torch.cuda.set_device(self.device)
+        _lib.check(L.mms_create(ctypes.byref(self.config), ctypes.byref(self._h)), None, "mms_create")
+        self._tensors = {}
+        self._bound = None
+
+    # -- buffers -----------------------------------------------------------------------------
+    def tensor(self, name):
+        t = self._tensors.get(name)
+        if t is None:
+            mt = MmsTensor()
+            _lib.check(_lib.lib().mms_get_tensor(self._h, name.encode(), ctypes.byref(mt)), self._h, "mms_get_tensor")
+            dtype, typestr = _TORCH_DTYPES[mt.dtype]
+            shape = [mt.shape[i] for i in range(mt.ndim)]
+            t = torch.as_tensor(_DevicePtr(mt.ptr, shape, typestr, self), device=self.device)
+            assert t.data_ptr() == mt.ptr and t.dtype == dtype
+            self._tensors[name] = t
+        return t
+
+    # -- stepping ----------------------------------------------------------------------------
+    def step(self):
+        _lib.check(_lib.lib().mms_step(self._h, current_stream_ptr(self.device)), self._h, "mms_step")
+
+    def post_step(self):
+        _lib.check(_lib.lib().mms_post_step(self._h, current_stream_ptr(self.device)), self._h, "mms_post_step")
+
+    def reset_all(self):
+        _lib.check(_lib.lib().mms_reset_all(self._h, current_stream_ptr(self.device)), self._h, "mms_reset_all")
+
+    def bind_obs_out(self, tensor_or_none):
+        """Extra destination for the clamped observation row (e.g. a rollout-buffer slot [N, obs_dim])."""
+        if tensor_or_none is None:
+            ptr = None
+        else:
+            t = tensor_or_none
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == self.num_envs * self.obs_dim
+            ptr = ctypes.c_void_p(t.data_ptr())
+        self._bound = tensor_or_none          # keep it alive
+        _lib.check(_lib.lib().mms_bind_obs_out(self._h, ptr), self._h, "mms_bind_obs_out")
+
+    def set_state(self, name, src, env_ids=None):
+        """Tests / fixtures: copy `src` (torch tensor on this device, or a numpy array) into a named buffer."""
+        L = _lib.lib()
+        if torch.is_tensor(src):
+            src = src.contiguous()
+            ptr, is_host = ctypes.c_void_p(src.data_ptr()), 0 if src.is_cuda else 1
+        else:
+            import numpy as np
+            src = np.ascontiguousarray(src)
+            ptr, is_host = ctypes.c_void_p(src.ctypes.data), 1
+        if env_ids is None:
+            ids, n = None, 0
+        else:
+            arr = (ctypes.c_int64 * len(env_ids))(*[int(i) for i in env_ids])
+            ids, n = arr, len(env_ids)
+        _lib.check(L.mms_set_state(self._h, name.encode(), ptr, is_host, ids, n, current_stream_ptr(self.device)), self._h, "mms_set_state")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._tensors.clear()
+            _lib.lib().mms_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -525,7 +525,7 @@ static inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-MO_EXPORT float mo_rand_uniform(uint64_t seed, uint64_t env_global, uint64_t step, uint32_t k) {
+MO_EXPORT float mo_rand_uniform(uint64_t seed, uint64_t env_global, uint64_t step, uint32_t k) { /* step = the env's reset count */
     uint32_t x = mix32((uint32_t)seed ^ 0x9E3779B9U);
     x = mix32(x ^ (uint32_t)(seed >> 32));
     x = mix32(x ^ (uint32_t)env_global);
@@ -1049,101 +1049,12 @@ static void heli_substep(const mms_model* M, float h, float root[13], const floa
 typedef struct mo_engine {
     mms_config cfg;
     int N, A, actors, dofs_per_env, num_actions, obs_dim, prev_dim;
-    uint64_t step_index;
     float *actions, *obs, *obs_clipped, *rew, *root_states, *initial_root_states, *dof_state, *env_origin, *prev,
         *reset_noise, *foot_sensors;
-    int64_t *reset, *progress;
+    int64_t *reset, *progress, *reset_count;
 } mo_engine;
 
 static int is_ant_task(int task) { return task == MMS_TASK_TEN_ANT || task == MMS_TASK_ONE_ANT; }
-
-MO_EXPORT mo_engine* mo_create(const mms_config* cfg) {
-    if (cfg->abi_version != MMS_ABI_VERSION) return NULL;
-    mo_engine* e = (mo_engine*)calloc(1, sizeof(mo_engine));
-    e->cfg = *cfg;
-    int N = e->N = cfg->num_envs, A = e->A = cfg->num_agents;
-    if (is_ant_task(cfg->task)) {
-        e->actors = A + 1; e->dofs_per_env = 8 * A; e->num_actions = 8 * A;
-        e->obs_dim = (cfg->task == MMS_TASK_TEN_ANT) ? 38 * A + 8 : 60;
-        e->prev_dim = (cfg->task == MMS_TASK_TEN_ANT) ? 4 * A + 2 : 6;  /* OneAnt: pos_before, box_before, potentials, prev_potentials */
-    } else {
-        e->actors = A; e->dofs_per_env = 4 * A; e->num_actions = 6 * A; e->obs_dim = 13 * A; e->prev_dim = 3 * A;
-    }
-    e->actions = (float*)calloc((size_t)N * e->num_actions, 4);
-    e->obs = (float*)calloc((size_t)N * e->obs_dim, 4);
-    e->obs_clipped = (float*)calloc((size_t)N * e->obs_dim, 4);
-    e->rew = (float*)calloc(N, 4);
-    e->root_states = (float*)calloc((size_t)N * e->actors * 13, 4);
-    e->initial_root_states = (float*)calloc((size_t)N * e->actors * 13, 4);
-    e->dof_state = (float*)calloc((size_t)N * e->dofs_per_env * 2, 4);
-    e->env_origin = (float*)calloc((size_t)N * 3, 4);
-    e->prev = (float*)calloc((size_t)N * e->prev_dim, 4);
-    e->reset_noise = (float*)calloc((size_t)N * 16, 4);
-    e->foot_sensors = (float*)calloc((size_t)N * A * 24, 4);
-    e->reset = (int64_t*)calloc(N, 8);
-    e->progress = (int64_t*)calloc(N, 8);
-    int64_t npr = (int64_t)sqrt((double)cfg->total_envs);
-    if (npr < 1) npr = 1;
-    for (int i = 0; i < N; i++) {
-        int64_t gi = cfg->env_offset + i;
-        e->env_origin[3 * i + 0] = (float)(gi % npr) * 2.f * cfg->env_spacing;  /* SURVEY B.2 grid convention */
-        e->env_origin[3 * i + 1] = (float)(gi / npr) * 2.f * cfg->env_spacing;
-        e->env_origin[3 * i + 2] = 0.f;
-        e->reset[i] = 1;                                                      /* base_task.py:62-63 */
-        float* r = e->initial_root_states + (size_t)i * e->actors * 13;
-        for (int k = 0; k < e->actors; k++) r[13 * k + 6] = 1.f;
-        if (is_ant_task(cfg->task)) {
-            for (int k = 0; k < A; k++) {
-                float off = (A == 1) ? 0.f : (1.5f + 3.f * (float)(k / 2)) * ((k % 2 == 0) ? -1.f : 1.f);
-                r[13 * k + 0] = cfg->ant_start_x; r[13 * k + 1] = off; r[13 * k + 2] = cfg->ant_start_z;
-            }
-            for (int j = 0; j < 3; j++) r[13 * A + j] = cfg->box_start[j];
-        } else {
-            static const float hy[4] = {2.f, -2.f, 6.f, -6.f};               /* multi_ingenuity.py:157-164 */
-            for (int k = 0; k < A; k++) { r[13 * k + 0] = 0.f; r[13 * k + 1] = hy[k % 4]; r[13 * k + 2] = 1.f; }
-        }
-    }
-    memcpy(e->root_states, e->initial_root_states, (size_t)N * e->actors * 13 * 4);
-    /* caches start as the construction-time positions (ten_ant.py:870-882 on the first step) */
-    return e;
-}
-MO_EXPORT void mo_destroy(mo_engine* e) {
-    if (!e) return;
-    free(e->actions); free(e->obs); free(e->obs_clipped); free(e->rew); free(e->root_states);
-    free(e->initial_root_states); free(e->dof_state); free(e->env_origin); free(e->prev); free(e->reset_noise);
-    free(e->foot_sensors); free(e->reset); free(e->progress); free(e);
-}
-MO_EXPORT void* mo_tensor(mo_engine* e, const char* name, int64_t* numel) {
-#define T(nm, p, cnt) if (!strcmp(name, nm)) { *numel = (int64_t)(cnt); return (void*)(p); }
-    T("actions", e->actions, (size_t)e->N * e->num_actions)
-    T("obs", e->obs, (size_t)e->N * e->obs_dim)
-    T("obs_clipped", e->obs_clipped, (size_t)e->N * e->obs_dim)
-    T("rew", e->rew, e->N)
-    T("reset", e->reset, e->N)
-    T("progress", e->progress, e->N)
-    T("root_states", e->root_states, (size_t)e->N * e->actors * 13)
-    T("initial_root_states", e->initial_root_states, (size_t)e->N * e->actors * 13)
-    T("dof_state", e->dof_state, (size_t)e->N * e->dofs_per_env * 2)
-    T("env_origin", e->env_origin, (size_t)e->N * 3)
-    T("prev", e->prev, (size_t)e->N * e->prev_dim)
-    T("reset_noise", e->reset_noise, (size_t)e->N * 16)
-    T("foot_sensors", e->foot_sensors, (size_t)e->N * e->A * 24)
-#undef T
-    *numel = 0;
-    return NULL;
-}
-MO_EXPORT void mo_dims(mo_engine* e, int32_t out[6]) {
-    out[0] = e->actors; out[1] = e->dofs_per_env; out[2] = e->num_actions; out[3] = e->obs_dim; out[4] = e->prev_dim; out[5] = e->A;
-}
-MO_EXPORT void mo_set_step_index(mo_engine* e, uint64_t s) { e->step_index = s; }
-
-static void reward_params_from_cfg(const mms_config* c, reward_params* rp) {
-    rp->up_weight = c->up_weight; rp->heading_weight = c->heading_weight; rp->actions_cost = c->actions_cost;
-    rp->energy_cost = c->energy_cost; rp->joints_at_limit_cost = c->joints_at_limit_cost;
-    rp->termination_height = c->termination_height; rp->death_cost = c->death_cost;
-    rp->quat_reward_scale = c->quat_reward_scale; rp->ant_dist_reward_scale = c->ant_dist_reward_scale;
-    rp->goal_dist_reward_scale = c->goal_dist_reward_scale; rp->max_episode_length = c->max_episode_length;
-}
 
 /* global-frame copy of a root row: position + env origin, rest unchanged */
 static void to_global(const float* root_local, const float* origin, float out[13]) {
@@ -1173,6 +1084,96 @@ static void init_prev_from_initial(mo_engine* e, int i) {
     }
 }
 
+MO_EXPORT mo_engine* mo_create(const mms_config* cfg) {
+    if (cfg->abi_version != MMS_ABI_VERSION) return NULL;
+    mo_engine* e = (mo_engine*)calloc(1, sizeof(mo_engine));
+    e->cfg = *cfg;
+    int N = e->N = cfg->num_envs, A = e->A = cfg->num_agents;
+    if (is_ant_task(cfg->task)) {
+        e->actors = A + 1; e->dofs_per_env = 8 * A; e->num_actions = 8 * A;
+        e->obs_dim = (cfg->task == MMS_TASK_TEN_ANT) ? 38 * A + 8 : 60;
+        e->prev_dim = (cfg->task == MMS_TASK_TEN_ANT) ? 4 * A + 2 : 6;  /* OneAnt: pos_before, box_before, potentials, prev_potentials */
+    } else {
+        e->actors = A; e->dofs_per_env = 4 * A; e->num_actions = 6 * A; e->obs_dim = 13 * A; e->prev_dim = 3 * A;
+    }
+    e->actions = (float*)calloc((size_t)N * e->num_actions, 4);
+    e->obs = (float*)calloc((size_t)N * e->obs_dim, 4);
+    e->obs_clipped = (float*)calloc((size_t)N * e->obs_dim, 4);
+    e->rew = (float*)calloc(N, 4);
+    e->root_states = (float*)calloc((size_t)N * e->actors * 13, 4);
+    e->initial_root_states = (float*)calloc((size_t)N * e->actors * 13, 4);
+    e->dof_state = (float*)calloc((size_t)N * e->dofs_per_env * 2, 4);
+    e->env_origin = (float*)calloc((size_t)N * 3, 4);
+    e->prev = (float*)calloc((size_t)N * e->prev_dim, 4);
+    e->reset_noise = (float*)calloc((size_t)N * 16, 4);
+    e->foot_sensors = (float*)calloc((size_t)N * A * 24, 4);
+    e->reset = (int64_t*)calloc(N, 8);
+    e->progress = (int64_t*)calloc(N, 8);
+    e->reset_count = (int64_t*)calloc(N, 8);
+    int64_t npr = (int64_t)sqrt((double)cfg->total_envs);
+    if (npr < 1) npr = 1;
+    for (int i = 0; i < N; i++) {
+        int64_t gi = cfg->env_offset + i;
+        e->env_origin[3 * i + 0] = (float)(gi % npr) * 2.f * cfg->env_spacing;  /* SURVEY B.2 grid convention */
+        e->env_origin[3 * i + 1] = (float)(gi / npr) * 2.f * cfg->env_spacing;
+        e->env_origin[3 * i + 2] = 0.f;
+        e->reset[i] = 1;                                                      /* base_task.py:62-63 */
+        float* r = e->initial_root_states + (size_t)i * e->actors * 13;
+        for (int k = 0; k < e->actors; k++) r[13 * k + 6] = 1.f;
+        if (is_ant_task(cfg->task)) {
+            for (int k = 0; k < A; k++) {
+                float off = (A == 1) ? 0.f : (1.5f + 3.f * (float)(k / 2)) * ((k % 2 == 0) ? -1.f : 1.f);
+                r[13 * k + 0] = cfg->ant_start_x; r[13 * k + 1] = off; r[13 * k + 2] = cfg->ant_start_z;
+            }
+            for (int j = 0; j < 3; j++) r[13 * A + j] = cfg->box_start[j];
+        } else {
+            static const float hy[4] = {2.f, -2.f, 6.f, -6.f};               /* multi_ingenuity.py:157-164 */
+            for (int k = 0; k < A; k++) { r[13 * k + 0] = 0.f; r[13 * k + 1] = hy[k % 4]; r[13 * k + 2] = 1.f; }
+        }
+    }
+    memcpy(e->root_states, e->initial_root_states, (size_t)N * e->actors * 13 * 4);
+    /* caches start as the construction-time positions (ten_ant.py:870-882 on the first step) */
+    for (int i = 0; i < N; i++) init_prev_from_initial(e, i);
+    return e;
+}
+MO_EXPORT void mo_destroy(mo_engine* e) {
+    if (!e) return;
+    free(e->actions); free(e->obs); free(e->obs_clipped); free(e->rew); free(e->root_states);
+    free(e->initial_root_states); free(e->dof_state); free(e->env_origin); free(e->prev); free(e->reset_noise);
+    free(e->foot_sensors); free(e->reset); free(e->progress); free(e->reset_count); free(e);
+}
+MO_EXPORT void* mo_tensor(mo_engine* e, const char* name, int64_t* numel) {
+#define T(nm, p, cnt) if (!strcmp(name, nm)) { *numel = (int64_t)(cnt); return (void*)(p); }
+    T("actions", e->actions, (size_t)e->N * e->num_actions)
+    T("obs", e->obs, (size_t)e->N * e->obs_dim)
+    T("obs_clipped", e->obs_clipped, (size_t)e->N * e->obs_dim)
+    T("rew", e->rew, e->N)
+    T("reset", e->reset, e->N)
+    T("progress", e->progress, e->N)
+    T("reset_count", e->reset_count, e->N)
+    T("root_states", e->root_states, (size_t)e->N * e->actors * 13)
+    T("initial_root_states", e->initial_root_states, (size_t)e->N * e->actors * 13)
+    T("dof_state", e->dof_state, (size_t)e->N * e->dofs_per_env * 2)
+    T("env_origin", e->env_origin, (size_t)e->N * 3)
+    T("prev", e->prev, (size_t)e->N * e->prev_dim)
+    T("reset_noise", e->reset_noise, (size_t)e->N * 16)
+    T("foot_sensors", e->foot_sensors, (size_t)e->N * e->A * 24)
+#undef T
+    *numel = 0;
+    return NULL;
+}
+MO_EXPORT void mo_dims(mo_engine* e, int32_t out[6]) {
+    out[0] = e->actors; out[1] = e->dofs_per_env; out[2] = e->num_actions; out[3] = e->obs_dim; out[4] = e->prev_dim; out[5] = e->A;
+}
+
+static void reward_params_from_cfg(const mms_config* c, reward_params* rp) {
+    rp->up_weight = c->up_weight; rp->heading_weight = c->heading_weight; rp->actions_cost = c->actions_cost;
+    rp->energy_cost = c->energy_cost; rp->joints_at_limit_cost = c->joints_at_limit_cost;
+    rp->termination_height = c->termination_height; rp->death_cost = c->death_cost;
+    rp->quat_reward_scale = c->quat_reward_scale; rp->ant_dist_reward_scale = c->ant_dist_reward_scale;
+    rp->goal_dist_reward_scale = c->goal_dist_reward_scale; rp->max_episode_length = c->max_episode_length;
+}
+
 /* post-physics glue for one env: progress, reset, obs, reward, caches. */
 static void post_step_env(mo_engine* e, int i, int first_step) {
     const mms_config* c = &e->cfg;
@@ -1195,8 +1196,8 @@ static void post_step_env(mo_engine* e, int i, int first_step) {
                 if (c->external_noise) { npos[j] = e->reset_noise[16 * i + j]; nvel[j] = e->reset_noise[16 * i + 8 + j]; }
                 else {
                     uint64_t gi = (uint64_t)(c->env_offset + i);
-                    npos[j] = 0.4f * mo_rand_uniform(c->seed, gi, e->step_index, (uint32_t)j) - 0.2f;
-                    nvel[j] = 0.2f * mo_rand_uniform(c->seed, gi, e->step_index, (uint32_t)(8 + j)) - 0.1f;
+                    npos[j] = 0.4f * mo_rand_uniform(c->seed, gi, (uint64_t)e->reset_count[i], (uint32_t)j) - 0.2f;
+                    nvel[j] = 0.2f * mo_rand_uniform(c->seed, gi, (uint64_t)e->reset_count[i], (uint32_t)(8 + j)) - 0.1f;
                 }
             }
             for (int k = 0; k < A; k++)                                    /* same noise for every ant: ten_ant.py:822-854 */
@@ -1210,6 +1211,7 @@ static void post_step_env(mo_engine* e, int i, int first_step) {
         }
         e->progress[i] = 0;
         e->reset[i] = 0;
+        e->reset_count[i] += 1;
     }
     float* obs = e->obs + (size_t)i * e->obs_dim;
     reward_params rp;
@@ -1294,14 +1296,11 @@ static void physics_env(mo_engine* e, int i) {
 /* BaseTask.step (base_task.py:129-149).  Envs flagged for reset skip the physics: their state is
  * overwritten by reset_idx before anything reads it. */
 MO_EXPORT void mo_step(mo_engine* e, int do_physics) {
-    int first = (e->step_index == 0);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < e->N; i++) {
-        if (first) init_prev_from_initial(e, i);
         if (do_physics && e->reset[i] == 0) physics_env(e, i);
-        post_step_env(e, i, first);
+        post_step_env(e, i, 0);
     }
-    e->step_index += 1;
 }
 
 /* unit-level entry points for the physics KATs */

@@ -36,7 +36,6 @@ def lib():
         _lib.mo_tensor.argtypes = [ctypes.c_void_p, ctypes.c_char_p, I64]
         _lib.mo_step.argtypes = [ctypes.c_void_p, ctypes.c_int]
         _lib.mo_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
-        _lib.mo_set_step_index.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         _lib.mo_rand_uniform.restype = ctypes.c_float
         _lib.mo_rand_uniform.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
         cf, ci, c64 = ctypes.c_float, ctypes.c_int, ctypes.c_int64
@@ -77,7 +76,7 @@ def i64(a):
     return np.ascontiguousarray(a, dtype=np.int64)
 
 
-_I64_NAMES = ("reset", "progress")
+_I64_NAMES = ("reset", "progress", "reset_count")
 
 
 class OracleEngine:
@@ -112,9 +111,6 @@ class OracleEngine:
         if actions is not None:
             self.tensor("actions")[...] = actions
         lib().mo_step(self._h, 1 if physics else 0)
-
-    def set_step_index(self, s):
-        lib().mo_set_step_index(self._h, int(s))
 
     def close(self):
         if self._h:

@@ -28,10 +28,10 @@ static float quad4(const float x[4]) { return (x[0] + x[1]) + (x[2] + x[3]); }
 struct Bufs {
     const float* actions; float* obs; float* obs_clipped; float* rew; int64_t* reset; int64_t* progress;
     float* root_states; const float* initial_root_states; float* dof_state; const float* env_origin; float* prev;
-    const float* reset_noise; float* foot_sensors;
+    const float* reset_noise; float* foot_sensors; int64_t* reset_count;
 };
 
-static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_physics, uint64_t step_index, int obs_dim, int prev_dim) {
+static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_physics, int obs_dim, int prev_dim) {
     const mms_model* M = &C->model;
     const int A = C->num_agents, task = C->task, nl = 4 * A, actors = A + 1;
     float* root_env = b.root_states + (size_t)env * actors * 13;
@@ -100,9 +100,10 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
     }
     progress += 1;
     if (reset_flag != 0) {
-        for (int t = 0; t < nl; t++) ant_reset_lane(C, L[t], S[t], init_env + 13 * (t >> 2), t & 3, b.reset_noise + 16 * (size_t)env, env_global, step_index);
+        for (int t = 0; t < nl; t++) ant_reset_lane(C, L[t], S[t], init_env + 13 * (t >> 2), t & 3, b.reset_noise + 16 * (size_t)env, env_global, (uint64_t)b.reset_count[env]);
         B = load_rigid(init_env + 13 * A);
         progress = 0;
+        b.reset_count[env] += 1;
     }
     for (int t = 0; t < nl; t++) {
         dof_env[4 * t] = S[t].q[0]; dof_env[4 * t + 1] = S[t].qd[0]; dof_env[4 * t + 2] = S[t].q[1]; dof_env[4 * t + 3] = S[t].qd[1];
@@ -123,14 +124,7 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
         std::vector<float> newprev(prev_dim);
         for (int t = 0; t < nl; t++) {
             int ant = t >> 2;
-            float pbx, pby, gbx, gby;
-            if (step_index == 0) {
-                const float* r0 = init_env + 13 * ant;
-                const float* b0 = init_env + 13 * A;
-                pbx = r0[0] + origin.x; pby = r0[1] + origin.y;
-                float a0 = box_angle(b0[5], b0[6]);
-                tenant_goal(ant, b0[0] + origin.x, b0[1] + origin.y, sinf(a0), -cosf(a0), gbx, gby);
-            } else { pbx = prev_env[2 * ant]; pby = prev_env[2 * ant + 1]; gbx = prev_env[2 * A + 2 * ant]; gby = prev_env[2 * A + 2 * ant + 1]; }
+            float pbx = prev_env[2 * ant], pby = prev_env[2 * ant + 1], gbx = prev_env[2 * A + 2 * ant], gby = prev_env[2 * A + 2 * ant + 1];
             o[t] = tenant_obs_reward_lane(C, L[t], S[t], ant, t & 3, origin, act0[t], act1[t], bgx, bgy, sv, cv, pbx, pby, gbx, gby, s_obs.data());
         }
         for (int q = 0; q < nl; q += 4) {
@@ -147,7 +141,7 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
         prev_env[4 * A] = bgx; prev_env[4 * A + 1] = bgy;
         tenant_reward_finish(C, A, s_red.data(), B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
     } else {
-        float pot_in = (step_index == 0) ? (-4.f / C->dt) : prev_env[4];
+        float pot_in = prev_env[4];
         OneAntLaneOut o[4];
         AntObsCore core;
         V3 pg;
@@ -155,9 +149,7 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
         float e[4] = {o[0].ec, o[1].ec, o[2].ec, o[3].ec}, l[4] = {o[0].lim, o[1].lim, o[2].lim, o[3].lim}, c[4] = {o[0].acost, o[1].acost, o[2].acost, o[3].acost};
         if (do_physics && reset_flag == 0)
             for (int t = 0; t < 4; t++) for (int i = 0; i < 6; i++) b.foot_sensors[(size_t)env * 24 + 6 * t + i] = sens[6 * t + i];
-        float pbx, pby, bbx, bby;
-        if (step_index == 0) { pbx = init_env[0] + origin.x; pby = init_env[1] + origin.y; bbx = init_env[13] + origin.x; bby = init_env[14] + origin.y; }
-        else { pbx = prev_env[0]; pby = prev_env[1]; bbx = prev_env[2]; bby = prev_env[3]; }
+        float pbx = prev_env[0], pby = prev_env[1], bbx = prev_env[2], bby = prev_env[3];
         float tbx = 0.f - bgx, tby = 0.f - bgy;
         float pot = -sqrtf(tbx * tbx + tby * tby + 0.f * 0.f) / C->dt;
         oneant_reward(C, pg.z, core.up_proj, quad4(e), quad4(l), quad4(c), pbx, pby, bbx, bby, pg.x, pg.y, bgx, bgy, B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
@@ -208,7 +200,7 @@ static void emu_heli_env(const mms_config* C, const Bufs& b, int env, int do_phy
         }
     }
     progress += 1;
-    if (reset_flag != 0) progress = 0;
+    if (reset_flag != 0) { progress = 0; b.reset_count[env] += 1; }
     float rew;
     int64_t rs;
     ingenuity_reward(&rows[0][0], C->max_episode_length, progress, rew, rs);
@@ -218,11 +210,11 @@ static void emu_heli_env(const mms_config* C, const Bufs& b, int env, int do_phy
 extern "C" __attribute__((visibility("default"))) void emu_step(const mms_config* C, const float* actions, float* obs, float* obs_clipped,
                                                                  float* rew, int64_t* reset, int64_t* progress, float* root_states,
                                                                  const float* initial_root_states, float* dof_state, const float* env_origin,
-                                                                 float* prev, const float* reset_noise, float* foot_sensors, int do_physics,
-                                                                 uint64_t step_index, int obs_dim, int prev_dim) {
-    Bufs b{actions, obs, obs_clipped, rew, reset, progress, root_states, initial_root_states, dof_state, env_origin, prev, reset_noise, foot_sensors};
+                                                                 float* prev, const float* reset_noise, float* foot_sensors, int64_t* reset_count,
+                                                                 int do_physics, int obs_dim, int prev_dim) {
+    Bufs b{actions, obs, obs_clipped, rew, reset, progress, root_states, initial_root_states, dof_state, env_origin, prev, reset_noise, foot_sensors, reset_count};
     for (int env = 0; env < C->num_envs; env++) {
         if (C->task == MMS_TASK_MULTI_INGENUITY) emu_heli_env(C, b, env, do_physics);
-        else emu_ant_env(C, b, env, do_physics, step_index, obs_dim, prev_dim);
+        else emu_ant_env(C, b, env, do_physics, obs_dim, prev_dim);
     }
 }

@@ -1,0 +1,401 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Everything goes through the C ABI
+(massive_marl_benchmark_amd/lib/libmms.so via ctypes) and is checked against the CPU oracle and the golden
+vectors produced from the reference's own functions.  Nothing here reads /root/reference.
+
+Tolerances are those of tests/test_lane_emulation.py (derivation there and in DESIGN.md section 7): poses 1e-4
+abs per step, velocities bounded by the model's own 1-ulp input sensitivity, integer outputs bit-exact."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import angle_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4
+VEL_TOL_MAX = 5e-2
+VEL_TOL_TYPICAL = 2e-3
+STATE = ["root_states", "dof_state", "prev", "reset", "progress", "foot_sensors", "reset_count"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; the product path has no CPU fallback")
+    return torch
+
+
+def make_pair(task, **kw):
+    from massive_marl_benchmark_amd.engine import Engine
+    from oracle.oracle import OracleEngine
+    return Engine(task, device=0, **kw), OracleEngine(task, **kw)
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def push_state(torch, eng, ora):
+    for name in STATE:
+        eng.tensor(name).copy_(torch.from_numpy(np.ascontiguousarray(ora.tensor(name))).to(eng.device))
+
+
+def split(task, root, dof):
+    pose = [root[:, 0:7].ravel()]
+    vel = [root[:, 7:13].ravel(), dof[:, 1].ravel()]
+    if task != "MultiIngenuity":
+        pose.append(dof[:, 0].ravel())
+    return np.concatenate(pose), np.concatenate(vel)
+
+
+def compare_step(task, eng, ora, what, verr):
+    po, vo = split(task, ora.tensor("root_states"), ora.tensor("dof_state"))
+    pg, vg = split(task, to_np(eng.tensor("root_states")), to_np(eng.tensor("dof_state")))
+    assert np.max(np.abs(po - pg)) < POSE_TOL, (what, "pose", float(np.max(np.abs(po - pg))))
+    v = float(np.max(np.abs(vo - vg) / np.maximum(1.0, np.abs(vo))))
+    assert v < VEL_TOL_MAX, (what, "velocity", v)
+    verr.append(v)
+    np.testing.assert_array_equal(to_np(eng.tensor("reset")), ora.tensor("reset"), err_msg=what)
+    np.testing.assert_array_equal(to_np(eng.tensor("progress")), ora.tensor("progress"), err_msg=what)
+    np.testing.assert_array_equal(to_np(eng.tensor("reset_count")), ora.tensor("reset_count"), err_msg=what)
+    ob, og = ora.tensor("obs"), to_np(eng.tensor("obs"))
+    assert np.max(np.abs(ob - og) / np.maximum(1.0, np.abs(ob))) < VEL_TOL_MAX, what
+    assert np.max(np.abs(ora.tensor("obs_clipped") - to_np(eng.tensor("obs_clipped")))) < VEL_TOL_MAX, what
+    pv = np.max(np.abs(ora.tensor("prev") - to_np(eng.tensor("prev"))) / np.maximum(1.0, np.abs(ora.tensor("prev"))))
+    assert pv < 1e-4, (what, "prev", pv)
+    if task == "OneAnt":
+        fo, fg = ora.tensor("foot_sensors"), to_np(eng.tensor("foot_sensors"))
+        assert np.max(np.abs(fo - fg) / np.maximum(1.0, np.abs(fo))) < VEL_TOL_MAX, what
+    gmax = float(np.max(np.abs(ora.tensor("env_origin")))) + 30.0
+    rew_tol = 500.0 * float(np.spacing(np.float32(gmax))) * 2 * ora.num_agents + 2e-3 * np.abs(ora.tensor("rew")) + 1e-3
+    assert np.all(np.abs(ora.tensor("rew") - to_np(eng.tensor("rew"))) <= rew_tol), (what, "rew")
+
+
+@pytest.mark.parametrize("task,n,steps", [("TenAnt", 64, 150), ("OneAnt", 64, 150), ("MultiIngenuity", 64, 150)])
+def test_teacher_forced_parity_vs_oracle(torch_cuda, task, n, steps):
+    """K >= 100 steps, step for step on identical state and actions, resets included."""
+    torch = torch_cuda
+    kw = dict(num_envs=n, seed=5, total_envs=4096, env_offset=1000)
+    eng, ora = make_pair(task, **kw)
+    rng = np.random.default_rng(1)
+    verr, resets = [], 0
+    for t in range(steps):
+        push_state(torch, eng, ora)
+        act = rng.uniform(-1.2, 1.2, (n, ora.num_actions)).astype(np.float32)      # beyond +-1: the clamp is exercised
+        if task == "MultiIngenuity":
+            act[:, 2::3] = np.abs(act[:, 2::3]) * 0.12
+        eng.tensor("actions").copy_(torch.from_numpy(act).to(eng.device))
+        eng.step()
+        ora.step(act)
+        torch.cuda.synchronize()
+        compare_step(task, eng, ora, "%s step %d" % (task, t), verr)
+        resets += int(ora.tensor("reset").sum())
+    assert np.median(verr) < VEL_TOL_TYPICAL
+    assert resets > 0
+    eng.close()
+
+
+def test_first_step_is_full_reset_and_noise_matches_oracle(torch_cuda):
+    torch = torch_cuda
+    eng, ora = make_pair("TenAnt", num_envs=32, seed=123, total_envs=64, env_offset=32)
+    a = np.zeros((32, 80), np.float32)
+    eng.tensor("actions").zero_()
+    eng.step()
+    ora.step(a)
+    torch.cuda.synchronize()
+    # reset state is pure integer hashing + clamp: bit-exact
+    np.testing.assert_array_equal(to_np(eng.tensor("dof_state")), ora.tensor("dof_state"))
+    np.testing.assert_array_equal(to_np(eng.tensor("root_states")), ora.tensor("root_states"))
+    np.testing.assert_array_equal(to_np(eng.tensor("progress")), np.zeros(32, np.int64))
+    d = to_np(eng.tensor("dof_state")).reshape(32, 10, 8, 2)
+    assert np.all(d[:, 0] == d[:, 5])                                       # same noise for all ten ants (ten_ant.py:822-854)
+    assert np.ptp(d[:, 0, 0, 0]) > 0.05                                     # but different per env
+    eng.close()
+
+
+def test_step_glue_fixture_from_reference(torch_cuda):
+    """tests/golden/tenant_step_glue.npz (the reference's post_physics_step / reset_idx on supplied state) through
+    mms_post_step on the GPU."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.engine import Engine
+    g = load_golden("tenant_step_glue")
+    S, n = g["actions"].shape[0], g["actions"].shape[1]
+    eng = Engine("TenAnt", num_envs=n, device=0, clip_obs=5.0, external_noise=True)
+    dev = eng.device
+    for t in range(S):
+        loc = g["sim_root"][t].reshape(n, 11, 13).copy()
+        loc[:, :, 0:3] -= g["env_origin"][:, None, :]
+        eng.set_state("root_states", loc.reshape(n * 11, 13).astype(np.float32))
+        eng.set_state("dof_state", g["sim_dof"][t].astype(np.float32))
+        eng.set_state("reset_noise", np.concatenate([g["noise_pos"][t], g["noise_vel"][t]], 1).astype(np.float32))
+        np.testing.assert_array_equal(to_np(eng.tensor("reset")), g["reset_in"][t])
+        if t == 2:
+            eng.set_state("progress", np.array([998], np.int64), env_ids=[7])
+        eng.tensor("actions").copy_(torch.from_numpy(g["actions"][t]).to(dev))
+        eng.post_step()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(to_np(eng.tensor("reset")), g["reset"][t])
+        np.testing.assert_array_equal(to_np(eng.tensor("progress")), g["progress"][t])
+        obs, ref = to_np(eng.tensor("obs")), g["obs"][t]
+        ang = np.zeros(388, bool)
+        for k in range(10):
+            ang[38 * k + 9:38 * k + 12] = True
+        assert np.max(np.abs(obs[:, ~ang] - ref[:, ~ang])) < 2e-4, t           # global coords up to 240 m: ulp 1.5e-5
+        assert angle_close(obs[:, ang], ref[:, ang], 0) < 2e-4, t
+        np.testing.assert_array_equal(to_np(eng.tensor("obs_clipped")), np.clip(obs, -5, 5))
+        assert np.max(np.abs(to_np(eng.tensor("rew")) - g["rew"][t])) < 0.4, t   # 500 x 20 x position rounding (see oracle test)
+        prev = to_np(eng.tensor("prev"))
+        assert np.max(np.abs(prev[:, :20] - g["pos_before"][t].reshape(n, 20))) < 2e-4
+        assert np.max(np.abs(prev[:, 20:40] - g["goal_before"][t].reshape(n, 20))) < 2e-4
+        assert np.max(np.abs(prev[:, 40:42] - g["box_before"][t])) < 2e-4
+        ra = g["root_after"][t].reshape(n, 11, 13).copy()
+        ra[:, :, 0:3] -= g["env_origin"][:, None, :]
+        assert np.max(np.abs(to_np(eng.tensor("root_states")).reshape(n, 11, 13) - ra)) < 2e-5
+        assert np.max(np.abs(to_np(eng.tensor("dof_state")) - g["dof_after"][t])) < 1e-6
+    eng.close()
+
+
+def test_obs_reward_fixtures_through_kernel(torch_cuda):
+    """The tenant_reward golden vectors (reference compute_ant_reward) through the fused kernel (mms_post_step): the
+    fixture rows are loaded as the states of env 0..N-1, with envSpacing 0 so that the global frame is the local one."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.engine import Engine
+    from massive_marl_benchmark_amd.model import default_cfg
+    g = load_golden("tenant_reward")
+    n = g["obs"].shape[0]
+    cfg = default_cfg("TenAnt")
+    cfg["env"]["envSpacing"] = 0.0
+    eng = Engine("TenAnt", cfg, num_envs=n, device=0, clip_obs=5.0)
+    origin = to_np(eng.tensor("env_origin"))
+    assert np.all(origin == 0)
+    # rebuild the state that produces the fixture's observation: positions, velocities and joints are recoverable
+    # from the obs only partially (local-frame velocities), so this test checks the REWARD path: it feeds the
+    # fixture's caches and checks rew/reset for rows whose obs the kernel reproduces from a consistent state.
+    obs = g["obs"]                                                               # [n,10,38]
+    # consistent state: identity orientation, zero velocity, joints from the unscaled positions, positions from obs
+    lower = np.array(eng.config.model.dof_lower[:], np.float32)
+    upper = np.array(eng.config.model.dof_upper[:], np.float32)
+    root = np.zeros((n, 11, 13), np.float32)
+    root[:, :, 6] = 1.0
+    root[:, :10, 0:3] = obs[:, :, 0:3] - origin[:, None, :]
+    root[:, 10, 0:2] = g["box_pos"] - origin[:, :2]
+    root[:, 10, 2] = 0.5
+    root[:, 10, 3:7] = g["box_quat"]
+    dof = np.zeros((n, 10, 8, 2), np.float32)
+    dof[..., 0] = 0.5 * (obs[:, :, 14:22] * (upper - lower) + upper + lower)
+    dof[..., 1] = obs[:, :, 22:30] / 0.2
+    prev = np.concatenate([g["pos_before"].reshape(n, 20), g["goal_before"].reshape(n, 20), g["box_before"]], 1).astype(np.float32)
+    eng.set_state("root_states", root.reshape(n * 11, 13))
+    eng.set_state("dof_state", dof.reshape(n * 80, 2))
+    eng.set_state("prev", prev)
+    eng.set_state("reset", np.zeros(n, np.int64))
+    eng.set_state("progress", (g["progress"] - 1).astype(np.int64))              # the kernel increments before the reward
+    eng.tensor("actions").copy_(torch.from_numpy(g["actions"]).to(eng.device))
+    eng.post_step()
+    torch.cuda.synchronize()
+    got = to_np(eng.tensor("obs")).reshape(n, 388)
+    # goals / box part of the row, joints, actions: reproduced exactly from the consistent state
+    for k in range(10):
+        assert np.max(np.abs(got[:, 38 * k:38 * k + 3] - obs[:, k, 0:3])) < 1e-4
+        assert np.max(np.abs(got[:, 38 * k + 14:38 * k + 22] - obs[:, k, 14:22])) < 1e-5
+        assert np.max(np.abs(got[:, 38 * k + 22:38 * k + 30] - obs[:, k, 22:30])) < 1e-5
+        np.testing.assert_array_equal(got[:, 38 * k + 30:38 * k + 38], np.clip(g["actions"][:, 8 * k:8 * k + 8], -1, 1))
+    np.testing.assert_array_equal(got[:, 380:382], g["box_pos"])
+    # reward: rows where the fixture's up_proj (obs[12]) does not cross 0.93 differ only in the up term -> add it back
+    rew = to_np(eng.tensor("rew"))
+    up_fix = 10.0 * 0.1 * (obs[:, :, 12] > 0.93).sum(1)
+    up_got = 10.0 * 0.1 * 10                                                     # identity orientation: all upright
+    fallen = (obs[:, :, 2] < 0.31).any(1)
+    expect = np.where(fallen, -2.0, g["rew"] - up_fix + up_got)
+    reset_in_zero = g["reset_in"] == 0
+    assert np.max(np.abs(rew - expect)) < 2e-3
+    exp_reset = np.where(fallen | (g["progress"] >= 999), 1, 0)
+    np.testing.assert_array_equal(to_np(eng.tensor("reset")), exp_reset)
+    assert reset_in_zero.any()
+    eng.close()
+
+
+def test_gae_kernels_golden(torch_cuda):
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.algorithms.marl.utils.separated_buffer import SeparatedReplayBuffer
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.storage import RolloutStorage
+    from massive_marl_benchmark_amd import spaces
+    dev = "cuda:0"
+    g = load_golden("ppo_gae")
+    T, N = g["rewards"].shape
+    st = RolloutStorage(N, T, (388,), (0,), (80,), device=dev)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for t in range(T):
+        st.add_transitions(torch.zeros(N, 388, device=dev), torch.zeros(N, 0, device=dev), torch.zeros(N, 80, device=dev),
+                           cu(g["rewards"][t]), cu(g["dones"][t]), cu(g["values"][t]), cu(g["logp"][t]),
+                           torch.zeros(N, 80, device=dev), torch.zeros(N, 80, device=dev))
+    np.testing.assert_array_equal(to_np(st.rewards), g["stored_rewards"])
+    np.testing.assert_array_equal(to_np(st.actions_log_prob), g["stored_logp"])
+    st.compute_returns(cu(g["last_values"]), float(g["gamma"]), float(g["lam"]))
+    torch.cuda.synchronize()
+    assert np.max(np.abs(to_np(st.returns) - g["returns"])) < 1e-4
+    assert np.max(np.abs(to_np(st.advantages) - g["advantages"])) < 1e-5
+    ln, mr = st.get_statistics()
+    assert abs(float(ln) - float(g["mean_traj_len"])) < 1e-5 and abs(float(mr) - float(g["mean_reward"])) < 1e-5
+
+    g = load_golden("marl_gae")
+    T, N = g["rewards"].shape[:2]
+
+    class Norm:
+        def __init__(self, mean, var):
+            self.m, self.v = torch.tensor(mean, device=dev), torch.tensor(var, device=dev)
+
+        def running_mean_var(self):
+            return self.m, self.v
+
+    for tag, popart, vn in (("popart", True, False), ("valuenorm", False, True), ("plain", False, False)):
+        cfg = dict(episode_length=T, n_rollout_threads=N, hidden_size=64, recurrent_N=1, gamma=float(g["gamma"]),
+                   gae_lambda=float(g["gae_lambda"]), use_gae=True, use_popart=popart, use_valuenorm=vn, use_proper_time_limits=False)
+        buf = SeparatedReplayBuffer(cfg, spaces.Box(-np.inf, np.inf, (46,)), spaces.Box(-np.inf, np.inf, (388,)),
+                                    spaces.Box(-np.ones(8), np.ones(8)), dev)
+        for t in range(T):
+            buf.insert(torch.zeros(N, 388, device=dev), torch.zeros(N, 46, device=dev), torch.zeros(N, 1, 64, device=dev),
+                       torch.zeros(N, 1, 64, device=dev), torch.zeros(N, 8, device=dev), torch.zeros(N, 8, device=dev),
+                       cu(g["values"][t]), cu(g["rewards"][t]), cu(g["masks_in"][t]))
+        np.testing.assert_array_equal(to_np(buf.masks), g["masks_" + tag])
+        norm = Norm(g["norm_mean_" + tag], g["norm_var_" + tag]) if (popart or vn) else None
+        buf.compute_returns(cu(g["next_value"]), norm)
+        torch.cuda.synchronize()
+        assert np.max(np.abs(to_np(buf.returns)[:T] - g["returns_" + tag][:T])) < 1e-4, tag
+        np.testing.assert_array_equal(to_np(buf.value_preds), g["value_preds_" + tag])
+
+
+def test_vec_wrappers(torch_cuda):
+    """VecTaskPython / MultiVecTaskPython return values against the reference wrapper fixture semantics."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    from massive_marl_benchmark_amd.engine import current_stream_ptr
+    from massive_marl_benchmark_amd.model import default_cfg
+    from massive_marl_benchmark_amd.tasks.agent_base.multi_vec_task import MultiVecTaskPython
+    from massive_marl_benchmark_amd.tasks.agent_base.vec_task import VecTaskPython
+    from massive_marl_benchmark_amd.tasks.ten_ant import TenAnt
+    # the slicing kernel against the fixture produced by the reference's MultiVecTaskPython.step
+    g = load_golden("vec_wrappers")
+    n = g["obs_buf"].shape[0]
+    clipped = torch.from_numpy(np.clip(g["obs_buf"], -7, 7)).cuda()
+    out = torch.empty(n, 10, 46, device="cuda")
+    _lib.check(_lib.lib().mms_marl_views(0, ctypes.c_void_p(clipped.data_ptr()), ctypes.c_void_p(out.data_ptr()), n, 10, 38, 8,
+                                         current_stream_ptr(torch.device("cuda", 0))), None, "mms_marl_views")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(to_np(out), g["obs_all"])
+
+    cfg = default_cfg("TenAnt")
+    cfg["env"]["numEnvs"] = 32
+    cfg["clip_observations"] = 7.0
+    task = TenAnt(cfg, None, "physx", "cuda", 0, True, is_multi_agent=True)
+    env = MultiVecTaskPython(task, "cuda:0")
+    assert env.num_agents == 10 and env.num_observations == 46 and env.nums_share_observations == 388
+    assert env.observation_space[0].shape == (46,) and env.share_observation_space[0].shape == (388,) and env.action_space[0].shape == (8,)
+    obs, state, _ = env.reset()
+    assert obs.shape == (32, 10, 46) and state.shape == (32, 10, 388)
+    acts = [torch.rand(32, 8, device="cuda") * 3 - 1.5 for _ in range(10)]
+    obs_all, state_all, reward_all, done_all, info_all, _ = env.step(acts)
+    torch.cuda.synchronize()
+    raw = task.obs_buf
+    np.testing.assert_array_equal(to_np(state_all[:, 3]), np.clip(to_np(raw), -7, 7))
+    ref_obs = torch.cat([torch.clamp(raw[:, 38 * 4:38 * 5], -7, 7), torch.clamp(raw[:, 380:], -7, 7)], 1)
+    np.testing.assert_array_equal(to_np(obs_all[:, 4]), to_np(ref_obs))
+    assert reward_all.shape == (32, 10, 1) and done_all.shape == (32, 10)
+    np.testing.assert_array_equal(to_np(reward_all[:, 7, 0]), to_np(task.rew_buf))
+    np.testing.assert_array_equal(to_np(done_all[:, 2]), to_np(task.reset_buf))
+    # actions reach the observation clamped to +-1 (multi_vec_task.py:101)
+    np.testing.assert_array_equal(to_np(raw[:, 30:38]), np.clip(to_np(acts[0]), -1, 1))
+    task.engine.close()
+
+    cfg = default_cfg("TenAnt")
+    cfg["env"]["numEnvs"] = 16
+    task = TenAnt(cfg, None, "physx", "cuda", 0, True, is_multi_agent=False)
+    env = VecTaskPython(task, "cuda:0", 5.0, 1.0)
+    assert env.num_obs == 388 and env.num_acts == 80 and env.observation_space.shape == (388,) and env.action_space.high[0] == 1.0
+    o = env.reset()
+    o2, r, d, info = env.step(torch.zeros(16, 80, device="cuda"))
+    assert o.shape == (16, 388) and r.shape == (16,) and d.dtype == torch.int64 and info == {}
+    assert float(o2.abs().max()) <= 5.0
+    assert env.get_state().shape == (16, 0)
+    task.engine.close()
+
+
+def test_full_size_properties(torch_cuda):
+    """BASELINE size (4096 envs): determinism, shard invariance, finiteness, resets, joint limits, box on the ground."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.engine import Engine
+    N = 4096
+    g = torch.Generator().manual_seed(1234)
+    ring = [(torch.rand(N, 80, generator=g) * 2 - 1).cuda() for _ in range(8)]
+
+    def run(offsets_sizes, steps):
+        engs = [Engine("TenAnt", num_envs=sz, device=0, seed=3, env_offset=off, total_envs=N) for off, sz in offsets_sizes]
+        for t in range(steps):
+            for e, (off, sz) in zip(engs, offsets_sizes):
+                e.tensor("actions").copy_(ring[t % 8][off:off + sz])
+                e.step()
+        torch.cuda.synchronize()
+        out = {k: torch.cat([e.tensor(k) for e in engs]).clone() for k in ("obs", "rew", "reset", "progress", "root_states", "dof_state", "reset_count")}
+        for e in engs:
+            e.close()
+        return out
+
+    steps = 200
+    a = run([(0, N)], steps)
+    b = run([(0, N)], steps)
+    c = run([(0, 1024), (1024, 1024), (2048, 2048)], steps)
+    for k in a:
+        assert torch.equal(a[k], b[k]), "not deterministic: " + k
+        assert torch.equal(a[k], c[k]), "depends on sharding: " + k
+    assert torch.isfinite(a["obs"]).all() and torch.isfinite(a["rew"]).all() and torch.isfinite(a["root_states"]).all()
+    assert int(a["reset_count"].sum()) > N                                  # first-step reset + natural terminations
+    assert int(a["reset_count"].max()) < 40
+    r = a["root_states"].view(N, 11, 13)
+    assert float(r[:, :10, 2].min()) > 0.0 and float(r[:, :10, 2].max()) < 2.5
+    settled = a["progress"] > 40
+    assert float((r[settled, 10, 2] - 0.5).abs().max()) < 0.03
+    lo = torch.tensor([-0.698132, 0.523599, -0.698132, -1.745329, -0.698132, -1.745329, -0.698132, 0.523599], device="cuda")
+    hi = torch.tensor([0.698132, 1.745329, 0.698132, -0.523599, 0.698132, -0.523599, 0.698132, 1.745329], device="cuda")
+    q = a["dof_state"].view(N, 10, 8, 2)[..., 0]
+    assert float((q - hi).max()) < 0.06 and float((lo - q).max()) < 0.06
+    assert float(a["root_states"].view(N, 11, 13)[:, :, 3:7].norm(dim=-1).sub(1).abs().max()) < 1e-5
+
+
+def test_bound_obs_out_and_graph_replay(torch_cuda):
+    """Zero-copy rollout slot and hipGraph capture of the step: replay == eager."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.engine import Engine
+    n = 256
+    acts = [(torch.rand(n, 80) * 2 - 1).cuda() for _ in range(4)]
+    e1 = Engine("TenAnt", num_envs=n, device=0, seed=9)
+    e2 = Engine("TenAnt", num_envs=n, device=0, seed=9)
+    slot = torch.zeros(n, 388, device="cuda")
+    e2.bind_obs_out(slot)
+    for e in (e1, e2):
+        for t in range(20):
+            e.tensor("actions").copy_(acts[t % 4])
+            e.step()
+    torch.cuda.synchronize()
+    assert torch.equal(slot, e2.tensor("obs_clipped"))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for t in range(4):
+                e2.tensor("actions").copy_(acts[t])
+                e2.step()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(5):
+        graph.replay()
+    # capture does not execute; 5 replays = 20 more steps on e2, the same 20 steps eagerly on e1
+    for t in range(20):
+        e1.tensor("actions").copy_(acts[t % 4])
+        e1.step()
+    torch.cuda.synchronize()
+    assert torch.equal(e1.tensor("root_states"), e2.tensor("root_states"))
+    assert torch.equal(e1.tensor("obs"), e2.tensor("obs"))
+    e1.close()
+    e2.close()

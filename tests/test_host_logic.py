@@ -1,0 +1,158 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/mms.h declares, struct layouts
+agree, the built-in configuration equals the reference YAML, the MJCF-subset compiler reproduces the built-in
+ant description, argument parsing, and the multi-rank logic (gloo, world size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+from massive_marl_benchmark_amd import _lib
+from massive_marl_benchmark_amd.model import (ANT_DESCRIPTION, MmsConfig, default_cfg, load_mjcf_ant, make_config, task_dims)
+
+REF = "/root/reference"
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "mms.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mms_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_header_symbols_match_loader_table():
+    assert declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "massive_marl_benchmark_amd", "csrc")])
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (mms_[a-z_0-9]+)", out))
+    assert set(declared_symbols()) <= exported, set(declared_symbols()) - exported
+    # the shared object carries a gfx950 code object
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_library_loads_without_gpu_and_refuses_cpu():
+    L = _lib.lib()                                   # dlopen + symbol binding only; no compute
+    assert L.mms_abi_version() == 1
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-device error path is not reachable")
+    cfg = make_config("TenAnt", num_envs=4)
+    h = ctypes.c_void_p()
+    assert L.mms_create(ctypes.byref(cfg), ctypes.byref(h)) != 0          # must fail loudly: no CPU fallback
+    assert "HIP" in _lib.last_error(None) or "device" in _lib.last_error(None)
+    from massive_marl_benchmark_amd.engine import Engine
+    with pytest.raises(_lib.MmsError):
+        Engine("TenAnt", num_envs=4)
+
+
+def test_struct_layout_matches_c():
+    src = '#include "include/mms.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(mms_config), sizeof(mms_model), offsetof(mms_config, model), offsetof(mms_model, gravity));return 0;}'
+    exe = "/tmp/mms_layout_test"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", ROOT, "-o", exe], input=src.encode(), check=True, cwd=ROOT)
+    a, b, c, d = map(int, subprocess.check_output([exe]).split())
+    from massive_marl_benchmark_amd.model import MmsModel
+    assert (a, b, c, d) == (ctypes.sizeof(MmsConfig), ctypes.sizeof(MmsModel), MmsConfig.model.offset, MmsModel.gravity.offset)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+@pytest.mark.parametrize("task", ["TenAnt", "OneAnt", "MultiIngenuity"])
+def test_default_cfg_equals_reference_yaml(task):
+    import yaml
+    ref = yaml.safe_load(open(os.path.join(REF, "cfg", task + ".yaml")))
+    assert default_cfg(task) == ref
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_mjcf_compiler_matches_builtin_description():
+    d = load_mjcf_ant(os.path.join(REF, "assets/mjcf/open_ai_assets/ant/nv_ant.xml"))
+    for key in ("armature", "damping", "gear", "density", "limb_radius"):
+        assert d[key] == ANT_DESCRIPTION[key], key
+    assert d["torso"]["sphere_radius"] == ANT_DESCRIPTION["torso"]["sphere_radius"]
+    assert d["torso"]["aux_capsules"] == ANT_DESCRIPTION["torso"]["aux_capsules"]
+    assert d["legs"] == ANT_DESCRIPTION["legs"]
+
+
+def test_config_and_dims():
+    c = make_config("TenAnt", num_envs=4096, env_offset=4096, total_envs=32768, seed=3)
+    assert (c.num_envs, c.num_agents, c.substeps, c.max_episode_length) == (4096, 10, 2, 1000)
+    assert abs(c.dt - 0.0166) < 1e-7 and abs(c.model.gravity - 9.81) < 1e-6
+    assert task_dims("TenAnt", 10) == (11, 80, 80, 388, 42)
+    assert task_dims("OneAnt", 1) == (2, 8, 8, 60, 6)
+    assert task_dims("MultiIngenuity", 4) == (4, 16, 24, 52, 12)
+    assert abs(make_config("MultiIngenuity").model.gravity - 3.721) < 1e-6
+
+
+def test_get_args_and_load_cfg():
+    from massive_marl_benchmark_amd.utils.config import get_args, load_cfg, parse_sim_params
+    args = get_args(["--task", "TenAnt", "--algo", "mappo", "--num_envs", "256", "--seed", "5", "--headless"])
+    assert args.task_type == "MultiAgent" and args.device == "cuda" and args.device_id == 0
+    cfg, cfg_train, logdir = load_cfg(args)
+    assert cfg["env"]["numEnvs"] == 256 and cfg_train["seed"] == 5 and cfg["sim"]["substeps"] == 2
+    sp = parse_sim_params(args, cfg, cfg_train)
+    assert sp.dt == 0.0166 and sp.substeps == 2
+    args = get_args(["--task", "OneAnt", "--algo", "ppo"])
+    assert args.task_type == "Python"
+
+
+def test_sharded_env_grid_matches_single():
+    """Env sharding: rank r of R owns envs [r*N, (r+1)*N); its env origins and RNG keys are
+    those of the corresponding envs of one big engine.  Checked on the oracle (same host code path as the product)."""
+    from oracle.oracle import OracleEngine
+    big = OracleEngine("TenAnt", num_envs=16, seed=11)
+    parts = [OracleEngine("TenAnt", num_envs=8, seed=11, env_offset=8 * r, total_envs=16) for r in range(2)]
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        a = rng.uniform(-1, 1, (16, 80)).astype(np.float32)
+        big.step(a)
+        for r, p in enumerate(parts):
+            p.step(a[8 * r:8 * r + 8])
+    for name in ("obs", "rew", "reset", "progress", "root_states", "dof_state"):
+        cat = np.concatenate([p.tensor(name) for p in parts])
+        np.testing.assert_array_equal(cat, big.tensor(name), err_msg=name)     # bit-identical: nothing crosses envs
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["MASTER_PORT"], rank=rank, world_size=world)
+# each rank holds the advantages of its env shard; the global normalisation needs {sum, sum sq, count} all-reduced
+rng = np.random.default_rng(123)
+full = rng.normal(1.5, 3.0, size=(8, 64)).astype(np.float32)
+mine = full[:, rank * 32:(rank + 1) * 32]
+stats = torch.tensor([mine.astype(np.float64).sum(), (mine.astype(np.float64) ** 2).sum(), float(mine.size)], dtype=torch.float64)
+dist.all_reduce(stats)
+n = stats[2].item(); mean = stats[0].item() / n; var = (stats[1].item() - n * mean * mean) / (n - 1.0)
+norm = (mine - np.float32(mean)) * np.float32(1.0 / (np.sqrt(var) + 1e-8))
+ref = (full - full.mean()) / (full.std(ddof=1) + 1e-8)
+assert np.max(np.abs(norm - ref[:, rank * 32:(rank + 1) * 32])) < 1e-5
+# env partition bookkeeping used by bench.py
+from bench import shard_for_rank
+off, total = shard_for_rank(rank, world, 4096)
+assert (off, total) == (rank * 4096, world * 4096)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_statistics_and_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    port = str(29500 + (os.getpid() % 2000))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()

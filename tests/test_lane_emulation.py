@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_SRC = os.path.join(HERE, "emu", "emu_step.cpp")
 EMU_LIB = os.path.join(HERE, "emu", "_libemu.so")
 NAMES = ["actions", "obs", "obs_clipped", "rew", "reset", "progress", "root_states", "initial_root_states", "dof_state",
-         "env_origin", "prev", "reset_noise", "foot_sensors"]
+         "env_origin", "prev", "reset_noise", "foot_sensors", "reset_count"]
 
 
 @pytest.fixture(scope="module")
@@ -26,7 +26,7 @@ def emu():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                                "-o", EMU_LIB, EMU_SRC])
     lib = ctypes.CDLL(EMU_LIB)
-    lib.emu_step.argtypes = [ctypes.POINTER(MmsConfig), F, F, F, F, I64, I64, F, F, F, F, F, F, F, ctypes.c_int, ctypes.c_uint64,
+    lib.emu_step.argtypes = [ctypes.POINTER(MmsConfig), F, F, F, F, I64, I64, F, F, F, F, F, F, F, I64, ctypes.c_int,
                              ctypes.c_int, ctypes.c_int]
     return lib
 
@@ -37,7 +37,6 @@ class EmuEngine:
         self.ref = OracleEngine(task, **kw)          # only used to get identically initialised buffers
         self.config = self.ref.config
         self.buf = {n: self.ref.tensor(n).copy() for n in NAMES}
-        self.step_index = 0
         self.obs_dim, self.prev_dim = self.ref.obs_dim, self.ref.prev_dim
 
     def step(self, actions, physics=True):
@@ -45,12 +44,11 @@ class EmuEngine:
         b["actions"][...] = actions
         self.lib.emu_step(ctypes.byref(self.config), fp(b["actions"]), fp(b["obs"]), fp(b["obs_clipped"]), fp(b["rew"]),
                           ip(b["reset"]), ip(b["progress"]), fp(b["root_states"]), fp(b["initial_root_states"]), fp(b["dof_state"]),
-                          fp(b["env_origin"]), fp(b["prev"]), fp(b["reset_noise"]), fp(b["foot_sensors"]), 1 if physics else 0,
-                          self.step_index, self.obs_dim, self.prev_dim)
-        self.step_index += 1
+                          fp(b["env_origin"]), fp(b["prev"]), fp(b["reset_noise"]), fp(b["foot_sensors"]), ip(b["reset_count"]),
+                          1 if physics else 0, self.obs_dim, self.prev_dim)
 
 
-STATE = ["root_states", "dof_state", "prev", "reset", "progress", "foot_sensors"]
+STATE = ["root_states", "dof_state", "prev", "reset", "progress", "foot_sensors", "reset_count"]
 
 
 # Tolerances.  Poses (positions, quaternions, joint angles) agree to 1e-4 abs per step.  Velocities cannot:
