@@ -245,8 +245,9 @@ def cpu_baseline(n_envs, steps):
     TenAnt N envs, sim step with pre-drawn actions, OpenMP over envs on all host cores."""
     import numpy as np
     from oracle.oracle import OracleEngine
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ.get("MMS_CPU_THREADS", min(avail, 16)))   # a 1-GPU box's CPU share is 16 cores
+    os.environ["OMP_NUM_THREADS"] = str(cores)                       # read by libgomp when the oracle library loads
     ora = OracleEngine("TenAnt", num_envs=n_envs, seed=0)
     rng = np.random.default_rng(1234)
     ring = [rng.uniform(-1, 1, (n_envs, 80)).astype(np.float32) for _ in range(16)]

@@ -37,7 +37,7 @@ MMS_HD V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 MMS_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MMS_HD V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 MMS_HD float clampf(float x, float lo, float hi) { return fmaxf(fminf(x, hi), lo); }
-// damper ramp: c(d) = c * clamp(d / r, 0, 1) keeps the contact force continuous at activation
+// activation weight of contacts / joint limits: clamp(x / r, 0, 1) (continuous contact law, see the oracle)
 MMS_HD float ramp01(float d, float r) { return fminf(fmaxf(d / r, 0.f), 1.f); }
 
 struct M3 { V3 c0, c1, c2; };   // columns
@@ -226,13 +226,14 @@ MMS_HD Contact sphere_ground(float k, float cdamp, float mu, float slip_eps, flo
     if (d > -kContactMargin) {
         V3 xc = V3{xs.x, xs.y, xs.z - rad};
         V3 vp = vb.l + cross(vb.a, xc);
-        float gn = h * k + cdamp * ramp01(d, pen_ramp);
-        float fn = fmaxf(k * d - gn * vp.z, 0.f);
-        if (d > 0.f || d - h * vp.z > 0.f) {
+        float w = ramp01(fmaxf(d, d - h * vp.z), pen_ramp);
+        float gn = w * (h * k + cdamp);
+        float fn = fmaxf(w * k * d - gn * vp.z, 0.f);
+        if (w > 0.f) {
             c.active = 1.f;
             c.xc = xc;
             c.n = V3{0.f, 0.f, 1.f};
-            c.kd = k * d;
+            c.kd = w * k * d;
             c.gn = gn;
             float vt = sqrtf(vp.x * vp.x + vp.y * vp.y);
             c.ct = mu * fn / fmaxf(vt, slip_eps);
@@ -270,12 +271,13 @@ MMS_HD Contact sphere_box(float k, float cdamp, float pen_ramp, float h, V3 Ow, 
         V3 vp = vb.l + cross(vb.a, xc);
         V3 rb = Ow + xc - box.pos;
         V3 vrel = vp - box.v - cross(box.w, rb);
-        float gn = h * k + cdamp * ramp01(d, pen_ramp);
-        if (d > 0.f || d - h * dot(n, vrel) > 0.f) {
+        float w = ramp01(fmaxf(d, d - h * dot(n, vrel)), pen_ramp);
+        float gn = w * (h * k + cdamp);
+        if (w > 0.f) {
             c.active = 1.f;
             c.xc = xc;
             c.n = n;
-            c.kd = k * d;
+            c.kd = w * k * d;
             c.gn = gn;
             c.ct = 0.f;
             c.vrel = vrel;
@@ -342,12 +344,13 @@ MMS_HD float joint_tau(const mms_model* M, float h, float q, float qd, float lo,
     float t = motor - M->joint_damping * qd;
     De = M->armature + h * M->joint_damping;
     float ehi = q - hi, elo = lo - q;
-    if (ehi > 0.f || ehi + h * qd > 0.f) {
-        float gl = h * M->limit_k + M->limit_c * ramp01(ehi, M->limit_ramp);
-        t += -M->limit_k * ehi - gl * qd; De += h * gl;
-    } else if (elo > 0.f || elo - h * qd > 0.f) {
-        float gl = h * M->limit_k + M->limit_c * ramp01(elo, M->limit_ramp);
-        t += M->limit_k * elo - gl * qd; De += h * gl;
+    float whi = ramp01(fmaxf(ehi, ehi + h * qd), M->limit_ramp), wlo = ramp01(fmaxf(elo, elo - h * qd), M->limit_ramp);
+    if (whi > 0.f) {
+        float gl = whi * (h * M->limit_k + M->limit_c);
+        t += -whi * M->limit_k * ehi - gl * qd; De += h * gl;
+    } else if (wlo > 0.f) {
+        float gl = wlo * (h * M->limit_k + M->limit_c);
+        t += wlo * M->limit_k * elo - gl * qd; De += h * gl;
     }
     return t;
 }
@@ -503,10 +506,11 @@ MMS_HD void box_corner(const mms_model* M, float h, const RigidState& B, const M
     float d = -(B.pos.z + xc.z);
     if (d <= -kContactMargin) return;
     V3 vp = B.vel + cross(B.ang, xc);
-    float gn = h * M->boxgnd_k + M->boxgnd_c * ramp01(d, M->pen_ramp);
-    if (!(d > 0.f || d - h * vp.z > 0.f)) return;
+    float w = ramp01(fmaxf(d, d - h * vp.z), M->pen_ramp);
+    float gn = w * (h * M->boxgnd_k + M->boxgnd_c);
+    if (!(w > 0.f)) return;
     Contact c = contact_none();
-    c.active = 1.f; c.xc = xc; c.n = V3{0, 0, 1}; c.kd = M->boxgnd_k * d; c.gn = gn; c.ct = 0.f; c.vrel = vp;
+    c.active = 1.f; c.xc = xc; c.n = V3{0, 0, 1}; c.kd = w * M->boxgnd_k * d; c.gn = gn; c.ct = 0.f; c.vrel = vp;
     S6 p = S6{V3{0, 0, 0}, V3{0, 0, 0}};
     contact_fold(c, h, A, p);
     b = S6{V3{-p.a.x, -p.a.y, -p.a.z}, V3{-p.l.x, -p.l.y, -p.l.z}};
@@ -554,11 +558,12 @@ MMS_HD void heli_substep(const mms_model* M, float h, RigidState& B, V3 thr0, V3
         float d = -(B.pos.z + xc.z);
         if (d <= -kContactMargin) continue;
         V3 vp = v0.l + cross(v0.a, xc);
-        float gn = h * M->heli_gnd_k + M->heli_gnd_c * ramp01(d, M->pen_ramp);
-        float fn = fmaxf(M->heli_gnd_k * d - gn * vp.z, 0.f);
-        if (!(d > 0.f || d - h * vp.z > 0.f)) continue;
+        float w = ramp01(fmaxf(d, d - h * vp.z), M->pen_ramp);
+        float gn = w * (h * M->heli_gnd_k + M->heli_gnd_c);
+        float fn = fmaxf(w * M->heli_gnd_k * d - gn * vp.z, 0.f);
+        if (!(w > 0.f)) continue;
         Contact ct = contact_none();
-        ct.active = 1.f; ct.xc = xc; ct.n = V3{0, 0, 1}; ct.kd = M->heli_gnd_k * d; ct.gn = gn;
+        ct.active = 1.f; ct.xc = xc; ct.n = V3{0, 0, 1}; ct.kd = w * M->heli_gnd_k * d; ct.gn = gn;
         float vt = sqrtf(vp.x * vp.x + vp.y * vp.y);
         ct.ct = M->gnd_mu * fn / fmaxf(vt, M->slip_eps);
         ct.vrel = vp;

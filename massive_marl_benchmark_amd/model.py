@@ -197,7 +197,7 @@ def build_model(task, num_agents, dt, substeps, gravity):
     h = dt / substeps
     # --- compliance parameters (this build's model) ---
     m.limit_k, m.limit_c, m.limit_ramp = 5000.0, 20.0, 5.0e-3
-    m.gnd_k, m.gnd_c, m.gnd_mu, m.slip_eps, m.pen_ramp = 2.0e4, 300.0, 1.0, 1.0e-2, 1.0e-3
+    m.gnd_k, m.gnd_c, m.gnd_mu, m.slip_eps, m.pen_ramp = 2.0e4, 300.0, 1.0, 1.0e-2, 5.0e-4
     if task == "OneAnt":
         bx, by, bz = 1.0, 1.0, 1.0                                         # one_ant.py:264
     else:

@@ -654,9 +654,10 @@ typedef struct { float pos[3]; float R[3][3]; float v[3]; float w[3]; float half
  * While active the force k d - (h k + c) v_n(new) is applied two-sidedly: no chatter at rest, no rebound;
  * the price is a viscous adhesion that lasts only while the shapes still overlap. */
 #define CONTACT_MARGIN 0.1f
-/* The damper is ramped in with the penetration depth, c(d) = c * clamp(d / ramp, 0, 1), so that the contact
- * force is a continuous function of the state at the activation boundary (a constant damper would jump by
- * c |v_n| there, and rounding-level differences would flip it). */
+/* Activation weight w = clamp(max(d, d - h v_n) / ramp, 0, 1) scales the whole contact law (spring and damper):
+ * the force is then a CONTINUOUS function of the state -- zero at the activation boundary, full strength once
+ * the pair overlaps by `ramp` -- so rounding-level differences cannot flip a contact on or off with a force
+ * jump.  Joint limits use the same construction. */
 static inline float ramp01(float d, float r) { return fminf(fmaxf(d / r, 0.f), 1.f); }
 
 /* Sphere (centre xs relative to O, O at world position Ow, radius rad) on a body with spatial velocity vb:
@@ -673,13 +674,14 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
             float vp[3], wx[3];
             cross3(vb, xc, wx);
             for (int i = 0; i < 3; i++) vp[i] = vb[3 + i] + wx[i];
-            float gn = h * M->gnd_k + M->gnd_c * ramp01(d, M->pen_ramp);
-            float fn = fmaxf(M->gnd_k * d - gn * vp[2], 0.f);   /* explicit estimate: friction bound only */
-            if (d > 0.f || d - h * vp[2] > 0.f) {               /* penetrating now or at the end of the step */
+            float w = ramp01(fmaxf(d, d - h * vp[2]), M->pen_ramp);   /* penetrating now or at the end of the step */
+            float gn = w * (h * M->gnd_k + M->gnd_c);
+            float fn = fmaxf(w * M->gnd_k * d - gn * vp[2], 0.f);     /* explicit estimate: friction bound only */
+            if (w > 0.f) {
                 cg->active = 1;
                 memcpy(cg->xc, xc, sizeof(xc));
                 cg->n[0] = 0.f; cg->n[1] = 0.f; cg->n[2] = 1.f;
-                cg->kd = M->gnd_k * d;
+                cg->kd = w * M->gnd_k * d;
                 cg->gn = gn;
                 float vt = sqrtf(vp[0] * vp[0] + vp[1] * vp[1]);
                 cg->ct = M->gnd_mu * fn / fmaxf(vt, M->slip_eps);
@@ -724,12 +726,13 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
             for (int i = 0; i < 3; i++) { vp[i] = vb[3 + i] + wx[i]; rb[i] = Ow[i] + xc[i] - box->pos[i]; }
             cross3(box->w, rb, vbx);
             float vrel[3] = {vp[0] - box->v[0] - vbx[0], vp[1] - box->v[1] - vbx[1], vp[2] - box->v[2] - vbx[2]};
-            float gn = h * M->antbox_k + M->antbox_c * ramp01(d, M->pen_ramp);
-            if (d > 0.f || d - h * dot3(n, vrel) > 0.f) {
+            float w = ramp01(fmaxf(d, d - h * dot3(n, vrel)), M->pen_ramp);
+            float gn = w * (h * M->antbox_k + M->antbox_c);
+            if (w > 0.f) {
                 cb->active = 1;
                 memcpy(cb->xc, xc, sizeof(xc));
                 memcpy(cb->n, n, sizeof(n));
-                cb->kd = M->antbox_k * d;
+                cb->kd = w * M->antbox_k * d;
                 cb->gn = gn;
                 cb->ct = 0.f;
                 memcpy(cb->vrel, vrel, sizeof(vrel));
@@ -827,12 +830,13 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
             float t = tau_motor[d] - M->joint_damping * qd;
             float De = M->armature + h * M->joint_damping;
             float ehi = q - M->dof_upper[d], elo = M->dof_lower[d] - q;
-            if (ehi > 0.f || ehi + h * qd > 0.f) {
-                float gl = h * M->limit_k + M->limit_c * ramp01(ehi, M->limit_ramp);
-                t += -M->limit_k * ehi - gl * qd; De += h * gl;
-            } else if (elo > 0.f || elo - h * qd > 0.f) {
-                float gl = h * M->limit_k + M->limit_c * ramp01(elo, M->limit_ramp);
-                t += M->limit_k * elo - gl * qd; De += h * gl;
+            float whi = ramp01(fmaxf(ehi, ehi + h * qd), M->limit_ramp), wlo = ramp01(fmaxf(elo, elo - h * qd), M->limit_ramp);
+            if (whi > 0.f) {
+                float gl = whi * (h * M->limit_k + M->limit_c);
+                t += -whi * M->limit_k * ehi - gl * qd; De += h * gl;
+            } else if (wlo > 0.f) {
+                float gl = wlo * (h * M->limit_k + M->limit_c);
+                t += wlo * M->limit_k * elo - gl * qd; De += h * gl;
             }
             tau[j] = t; Dextra[j] = De;
         }
@@ -963,13 +967,14 @@ static void box_substep(const mms_model* M, float h, float root[13], const float
         float wx[3], vp[3];
         cross3(w, xc, wx);
         for (int i = 0; i < 3; i++) vp[i] = v[i] + wx[i];
-        float gn = h * M->boxgnd_k + M->boxgnd_c * ramp01(d, M->pen_ramp);
-        if (!(d > 0.f || d - h * vp[2] > 0.f)) continue;
+        float w = ramp01(fmaxf(d, d - h * vp[2]), M->pen_ramp);
+        float gn = w * (h * M->boxgnd_k + M->boxgnd_c);
+        if (!(w > 0.f)) continue;
         contact_t ct;
         ct.active = 1;
         memcpy(ct.xc, xc, sizeof(xc));
         ct.n[0] = 0.f; ct.n[1] = 0.f; ct.n[2] = 1.f;
-        ct.kd = M->boxgnd_k * d; ct.gn = gn; ct.ct = 0.f;
+        ct.kd = w * M->boxgnd_k * d; ct.gn = gn; ct.ct = 0.f;
         memcpy(ct.vrel, vp, sizeof(vp));
         float p[6] = {0, 0, 0, 0, 0, 0};
         contact_fold(&ct, h, A, p);
@@ -1018,14 +1023,15 @@ static void heli_substep(const mms_model* M, float h, float root[13], const floa
         float wx[3], vp[3];
         cross3(v0, xc, wx);
         for (int i = 0; i < 3; i++) vp[i] = v0[3 + i] + wx[i];
-        float gn = h * M->heli_gnd_k + M->heli_gnd_c * ramp01(d, M->pen_ramp);
-        float fn = fmaxf(M->heli_gnd_k * d - gn * vp[2], 0.f);
-        if (!(d > 0.f || d - h * vp[2] > 0.f)) continue;
+        float w = ramp01(fmaxf(d, d - h * vp[2]), M->pen_ramp);
+        float gn = w * (h * M->heli_gnd_k + M->heli_gnd_c);
+        float fn = fmaxf(w * M->heli_gnd_k * d - gn * vp[2], 0.f);
+        if (!(w > 0.f)) continue;
         contact_t ct;
         ct.active = 1;
         memcpy(ct.xc, xc, sizeof(xc));
         ct.n[0] = 0.f; ct.n[1] = 0.f; ct.n[2] = 1.f;
-        ct.kd = M->heli_gnd_k * d; ct.gn = gn;
+        ct.kd = w * M->heli_gnd_k * d; ct.gn = gn;
         float vt = sqrtf(vp[0] * vp[0] + vp[1] * vp[1]);
         ct.ct = M->gnd_mu * fn / fmaxf(vt, M->slip_eps);
         memcpy(ct.vrel, vp, sizeof(vp));
