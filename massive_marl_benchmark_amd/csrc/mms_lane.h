@@ -290,7 +290,8 @@ MMS_HD Contact sphere_box(float k, float cdamp, float pen_ramp, float h, V3 Ow, 
 // per-leg constants (loaded once per lane from the device copy of mms_config)
 // ---------------------------------------------------------------------------------------------
 struct LegConst {
-    V3 hip_pos, limb_dir, ankle_axis;
+    V3 hip_pos, limb_dir, ankle_axis, limb_perp;   // limb_perp = ankle_axis x limb_dir
+    float axis_dot_dir;                            // ankle_axis . limb_dir (0 for the ant)
     float lower[2], upper[2], init[2], gear[2];
 };
 MMS_HD LegConst load_leg_const(const mms_model* M, int l) {
@@ -298,6 +299,8 @@ MMS_HD LegConst load_leg_const(const mms_model* M, int l) {
     L.hip_pos = V3{M->hip_pos[l][0], M->hip_pos[l][1], M->hip_pos[l][2]};
     L.limb_dir = V3{M->limb_dir[l][0], M->limb_dir[l][1], M->limb_dir[l][2]};
     L.ankle_axis = V3{M->ankle_axis[l][0], M->ankle_axis[l][1], M->ankle_axis[l][2]};
+    L.limb_perp = cross(L.ankle_axis, L.limb_dir);
+    L.axis_dot_dir = dot(L.ankle_axis, L.limb_dir);
     for (int j = 0; j < 2; j++) {
         L.lower[j] = M->dof_lower[2 * l + j];
         L.upper[j] = M->dof_upper[2 * l + j];
@@ -329,15 +332,66 @@ MMS_HD void clamp_angvel(V3& w, float wmax) {
     if (wn > wmax) { float s = wmax / wn; w = s * w; }
 }
 
+// sin / cos of a joint angle (|x| <= 2.5 rad: the joint ranges are +-0.7 and +-1.75 rad) by a half-angle
+// polynomial: truncation error < 3e-9, i.e. fp32 rounding level; ~20 flops instead of a libm call each.
+MMS_HD void sincos_joint(float x, float& s, float& c) {
+    float y = 0.5f * clampf(x, -2.5f, 2.5f), y2 = y * y;
+    float sy = y * (1.f + y2 * (-1.f / 6.f + y2 * (1.f / 120.f + y2 * (-1.f / 5040.f + y2 * (1.f / 362880.f + y2 * (-1.f / 39916800.f))))));
+    float cy = 1.f + y2 * (-0.5f + y2 * (1.f / 24.f + y2 * (-1.f / 720.f + y2 * (1.f / 40320.f + y2 * (-1.f / 3628800.f + y2 * (1.f / 479001600.f))))));
+    s = 2.f * sy * cy;
+    c = 1.f - 2.f * sy * sy;
+}
+MMS_HD V3 rot_z(V3 v, float s, float c) { return V3{c * v.x - s * v.y, s * v.x + c * v.y, v.z}; }
+
+// A box contact as kept between the passes: the normal force is f = f0 - hgn * (wn . a_body) and its reaction on
+// the box is -f * (wba, wn.l).  All zero when the contact is inactive.
+struct BoxContact { S6 wn; V3 wba; float f0, hgn; };
+MMS_HD BoxContact box_contact_none() { return BoxContact{S6{V3{0, 0, 0}, V3{0, 0, 0}}, V3{0, 0, 0}, 0.f, 0.f}; }
+
+// ground contact fold, n = (0,0,1), G = diag(ct, ct, gn): the sparse form of I^A += h P^T G P
+MMS_HD void contact_fold_ground(const Contact& c, float h, Sym6& IA, S6& pA) {
+    if (c.active == 0.f) return;
+    float x = c.xc.x, y = c.xc.y, z = c.xc.z, ct = h * c.ct, gn = h * c.gn;
+    IA.m[sidx(0, 0)] += ct * z * z + gn * y * y;
+    IA.m[sidx(0, 1)] += -gn * x * y;
+    IA.m[sidx(0, 2)] += -ct * x * z;
+    IA.m[sidx(1, 1)] += ct * z * z + gn * x * x;
+    IA.m[sidx(1, 2)] += -ct * y * z;
+    IA.m[sidx(2, 2)] += ct * (x * x + y * y);
+    IA.m[sidx(1, 3)] += ct * z;  IA.m[sidx(2, 3)] += -ct * y;      // column of e_x: ct (0, z, -y)
+    IA.m[sidx(0, 4)] += -ct * z; IA.m[sidx(2, 4)] += ct * x;       // column of e_y: ct (-z, 0, x)
+    IA.m[sidx(0, 5)] += gn * y;  IA.m[sidx(1, 5)] += -gn * x;      // column of e_z: gn (y, -x, 0)
+    IA.m[sidx(3, 3)] += ct; IA.m[sidx(4, 4)] += ct; IA.m[sidx(5, 5)] += gn;
+    V3 f0 = V3{-c.ct * c.vrel.x, -c.ct * c.vrel.y, c.kd - c.gn * c.vrel.z};
+    pA.a = pA.a - cross(c.xc, f0);
+    pA.l = pA.l - f0;
+}
+// frictionless box contact fold (rank 1) + the record kept for the outward pass
+MMS_HD BoxContact contact_fold_box(const Contact& c, float h, V3 Ow, const BoxPose& box, Sym6& IA, S6& pA) {
+    BoxContact b = box_contact_none();
+    if (c.active == 0.f) return b;
+    b.wn = S6{cross(c.xc, c.n), c.n};
+    b.hgn = h * c.gn;
+    b.f0 = c.kd - c.gn * dot(c.n, c.vrel);
+    b.wba = cross(Ow + c.xc - box.pos, c.n);
+    sym_rank1(IA, b.hgn, b.wn);
+    pA = pA + (-b.f0) * b.wn;
+    return b;
+}
+MMS_HD float box_contact_force(const BoxContact& b, S6 acc) { return b.f0 - b.hgn * dot(b.wn, acc); }
+MMS_HD void acc_box(const BoxContact& b, float f, S6& w) {
+    w.a = w.a - f * b.wba;
+    w.l = w.l - f * b.wn.l;
+}
+
 // What a leg lane keeps between the inward and the outward pass
 struct LegPass {
     S6 s1, s2, c1, c2, U1, U2;
     float D1, D2, u1, u2;
-    Contact hip_g, hip_b, knee_g, knee_b, tip_g, tip_b, torso_g, torso_b;
-    M3 Rf;
-    V3 J2;
-    S6 v0;
+    BoxContact hip_b, knee_b, tip_b, torso_b;
 };
+// extra state for the foot force sensors (OneAnt only)
+struct SensorPass { Contact tip_g, tip_b; M3 Rf; V3 J2; };
 
 // joint torque with linearly-implicit damping and limits: returns tau, adds to De
 MMS_HD float joint_tau(const mms_model* M, float h, float q, float qd, float lo, float hi, float motor, float& De) {
@@ -357,21 +411,23 @@ MMS_HD float joint_tau(const mms_model* M, float h, float q, float qd, float lo,
 
 // Phase A (inward pass of one leg chain).  Returns this lane's contribution (Ia, pa) to the torso's
 // articulated inertia; lane l == 0 also adds the torso body itself and the torso sphere contacts.
+template <bool SENSORS>
 MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const AntLane& S, int leg, float tau1, float tau2,
-                       bool has_box, const BoxPose& box, LegPass& P, Sym6& IA0, S6& pA0) {
+                       bool has_box, const BoxPose& box, LegPass& P, SensorPass* SP, Sym6& IA0, S6& pA0) {
     M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
     V3 Ow = S.pos;
     S6 v0 = S6{S.ang, S.vel};
-    P.v0 = v0;
-    // kinematics
+    // kinematics: R_leg = R_t Rz(q1), R_foot = R_leg Rot(ankle_axis, q2); only the vectors that are needed
+    float s1q, c1q, s2q, c2q;
+    sincos_joint(S.q[0], s1q, c1q);
+    sincos_joint(S.q[1], s2q, c2q);
     V3 J1 = mul(Rt, L.hip_pos), a1 = Rt.c2;
-    M3 Rl = mul(Rt, axis_angle_to_mat(V3{0.f, 0.f, 1.f}, S.q[0]));
-    V3 ul = mul(Rl, L.limb_dir), a2 = mul(Rl, L.ankle_axis);
+    V3 ul = mul(Rt, rot_z(L.limb_dir, s1q, c1q));
+    V3 a2 = mul(Rt, rot_z(L.ankle_axis, s1q, c1q));
+    V3 pw = mul(Rt, rot_z(L.limb_perp, s1q, c1q));
     V3 J2 = J1 + M->leg_len * ul;
-    M3 Rf = mul(Rl, axis_angle_to_mat(L.ankle_axis, S.q[1]));
-    V3 uf = mul(Rf, L.limb_dir);
+    V3 uf = c2q * ul + s2q * pw + ((1.f - c2q) * L.axis_dot_dir) * a2;     // Rodrigues applied to limb_dir
     V3 cl = J1 + (0.5f * M->leg_len) * ul, cf = J2 + (0.5f * M->foot_len) * uf, tip = J2 + M->foot_len * uf;
-    P.Rf = Rf; P.J2 = J2;
     // motion subspaces, velocities, velocity-product accelerations
     P.s1 = S6{a1, cross(J1, a1)};
     P.s2 = S6{a2, cross(J2, a2)};
@@ -387,20 +443,32 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
     S6 pAl = bias_force(IAl, vl, M->leg_mass, cl, M->gravity);
     spatial_inertia_axisym(M->foot_mass, cf, uf, M->foot_ia, M->foot_it, IAf);
     S6 pAf = bias_force(IAf, vf, M->foot_mass, cf, M->gravity);
-    // contacts
-    P.hip_g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, J1, M->limb_radius, vl);
-    P.knee_g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, J2, M->limb_radius, vl);
-    P.tip_g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, tip, M->limb_radius, vf);
-    if (has_box) {
-        P.hip_b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, J1, M->limb_radius, vl, box);
-        P.knee_b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, J2, M->limb_radius, vl, box);
-        P.tip_b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, tip, M->limb_radius, vf, box);
-    } else {
-        P.hip_b = contact_none(); P.knee_b = contact_none(); P.tip_b = contact_none();
+    // contacts: hip and knee spheres on the leg body, tip sphere on the foot body
+    {
+        Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, J1, M->limb_radius, vl);
+        contact_fold_ground(g, h, IAl, pAl);
+        g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, J2, M->limb_radius, vl);
+        contact_fold_ground(g, h, IAl, pAl);
+        g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, tip, M->limb_radius, vf);
+        contact_fold_ground(g, h, IAf, pAf);
+        if (SENSORS) SP->tip_g = g;
     }
-    contact_fold(P.hip_g, h, IAl, pAl);  contact_fold(P.hip_b, h, IAl, pAl);
-    contact_fold(P.knee_g, h, IAl, pAl); contact_fold(P.knee_b, h, IAl, pAl);
-    contact_fold(P.tip_g, h, IAf, pAf);  contact_fold(P.tip_b, h, IAf, pAf);
+    P.hip_b = box_contact_none(); P.knee_b = box_contact_none(); P.tip_b = box_contact_none(); P.torso_b = box_contact_none();
+    if (SENSORS) SP->tip_b = contact_none();
+    if (has_box) {
+        Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, J1, M->limb_radius, vl, box);
+        P.hip_b = contact_fold_box(b, h, Ow, box, IAl, pAl);
+        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, J2, M->limb_radius, vl, box);
+        P.knee_b = contact_fold_box(b, h, Ow, box, IAl, pAl);
+        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, tip, M->limb_radius, vf, box);
+        P.tip_b = contact_fold_box(b, h, Ow, box, IAf, pAf);
+        if (SENSORS) SP->tip_b = b;
+    }
+    if (SENSORS) {
+        M3 Rl = mul(Rt, axis_angle_to_mat(V3{0.f, 0.f, 1.f}, S.q[0]));
+        SP->Rf = mul(Rl, axis_angle_to_mat(L.ankle_axis, S.q[1]));
+        SP->J2 = J2;
+    }
     // joints
     float De1, De2;
     float t1 = joint_tau(M, h, S.q[0], S.qd[0], L.lower[0], L.upper[0], tau1, De1);
@@ -428,63 +496,52 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         pA0 = pAl + Iac + (P.u1 * invD) * P.U1;
     }
     // the torso body itself (lane 0 of the quad adds it once)
-    P.torso_g = contact_none();
-    P.torso_b = contact_none();
     if (leg == 0) {
         Sym6 It;
         V3 zero = V3{0, 0, 0};
         spatial_inertia_axisym(M->torso_mass, zero, Rt.c2, M->torso_izz, M->torso_ixx, It);
         S6 pt = bias_force(It, v0, M->torso_mass, zero, M->gravity);
-        P.torso_g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, zero, M->torso_radius, v0);
-        if (has_box) P.torso_b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, zero, M->torso_radius, v0, box);
-        contact_fold(P.torso_g, h, It, pt);
-        contact_fold(P.torso_b, h, It, pt);
+        Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, zero, M->torso_radius, v0);
+        contact_fold_ground(g, h, It, pt);
+        if (has_box) {
+            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, zero, M->torso_radius, v0, box);
+            P.torso_b = contact_fold_box(b, h, Ow, box, It, pt);
+        }
         sym_add(IA0, It);
         pA0 = pA0 + pt;
     }
 }
 
-// reaction of one contact on the box: (torque about the box COM, force)
-MMS_HD void acc_box(const Contact& c, V3 f, V3 Ow, const BoxPose& box, S6& w) {
-    if (c.active == 0.f) return;
-    V3 rb = Ow + c.xc - box.pos;
-    V3 nf = V3{-f.x, -f.y, -f.z};
-    w.a = w.a + cross(rb, nf);
-    w.l = w.l + nf;
-}
-
 // Phase B (after the quad reduction): root solve, outward pass, contact forces, integration.
 // `wrench` returns this lane's reaction on the box; `sens` the foot sensor (force, torque) in the foot frame.
-MMS_HD void leg_outward(const mms_model* M, float h, AntLane& S, int leg, bool has_box, const BoxPose& box, const LegPass& P,
-                        const Sym6& IA0, S6 pA0, S6& wrench, float sens[6]) {
+template <bool SENSORS>
+MMS_HD void leg_outward(const mms_model* M, float h, AntLane& S, const LegPass& P, const SensorPass* SP, const Sym6& IA0, S6 pA0,
+                        S6& wrench, float* sens) {
     S6 rhs = S6{V3{-pA0.a.x, -pA0.a.y, -pA0.a.z}, V3{-pA0.l.x, -pA0.l.y, -pA0.l.z}};
     S6 a0 = solve6(IA0, rhs);
-    V3 Ow = S.pos;
     wrench = S6{V3{0, 0, 0}, V3{0, 0, 0}};
-    if (leg == 0 && has_box) acc_box(P.torso_b, contact_force(P.torso_b, h, a0), Ow, box, wrench);
+    acc_box(P.torso_b, box_contact_force(P.torso_b, a0), wrench);       // zero record on lanes with leg != 0
     S6 al = a0 + P.c1;
     float qdd1 = (P.u1 - dot(P.U1, al)) / P.D1;
     al = al + qdd1 * P.s1;
     S6 af = al + P.c2;
     float qdd2 = (P.u2 - dot(P.U2, af)) / P.D2;
     af = af + qdd2 * P.s2;
-    V3 f_tip_g = contact_force(P.tip_g, h, af), f_tip_b = contact_force(P.tip_b, h, af);
-    if (has_box) {
-        acc_box(P.hip_b, contact_force(P.hip_b, h, al), Ow, box, wrench);
-        acc_box(P.knee_b, contact_force(P.knee_b, h, al), Ow, box, wrench);
-        acc_box(P.tip_b, f_tip_b, Ow, box, wrench);
-    }
-    if (sens) {
+    acc_box(P.hip_b, box_contact_force(P.hip_b, al), wrench);
+    acc_box(P.knee_b, box_contact_force(P.knee_b, al), wrench);
+    acc_box(P.tip_b, box_contact_force(P.tip_b, af), wrench);
+    if (SENSORS) {
+        V3 f_tip_g = contact_force(SP->tip_g, h, af), f_tip_b = contact_force(SP->tip_b, h, af);
         V3 F = V3{0, 0, 0}, T = V3{0, 0, 0};
-        if (P.tip_g.active != 0.f) { F = F + f_tip_g; T = T + cross(P.tip_g.xc - P.J2, f_tip_g); }
-        if (P.tip_b.active != 0.f) { F = F + f_tip_b; T = T + cross(P.tip_b.xc - P.J2, f_tip_b); }
-        V3 Fl = mulT(P.Rf, F), Tl = mulT(P.Rf, T);
+        if (SP->tip_g.active != 0.f) { F = F + f_tip_g; T = T + cross(SP->tip_g.xc - SP->J2, f_tip_g); }
+        if (SP->tip_b.active != 0.f) { F = F + f_tip_b; T = T + cross(SP->tip_b.xc - SP->J2, f_tip_b); }
+        V3 Fl = mulT(SP->Rf, F), Tl = mulT(SP->Rf, T);
         sens[0] = Fl.x; sens[1] = Fl.y; sens[2] = Fl.z; sens[3] = Tl.x; sens[4] = Tl.y; sens[5] = Tl.z;
     }
-    // integrate (semi-implicit Euler)
+    // integrate (semi-implicit Euler); S still holds the pre-step velocities here
+    V3 wxv = cross(S.ang, S.vel);
     S.qd[0] += h * qdd1; S.q[0] += h * S.qd[0];
     S.qd[1] += h * qdd2; S.q[1] += h * S.qd[1];
-    V3 wxv = cross(P.v0.a, P.v0.l);
     S.vel = S.vel + h * (a0.l + wxv);
     S.ang = S.ang + h * a0.a;
     clamp_angvel(S.ang, kMaxAngVel);

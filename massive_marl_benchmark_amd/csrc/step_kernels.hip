@@ -161,12 +161,14 @@ __global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
             bp.half = V3{M->box_half[0], M->box_half[1], M->box_half[2]};
             Sym6 IA0;
             S6 pA0;
+            constexpr bool kSensors = (TASK == MMS_TASK_ONE_ANT);
             LegPass P;
-            if (is_ant) leg_inward(M, L, h, S, leg, tau1, tau2, true, bp, P, IA0, pA0);
+            SensorPass SP;
+            if (is_ant) leg_inward<kSensors>(M, L, h, S, leg, tau1, tau2, true, bp, P, &SP, IA0, pA0);
             else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
             quad_sum(IA0, pA0);
             S6 wr = S6{V3{0, 0, 0}, V3{0, 0, 0}};
-            if (is_ant) leg_outward(M, h, S, leg, true, bp, P, IA0, pA0, wr, TASK == MMS_TASK_ONE_ANT ? sens : nullptr);
+            if (is_ant) leg_outward<kSensors>(M, h, S, P, &SP, IA0, pA0, wr, sens);
             s_wr[0 * (BLOCK + 1) + tid] = wr.a.x; s_wr[1 * (BLOCK + 1) + tid] = wr.a.y; s_wr[2 * (BLOCK + 1) + tid] = wr.a.z;
             s_wr[3 * (BLOCK + 1) + tid] = wr.l.x; s_wr[4 * (BLOCK + 1) + tid] = wr.l.y; s_wr[5 * (BLOCK + 1) + tid] = wr.l.z;
             __syncthreads();

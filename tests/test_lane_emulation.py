@@ -57,17 +57,24 @@ STATE = ["root_states", "dof_state", "prev", "reset", "progress", "foot_sensors"
 # output joint velocities by 6e-3 rad/s (median of the per-step maximum over 32 envs), 5e-2 at the 99th percentile.
 # Two correct fp32 implementations that round intermediates differently therefore cannot agree to 1e-4 on every entry
 # of every step; a wrong term, index or sign shows up as O(0.1 .. 10) on most steps.  Gates, per teacher-forced step:
-VEL_TOL_TYPICAL = 2e-3   # median over steps of max |dv| / max(1, |v|)
-VEL_TOL_P99 = 5e-2       # 99th percentile over steps
-VEL_TOL_CAP = 0.5        # any step
+VEL_TOL_TYPICAL = 5e-3   # median over steps of max |dv| / max(1, |v|)   (= the oracle's own 1-ulp sensitivity)
+VEL_TOL_P99 = 1e-1       # 99th percentile over steps
+VEL_TOL_CAP = 1.0        # any step
 POSE_TOL_TYPICAL = 1e-4  # median over steps of the max pose error (positions, quaternions, joint angles)
-POSE_TOL_CAP = 5e-3      # any step (= dt/2 x VEL_TOL_CAP)
+POSE_TOL_CAP = 1e-2      # any step (= dt/2 x VEL_TOL_CAP)
+# The reward has hard thresholds (|ant - goal| < 1.5, up_proj > 0.93, |box - target| < 0.5: ten_ant.py:1073-1079,1193):
+# a state within rounding distance of one flips a whole term.  Such flips are counted, not tolerated silently:
+REW_FLIP_BUDGET = 1e-3   # fraction of (env, step) pairs whose reward may differ by more than the rounding tolerance
 
 
 def check_distribution(verr, perr):
     assert np.median(verr) < VEL_TOL_TYPICAL, ("velocity median", np.median(verr))
     assert np.percentile(verr, 99) < VEL_TOL_P99, ("velocity p99", np.percentile(verr, 99))
     assert np.median(perr) < POSE_TOL_TYPICAL, ("pose median", np.median(perr))
+
+
+def check_reward_flips(flips, pairs):
+    assert sum(flips) <= max(2, REW_FLIP_BUDGET * pairs), ("reward threshold flips", sum(flips), pairs)
 
 
 def pose_vel_split(task, root, dof):
@@ -82,7 +89,7 @@ def pose_vel_split(task, root, dof):
     return np.concatenate(pose), np.concatenate(vel)
 
 
-def compare(o, e, what, vel_err_log, pose_err_log):
+def compare(o, e, what, vel_err_log, pose_err_log, flips):
     po, vo = pose_vel_split(o.task, o.tensor("root_states"), o.tensor("dof_state"))
     pe, ve = pose_vel_split(o.task, e.buf["root_states"], e.buf["dof_state"])
     assert np.max(np.abs(po - pe)) < POSE_TOL_CAP, (what, "pose", np.max(np.abs(po - pe)))
@@ -104,7 +111,7 @@ def compare(o, e, what, vel_err_log, pose_err_log):
     # of a coordinate several hundred metres from the origin is 3e-5..6e-5 m -> 0.03 reward per term, 2 terms per ant
     gmax = float(np.max(np.abs(o.tensor("env_origin")))) + 30.0
     rew_tol = 500.0 * (float(np.spacing(np.float32(gmax))) + pose_err_log[-1]) * 2 * o.num_agents + 2e-3 * np.abs(o.tensor("rew")) + 1e-3
-    assert np.all(np.abs(o.tensor("rew") - e.buf["rew"]) <= rew_tol), (what, "rew", np.max(np.abs(o.tensor("rew") - e.buf["rew"])))
+    flips.append(int(np.sum(np.abs(o.tensor("rew") - e.buf["rew"]) > rew_tol)))
 
 
 @pytest.mark.parametrize("task,n,steps", [("TenAnt", 6, 120), ("OneAnt", 8, 120), ("MultiIngenuity", 8, 120)])
@@ -113,7 +120,7 @@ def test_teacher_forced_parity(emu, task, n, steps):
     o = OracleEngine(task, **kw)
     e = EmuEngine(emu, task, **kw)
     rng = np.random.default_rng(1)
-    resets, verr, perr = 0, [], []
+    resets, verr, perr, flips = 0, [], [], []
     for t in range(steps):
         for name in STATE:                                # identical state in
             e.buf[name][...] = o.tensor(name)
@@ -122,9 +129,10 @@ def test_teacher_forced_parity(emu, task, n, steps):
             act[:, 2::3] = np.abs(act[:, 2::3]) * 0.12      # near hover thrust so that episodes last
         o.step(act)
         e.step(act)
-        compare(o, e, "%s step %d" % (task, t), verr, perr)
+        compare(o, e, "%s step %d" % (task, t), verr, perr, flips)
         resets += int(o.tensor("reset").sum())
     check_distribution(verr, perr)
+    check_reward_flips(flips, n * steps)
     assert resets > 0 or task != "TenAnt"
 
 
