@@ -6,7 +6,7 @@ import os
 from .model import MmsConfig, MmsTensor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmms.so")
+LIB_PATH = os.environ.get("MMS_LIB", os.path.join(_HERE, "lib", "libmms.so"))   # MMS_LIB: A/B builds of the same library
 _lib = None
 
 # every symbol include/mms.h declares (tests check that the library exports all of them)

@@ -343,6 +343,13 @@ MMS_HD void sincos_joint(float x, float& s, float& c) {
 }
 MMS_HD V3 rot_z(V3 v, float s, float c) { return V3{c * v.x - s * v.y, s * v.x + c * v.y, v.z}; }
 
+// Broad phase: can any of this ant's spheres (all within `reach` of the torso centre) touch the box?
+MMS_HD bool ant_near_box(V3 Ow, const BoxPose& box, float reach) {
+    V3 xb = mulT(box.R, Ow - box.pos);
+    float dx = fmaxf(fabsf(xb.x) - box.half.x, 0.f), dy = fmaxf(fabsf(xb.y) - box.half.y, 0.f), dz = fmaxf(fabsf(xb.z) - box.half.z, 0.f);
+    return dx * dx + dy * dy + dz * dz < reach * reach;
+}
+
 // A box contact as kept between the passes: the normal force is f = f0 - hgn * (wn . a_body) and its reaction on
 // the box is -f * (wba, wn.l).  All zero when the contact is inactive.
 struct BoxContact { S6 wn; V3 wba; float f0, hgn; };
@@ -455,6 +462,9 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
     }
     P.hip_b = box_contact_none(); P.knee_b = box_contact_none(); P.tip_b = box_contact_none(); P.torso_b = box_contact_none();
     if (SENSORS) SP->tip_b = contact_none();
+    // reach: hip offset + leg + foot + sphere radius + activation margin; farther ants skip the narrow phase
+    const float reach = sqrtf(dot(L.hip_pos, L.hip_pos)) + M->leg_len + M->foot_len + M->limb_radius + kContactMargin;
+    has_box = has_box && ant_near_box(Ow, box, fmaxf(reach, M->torso_radius + kContactMargin));
     if (has_box) {
         Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, J1, M->limb_radius, vl, box);
         P.hip_b = contact_fold_box(b, h, Ow, box, IAl, pAl);
@@ -554,37 +564,68 @@ MMS_HD void leg_outward(const mms_model* M, float h, AntLane& S, const LegPass& 
 // ---------------------------------------------------------------------------------------------
 struct RigidState { V3 pos; float qx, qy, qz, qw; V3 vel, ang; };
 
-MMS_HD void box_corner(const mms_model* M, float h, const RigidState& B, const M3& R, int corner, Sym6& A, S6& b) {
-    sym_zero(A);
-    b = S6{V3{0, 0, 0}, V3{0, 0, 0}};
+// One corner's ground contact.  The ground normal is z and the box is frictionless, so the implicit term
+// h gn w w^T, w = (xc x z, z) = (y, -x, 0, 0, 0, 1), has six distinct non-zero entries and the right-hand side three:
+//   t[0] = g y^2   t[1] = -g x y   t[2] = g x^2   t[3] = g y   t[4] = -g x   t[5] = g        (g = h * gn)
+//   t[6] = fz y    t[7] = -fz x    t[8] = fz                                                 (fz = kd - gn vz)
+// Only these nine values are reduced over the eight corner lanes.
+struct BoxCorner { float t[9]; };
+MMS_HD BoxCorner box_corner(const mms_model* M, float h, const RigidState& B, const M3& R, int corner) {
+    BoxCorner o;
+#pragma unroll
+    for (int k = 0; k < 9; k++) o.t[k] = 0.f;
     V3 loc = V3{(corner & 1 ? 1.f : -1.f) * M->box_half[0], (corner & 2 ? 1.f : -1.f) * M->box_half[1],
                 (corner & 4 ? 1.f : -1.f) * M->box_half[2]};
     V3 xc = mul(R, loc);
     float d = -(B.pos.z + xc.z);
-    if (d <= -kContactMargin) return;
+    if (d <= -kContactMargin) return o;
     V3 vp = B.vel + cross(B.ang, xc);
     float w = ramp01(fmaxf(d, d - h * vp.z), M->pen_ramp);
+    if (!(w > 0.f)) return o;
     float gn = w * (h * M->boxgnd_k + M->boxgnd_c);
-    if (!(w > 0.f)) return;
-    Contact c = contact_none();
-    c.active = 1.f; c.xc = xc; c.n = V3{0, 0, 1}; c.kd = w * M->boxgnd_k * d; c.gn = gn; c.ct = 0.f; c.vrel = vp;
-    S6 p = S6{V3{0, 0, 0}, V3{0, 0, 0}};
-    contact_fold(c, h, A, p);
-    b = S6{V3{-p.a.x, -p.a.y, -p.a.z}, V3{-p.l.x, -p.l.y, -p.l.z}};
+    float g = h * gn, fz = w * M->boxgnd_k * d - gn * vp.z;
+    o.t[0] = g * xc.y * xc.y; o.t[1] = -g * xc.x * xc.y; o.t[2] = g * xc.x * xc.x;
+    o.t[3] = g * xc.y; o.t[4] = -g * xc.x; o.t[5] = g;
+    o.t[6] = fz * xc.y; o.t[7] = -fz * xc.x; o.t[8] = fz;
+    return o;
 }
-MMS_HD void box_finish(const mms_model* M, float h, RigidState& B, const M3& R, Sym6 A, S6 b, S6 wrench) {
-    Sym6 Ib;
-    V3 zero = V3{0, 0, 0};
-    spatial_inertia_diag(M->box_mass, zero, R, V3{M->box_inertia[0], M->box_inertia[1], M->box_inertia[2]}, Ib);
-    // gyroscopic torque w x (I w)
-    S6 hw = sym_mul(Ib, S6{B.ang, zero});
-    V3 gyro = cross(B.ang, hw.a);
-    sym_add(A, Ib);
-    b.a = b.a + wrench.a - gyro;
-    b.l = b.l + wrench.l + V3{0.f, 0.f, -M->box_mass * M->gravity};
-    S6 a = solve6(A, b);
-    B.ang = B.ang + h * a.a;
-    B.vel = B.vel + h * a.l;
+// Box update from the reduced corner terms and the ants' reaction wrench (torque about the COM, force).
+// (I_w + C) alpha + g a_z = tau,  g^T alpha + (m + c55) a_z = f_z,  m a_xy = f_xy: the 6x6 system reduces to a
+// symmetric 3x3 one for alpha by eliminating a_z.
+MMS_HD void box_finish(const mms_model* M, float h, RigidState& B, const M3& R, const BoxCorner& c, S6 wrench) {
+    // I_w = R diag(I) R^T
+    V3 d = V3{M->box_inertia[0], M->box_inertia[1], M->box_inertia[2]};
+    float ixx = d.x * R.c0.x * R.c0.x + d.y * R.c1.x * R.c1.x + d.z * R.c2.x * R.c2.x;
+    float ixy = d.x * R.c0.x * R.c0.y + d.y * R.c1.x * R.c1.y + d.z * R.c2.x * R.c2.y;
+    float ixz = d.x * R.c0.x * R.c0.z + d.y * R.c1.x * R.c1.z + d.z * R.c2.x * R.c2.z;
+    float iyy = d.x * R.c0.y * R.c0.y + d.y * R.c1.y * R.c1.y + d.z * R.c2.y * R.c2.y;
+    float iyz = d.x * R.c0.y * R.c0.z + d.y * R.c1.y * R.c1.z + d.z * R.c2.y * R.c2.z;
+    float izz = d.x * R.c0.z * R.c0.z + d.y * R.c1.z * R.c1.z + d.z * R.c2.z * R.c2.z;
+    V3 Iw_w = V3{ixx * B.ang.x + ixy * B.ang.y + ixz * B.ang.z, ixy * B.ang.x + iyy * B.ang.y + iyz * B.ang.z,
+                 ixz * B.ang.x + iyz * B.ang.y + izz * B.ang.z};
+    V3 gyro = cross(B.ang, Iw_w);
+    V3 tau = wrench.a - gyro + V3{c.t[6], c.t[7], 0.f};
+    V3 f = wrench.l + V3{0.f, 0.f, c.t[8] - M->box_mass * M->gravity};
+    float m55 = M->box_mass + c.t[5];
+    float inv55 = 1.f / m55;
+    float g0 = c.t[3], g1 = c.t[4];
+    // Schur complement on alpha
+    float a00 = ixx + c.t[0] - g0 * g0 * inv55, a01 = ixy + c.t[1] - g0 * g1 * inv55, a02 = ixz;
+    float a11 = iyy + c.t[2] - g1 * g1 * inv55, a12 = iyz, a22 = izz;
+    float r0 = tau.x - g0 * f.z * inv55, r1 = tau.y - g1 * f.z * inv55, r2 = tau.z;
+    // 3x3 LDL^T
+    float d0 = a00, l10 = a01 / d0, l20 = a02 / d0;
+    float d1 = a11 - l10 * l10 * d0, l21 = (a12 - l20 * l10 * d0) / d1;
+    float d2 = a22 - l20 * l20 * d0 - l21 * l21 * d1;
+    float y0 = r0, y1 = r1 - l10 * y0, y2 = r2 - l20 * y0 - l21 * y1;
+    float az_ = y2 / d2;
+    float ay_ = y1 / d1 - l21 * az_;
+    float ax_ = y0 / d0 - l10 * ay_ - l20 * az_;
+    V3 alpha = V3{ax_, ay_, az_};
+    float inv_m = 1.f / M->box_mass;
+    V3 acc = V3{f.x * inv_m, f.y * inv_m, (f.z - g0 * alpha.x - g1 * alpha.y) * inv55};
+    B.ang = B.ang + h * alpha;
+    B.vel = B.vel + h * acc;
     clamp_angvel(B.ang, kMaxAngVel);
     B.pos = B.pos + h * B.vel;
     quat_integrate(B.qx, B.qy, B.qz, B.qw, B.ang, h);

@@ -43,11 +43,17 @@ __device__ __forceinline__ void quad_sum(Sym6& A, S6& p) {
     p.a.x = quad_sum(p.a.x); p.a.y = quad_sum(p.a.y); p.a.z = quad_sum(p.a.z);
     p.l.x = quad_sum(p.l.x); p.l.y = quad_sum(p.l.y); p.l.z = quad_sum(p.l.z);
 }
-__device__ __forceinline__ void oct_sum(Sym6& A, S6& p) {
+__device__ __forceinline__ void oct_sum(BoxCorner& c) {
 #pragma unroll
-    for (int k = 0; k < 21; k++) A.m[k] = oct_sum(A.m[k]);
-    p.a.x = oct_sum(p.a.x); p.a.y = oct_sum(p.a.y); p.a.z = oct_sum(p.a.z);
-    p.l.x = oct_sum(p.l.x); p.l.y = oct_sum(p.l.y); p.l.z = oct_sum(p.l.z);
+    for (int k = 0; k < 9; k++) c.t[k] = oct_sum(c.t[k]);
+}
+// all-reduce over the 64 lanes of a wave: DPP inside rows of 16, then two cross-row exchanges
+__device__ __forceinline__ float wave_sum(float x) {
+    x = oct_sum(x);
+    x += dpp_mov<0x140>(x);                       // row_mirror: lane i <-> 15 - i within each 16
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
 }
 
 __device__ __forceinline__ RigidState load_rigid(const float* r) {
@@ -64,6 +70,11 @@ __device__ __forceinline__ void store_rigid(float* r, const RigidState& B) {
     r[7] = B.vel.x; r[8] = B.vel.y; r[9] = B.vel.z;
     r[10] = B.ang.x; r[11] = B.ang.y; r[12] = B.ang.z;
 }
+
+// Barrier only when the workgroup has more than one wave (inside a branch that every lane of the box's wave takes
+// together; multi-wave blocks place the box lanes in one wave, and the other waves do not touch s_box / s_bp here).
+template <int BLOCK>
+__device__ __forceinline__ void __syncthreads_if_multiwave() {}
 
 // write the staged observation row: raw, clamped, and the optional bound rollout slot
 __device__ __forceinline__ void write_obs_row(const float* s_obs, int obs_dim, float clip, float* obs, float* obs_clip,
@@ -90,10 +101,14 @@ __device__ __forceinline__ void write_obs_row(const float* s_obs, int obs_dim, f
 
 // ---------------------------------------------------------------------------------------------
 // ant tasks.  TASK: MMS_TASK_TEN_ANT or MMS_TASK_ONE_ANT.  BLOCK: threads per env (64 for A <= 14).
-// dynamic LDS (floats): [obs_dim rounded to 4][6*(BLOCK+1) wrench partials][8 wrench total][16 box][RP_STRIDE*A]
+// dynamic LDS: [obs_dim rounded to 4][6*(BLOCK+1) wrench partials][8 wrench total][16 box state][RP_STRIDE*A] floats,
+// then LegConst[4] and one BoxPose
 // ---------------------------------------------------------------------------------------------
+#ifndef MMS_WAVES_PER_EU
+#define MMS_WAVES_PER_EU 3      // one-wave envs: 3 waves per SIMD (<= 168 VGPRs); measured against 2 and 4 in profiles/
+#endif
 template <int TASK, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const mms_config* __restrict__ C = a.cfg;
     const mms_model* __restrict__ M = &C->model;
@@ -111,8 +126,12 @@ __global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
     float* s_obs = lds;
     float* s_wr = s_obs + obs_pad;                 // [6][BLOCK + 1]
     float* s_wtot = s_wr + 6 * (BLOCK + 1);        // [8]
-    float* s_box = s_wtot + 8;                     // [16]
+    float* s_box = s_wtot + 8;                     // [16] box rigid state (home of the box between phases)
     float* s_red = s_box + 16;                     // [A][RP_STRIDE]
+    // per-leg constants and the box pose live in LDS and are read at the point of use: keeping them in registers
+    // costs ~55 VGPRs per lane for values that are wave-uniform or 4-periodic
+    LegConst* s_leg = reinterpret_cast<LegConst*>(s_red + RP_STRIDE * A);          // [4]
+    BoxPose* s_bp = reinterpret_cast<BoxPose*>(s_leg + 4);
 
     const int actors = A + 1;
     float* root_env = a.root_states + (size_t)env * actors * 13;
@@ -126,11 +145,18 @@ __global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
     const uint64_t env_global = (uint64_t)(C->env_offset + env);
 
     // ---- load state -------------------------------------------------------------------------
-    LegConst L = {};
+    if (tid < 4) s_leg[tid] = load_leg_const(M, tid);
+    if (tid == box_base) {
+        RigidState B0 = load_rigid(root_env + 13 * A);
+        store_rigid(s_box, B0);
+        s_bp->pos = B0.pos; s_bp->R = quat_to_mat(B0.qx, B0.qy, B0.qz, B0.qw); s_bp->v = B0.vel; s_bp->w = B0.ang;
+        s_bp->half = V3{M->box_half[0], M->box_half[1], M->box_half[2]};
+    }
+    __syncthreads();
+    const LegConst& L = s_leg[leg];
     AntLane S = {};
     float act0 = 0.f, act1 = 0.f;
     if (is_ant) {
-        L = load_leg_const(M, leg);
         const float* r = root_env + 13 * ant;
         S.pos = V3{r[0], r[1], r[2]};
         S.qx = r[3]; S.qy = r[4]; S.qz = r[5]; S.qw = r[6];
@@ -142,7 +168,6 @@ __global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
         act0 = clampf(ac.x, -C->clip_actions, C->clip_actions);         // vec_task.py:127
         act1 = clampf(ac.y, -C->clip_actions, C->clip_actions);
     }
-    RigidState B = load_rigid(root_env + 13 * A);
     float sens[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (TASK == MMS_TASK_ONE_ANT && is_ant) {      // sensors of the last simulated substep persist across a skipped step
         const float* fs = a.foot_sensors + ((size_t)env * A + ant) * 24 + 6 * leg;
@@ -153,54 +178,63 @@ __global__ void __launch_bounds__(BLOCK) ant_step_kernel(StepArgs a) {
     // ---- physics: skipped for envs flagged for reset (their state is overwritten below) ------
     if (a.do_physics && reset_flag == 0) {
         const float h = C->dt / (float)C->substeps;
-        const float tau1 = act0 * L.gear[0] * C->power_scale;            // ten_ant.py:889
-        const float tau2 = act1 * L.gear[1] * C->power_scale;
         for (int s = 0; s < C->substeps; s++) {
-            BoxPose bp;
-            bp.pos = B.pos; bp.R = quat_to_mat(B.qx, B.qy, B.qz, B.qw); bp.v = B.vel; bp.w = B.ang;
-            bp.half = V3{M->box_half[0], M->box_half[1], M->box_half[2]};
+            constexpr bool kSensors = (TASK == MMS_TASK_ONE_ANT);
             Sym6 IA0;
             S6 pA0;
-            constexpr bool kSensors = (TASK == MMS_TASK_ONE_ANT);
             LegPass P;
             SensorPass SP;
-            if (is_ant) leg_inward<kSensors>(M, L, h, S, leg, tau1, tau2, true, bp, P, &SP, IA0, pA0);
-            else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
+            if (is_ant) {
+                const float tau1 = act0 * L.gear[0] * C->power_scale;    // ten_ant.py:889
+                const float tau2 = act1 * L.gear[1] * C->power_scale;
+                leg_inward<kSensors>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0);
+            } else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
             quad_sum(IA0, pA0);
             S6 wr = S6{V3{0, 0, 0}, V3{0, 0, 0}};
             if (is_ant) leg_outward<kSensors>(M, h, S, P, &SP, IA0, pA0, wr, sens);
-            s_wr[0 * (BLOCK + 1) + tid] = wr.a.x; s_wr[1 * (BLOCK + 1) + tid] = wr.a.y; s_wr[2 * (BLOCK + 1) + tid] = wr.a.z;
-            s_wr[3 * (BLOCK + 1) + tid] = wr.l.x; s_wr[4 * (BLOCK + 1) + tid] = wr.l.y; s_wr[5 * (BLOCK + 1) + tid] = wr.l.z;
-            __syncthreads();
-            if (is_box && tid - box_base < 6) {                          // component c summed in lane order
-                const float* col = s_wr + (tid - box_base) * (BLOCK + 1);
-                float t = 0.f;
-                for (int i = 0; i < n_ant_lanes; i++) t += col[i];
-                s_wtot[tid - box_base] = t;
+            S6 w;
+            if (BLOCK == 64) {                                           // one wave per env: the reaction wrench by DPP / permute
+                w = S6{V3{wave_sum(wr.a.x), wave_sum(wr.a.y), wave_sum(wr.a.z)}, V3{wave_sum(wr.l.x), wave_sum(wr.l.y), wave_sum(wr.l.z)}};
+            } else {                                                     // several waves: through LDS, column c summed by box lane c
+                s_wr[0 * (BLOCK + 1) + tid] = wr.a.x; s_wr[1 * (BLOCK + 1) + tid] = wr.a.y; s_wr[2 * (BLOCK + 1) + tid] = wr.a.z;
+                s_wr[3 * (BLOCK + 1) + tid] = wr.l.x; s_wr[4 * (BLOCK + 1) + tid] = wr.l.y; s_wr[5 * (BLOCK + 1) + tid] = wr.l.z;
+                __syncthreads();
+                if (is_box && tid - box_base < 6) {
+                    const float* col = s_wr + (tid - box_base) * (BLOCK + 1);
+                    float t = 0.f;
+                    for (int i = 0; i < n_ant_lanes; i++) t += col[i];
+                    s_wtot[tid - box_base] = t;
+                }
+                __syncthreads();
+                w = S6{V3{s_wtot[0], s_wtot[1], s_wtot[2]}, V3{s_wtot[3], s_wtot[4], s_wtot[5]}};
             }
-            __syncthreads();
             if (is_box) {
-                Sym6 Ab;
-                S6 bb;
-                box_corner(M, h, B, bp.R, tid - box_base, Ab, bb);
-                oct_sum(Ab, bb);
-                S6 w = S6{V3{s_wtot[0], s_wtot[1], s_wtot[2]}, V3{s_wtot[3], s_wtot[4], s_wtot[5]}};
-                box_finish(M, h, B, bp.R, Ab, bb, w);
-                if (tid == box_base) store_rigid(s_box, B);
+                RigidState B = load_rigid(s_box);
+                M3 R = s_bp->R;
+                BoxCorner bc = box_corner(M, h, B, R, tid - box_base);
+                oct_sum(bc);
+                box_finish(M, h, B, R, bc, w);
+                __syncthreads_if_multiwave<BLOCK>();                     // (no-op for one wave) everyone has read s_box / s_bp
+                if (tid == box_base) {
+                    store_rigid(s_box, B);
+                    s_bp->pos = B.pos; s_bp->R = quat_to_mat(B.qx, B.qy, B.qz, B.qw); s_bp->v = B.vel; s_bp->w = B.ang;
+                }
             }
             __syncthreads();
-            B = load_rigid(s_box);
         }
     }
 
     // ---- post_physics_step: progress, reset_idx (ten_ant.py:894-901) --------------------------
     progress += 1;
+    RigidState B;
     if (reset_flag != 0) {
         if (is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env, env_global, (uint64_t)a.reset_count[env]);
         B = load_rigid(init_env + 13 * A);
         progress = 0;
         __syncthreads();                               // every lane has read reset_count before it is bumped
         if (tid == 0) a.reset_count[env] += 1;
+    } else {
+        B = load_rigid(s_box);
     }
     // ---- write the state back ---------------------------------------------------------------
     if (is_ant) {
@@ -376,7 +410,7 @@ __global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
 // ---- launchers ---------------------------------------------------------------------------------
 size_t ant_step_lds_bytes(int block, int obs_dim, int num_agents) {
     int obs_pad = (obs_dim + 3) & ~3;
-    return sizeof(float) * (size_t)(obs_pad + 6 * (block + 1) + 8 + 16 + RP_STRIDE * num_agents);
+    return sizeof(float) * (size_t)(obs_pad + 6 * (block + 1) + 8 + 16 + RP_STRIDE * num_agents) + 4 * sizeof(LegConst) + sizeof(BoxPose) + 16;
 }
 
 hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {

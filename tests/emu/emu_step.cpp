@@ -88,19 +88,13 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
             }
             float wt[6];
             for (int c = 0; c < 6; c++) { float tsum = 0.f; for (int t = 0; t < nl; t++) tsum += get(wr[t], c); wt[c] = tsum; }
-            Sym6 Ab[8];
-            S6 bb[8];
-            for (int c = 0; c < 8; c++) box_corner(M, h, B, bp.R, c, Ab[c], bb[c]);
-            Sym6 At;
-            S6 bt;
-            auto oct = [](const float x[8]) {                      // quad sums, then the half-mirror pair
-                float q0 = (x[0] + x[1]) + (x[2] + x[3]), q1 = (x[4] + x[5]) + (x[6] + x[7]);
-                return q0 + q1;
-            };
-            for (int k = 0; k < 21; k++) { float x[8]; for (int c = 0; c < 8; c++) x[c] = Ab[c].m[k]; At.m[k] = oct(x); }
-            float* bp6[6] = {&bt.a.x, &bt.a.y, &bt.a.z, &bt.l.x, &bt.l.y, &bt.l.z};
-            for (int k = 0; k < 6; k++) { float x[8]; for (int c = 0; c < 8; c++) x[c] = get(bb[c], k); *bp6[k] = oct(x); }
-            box_finish(M, h, B, bp.R, At, bt, S6{V3{wt[0], wt[1], wt[2]}, V3{wt[3], wt[4], wt[5]}});
+            BoxCorner bc[8], bt;
+            for (int c = 0; c < 8; c++) bc[c] = box_corner(M, h, B, bp.R, c);
+            for (int k = 0; k < 9; k++) {                          // quad sums, then the half-mirror pair
+                float q0 = (bc[0].t[k] + bc[1].t[k]) + (bc[2].t[k] + bc[3].t[k]), q1 = (bc[4].t[k] + bc[5].t[k]) + (bc[6].t[k] + bc[7].t[k]);
+                bt.t[k] = q0 + q1;
+            }
+            box_finish(M, h, B, bp.R, bt, S6{V3{wt[0], wt[1], wt[2]}, V3{wt[3], wt[4], wt[5]}});
         }
     }
     progress += 1;
