@@ -37,6 +37,18 @@ NSTEPS = 8                              # cfg/ppo/config.yaml:23
 GAMMA, LAM = 0.96, 0.95                 # cfg/ppo/config.yaml:30-31
 
 
+def measured_traffic():
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/step_kernel_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of tools/profile_step.py, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself; None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "step_kernel_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def shard_for_rank(rank, world, envs_per_gpu):
     """(env_offset, total_envs) of rank's shard: rank r owns global envs [r*n, (r+1)*n)."""
     return rank * envs_per_gpu, world * envs_per_gpu
@@ -218,6 +230,8 @@ def main():
         value = world * N * K / elapsed
         sim_value = world * N * sim_steps / sim_wall
         achieved = ALGO_BYTES_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e9
+        tr = measured_traffic()
+        traffic = tr["traffic_bytes_per_launch"] if (tr and tr.get("num_envs") == N) else None
         line = {
             "metric": "env-steps/sec (whole node), TenAnt 4096 envs/GPU, PPO rollout",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -230,7 +244,8 @@ def main():
             "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
                          "note": "engine step with pre-drawn actions (ring of 16)", "hipgraph": sim_graph is not None},
             "roofline": {"bound": "hbm", "kernel": "mms::ant_step_kernel<TEN_ANT,64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (tr or {}).get("source"),
                          "bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "launch_ms": kernel_ms},
             "cpu_baseline": cpu,
         }

@@ -147,6 +147,17 @@ MMS_HD S6 bias_force(const Sym6& I, S6 v, float m, V3 c, float grav) {
     p.l = cross(v.a, h.l) - fg;
     return p;
 }
+// the same for an axisymmetric body, from its parameters instead of the assembled 6x6 (momentum: f = m (vO + w x c),
+// n = Ic w + c x f with Ic w = it w + (ia - it)(u.w) u): about half the instructions of the dense product
+MMS_HD S6 bias_force_axisym(S6 v, float m, V3 c, V3 u, float ia, float it, float grav) {
+    V3 f = m * (v.l + cross(v.a, c));
+    V3 n = it * v.a + ((ia - it) * dot(u, v.a)) * u + cross(c, f);
+    V3 fg = V3{0.f, 0.f, -m * grav};
+    S6 p;
+    p.a = cross(v.a, n) + cross(v.l, f) - cross(c, fg);
+    p.l = cross(v.a, f) - fg;
+    return p;
+}
 // LDL^T solve of a symmetric positive definite 6x6 system
 MMS_HD S6 solve6(const Sym6& A, S6 bv) {
     float b[6] = {bv.a.x, bv.a.y, bv.a.z, bv.l.x, bv.l.y, bv.l.z};
@@ -447,9 +458,9 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
     // body inertias and bias forces
     Sym6 IAl, IAf;
     spatial_inertia_axisym(M->leg_mass, cl, ul, M->leg_ia, M->leg_it, IAl);
-    S6 pAl = bias_force(IAl, vl, M->leg_mass, cl, M->gravity);
+    S6 pAl = bias_force_axisym(vl, M->leg_mass, cl, ul, M->leg_ia, M->leg_it, M->gravity);
     spatial_inertia_axisym(M->foot_mass, cf, uf, M->foot_ia, M->foot_it, IAf);
-    S6 pAf = bias_force(IAf, vf, M->foot_mass, cf, M->gravity);
+    S6 pAf = bias_force_axisym(vf, M->foot_mass, cf, uf, M->foot_ia, M->foot_it, M->gravity);
     // contacts: hip and knee spheres on the leg body, tip sphere on the foot body
     {
         Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, J1, M->limb_radius, vl);
@@ -510,7 +521,7 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         Sym6 It;
         V3 zero = V3{0, 0, 0};
         spatial_inertia_axisym(M->torso_mass, zero, Rt.c2, M->torso_izz, M->torso_ixx, It);
-        S6 pt = bias_force(It, v0, M->torso_mass, zero, M->gravity);
+        S6 pt = bias_force_axisym(v0, M->torso_mass, zero, Rt.c2, M->torso_izz, M->torso_ixx, M->gravity);
         Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, zero, M->torso_radius, v0);
         contact_fold_ground(g, h, It, pt);
         if (has_box) {

@@ -105,7 +105,7 @@ __device__ __forceinline__ void write_obs_row(const float* s_obs, int obs_dim, f
 // then LegConst[4] and one BoxPose
 // ---------------------------------------------------------------------------------------------
 #ifndef MMS_WAVES_PER_EU
-#define MMS_WAVES_PER_EU 3      // one-wave envs: 3 waves per SIMD (<= 168 VGPRs); measured against 2 and 4 in profiles/
+#define MMS_WAVES_PER_EU 2      // one-wave envs: 2 waves per SIMD; 3 and 4 need spills and measured slower (profiles/r01_v3_bench_wpe*.json)
 #endif
 template <int TASK, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant_step_kernel(StepArgs a) {

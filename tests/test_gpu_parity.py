@@ -390,6 +390,62 @@ def test_full_size_properties(torch_cuda):
     assert float(a["root_states"].view(N, 11, 13)[:, :, 3:7].norm(dim=-1).sub(1).abs().max()) < 1e-5
 
 
+def test_hundred_agent_swarm_parity(torch_cuda):
+    """BASELINE config 5 shape (100 ants per env, 408 lanes = the 512-thread multi-wave variant of the step kernel with
+    LDS reductions across waves), small N, teacher forced against the oracle.  The reference has no 100-agent task
+    (SURVEY.md section 0 fact 8): the extrapolated scene is this build's own, parity is against the oracle only."""
+    torch = torch_cuda
+    n, steps = 6, 40
+    kw = dict(num_envs=n, num_agents=100, seed=2)
+    eng, ora = make_pair("TenAnt", **kw)
+    assert eng.obs_dim == 3808 and eng.num_actions == 800
+    rng = np.random.default_rng(3)
+    verr, perr, flips = [], [], []
+    for t in range(steps):
+        push_state(torch, eng, ora)
+        act = rng.uniform(-1, 1, (n, 800)).astype(np.float32)
+        eng.tensor("actions").copy_(torch.from_numpy(act).to(eng.device))
+        eng.step()
+        ora.step(act)
+        torch.cuda.synchronize()
+        compare_step("TenAnt", eng, ora, "swarm step %d" % t, verr, perr, flips)
+    check_distribution(verr, perr)
+    eng.close()
+
+
+def test_ingenuity_full_size_properties(torch_cuda):
+    """BASELINE config 3 size (MultiIngenuity, 8192 envs): determinism, shard invariance, finiteness, resets."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.engine import Engine
+    N = 8192
+    g = torch.Generator().manual_seed(7)
+    ring = []
+    for _ in range(8):
+        a = torch.rand(N, 24, generator=g) * 2 - 1
+        a[:, 2::3] = a[:, 2::3].abs() * 0.2
+        ring.append(a.cuda())
+
+    def run(parts, steps):
+        engs = [Engine("MultiIngenuity", num_envs=sz, device=0, seed=1, env_offset=off, total_envs=N) for off, sz in parts]
+        for t in range(steps):
+            for e, (off, sz) in zip(engs, parts):
+                e.tensor("actions").copy_(ring[t % 8][off:off + sz])
+                e.step()
+        torch.cuda.synchronize()
+        out = {k: torch.cat([e.tensor(k) for e in engs]).clone() for k in ("obs", "rew", "reset", "progress", "root_states", "reset_count")}
+        for e in engs:
+            e.close()
+        return out
+
+    a = run([(0, N)], 150)
+    b = run([(0, 4096), (4096, 4096)], 150)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.isfinite(a["obs"]).all() and torch.isfinite(a["rew"]).all()
+    assert int(a["reset_count"].sum()) > N and float(a["rew"].min()) >= 0.0
+    assert float(a["root_states"][:, 10:13].norm(dim=-1).max()) <= 4 * np.pi + 1e-3      # max_angular_velocity (multi_ingenuity.py:149)
+
+
 def test_bound_obs_out_and_graph_replay(torch_cuda):
     """Zero-copy rollout slot and hipGraph capture of the step: replay == eager."""
     torch = torch_cuda

@@ -249,3 +249,30 @@ def test_ingenuity_hover_and_thrust():
     for _ in range(20):
         lib().mo_heli_substep(ctypes.byref(m), H, fp(root), fp(thr))
     assert root[7] > 0 and root[11] != 0
+
+
+def test_oneant_plumbing_config():
+    """BASELINE config 1 (OneAnt, 64 envs, PPO, CPU pipeline): the plumbing case, on the oracle engine -- step
+    protocol, 60-wide observations with foot sensors, reward, resets, and the PPO GAE on the collected rollout."""
+    n, T = 64, 8
+    eng = OracleEngine("OneAnt", num_envs=n, seed=4)
+    rng = np.random.default_rng(5)
+    assert eng.obs_dim == 60 and eng.num_actions == 8
+    rewards, dones = np.zeros((T, n), np.float32), np.zeros((T, n), np.uint8)
+    values = rng.normal(size=(T, n)).astype(np.float32)
+    total_resets = 0
+    for it in range(12):
+        for t in range(T):
+            eng.step(f32(rng.uniform(-1, 1, (n, 8))))
+            assert np.isfinite(eng.tensor("obs")).all()
+            rewards[t], dones[t] = eng.tensor("rew"), eng.tensor("reset")
+            assert np.all(np.abs(eng.tensor("obs_clipped")) <= 5.0)
+        total_resets += int(dones.sum())
+        ret, adv = np.zeros((T, n), np.float32), np.zeros((T, n), np.float32)
+        from oracle.oracle import U8
+        lib().mo_gae_ppo(T, n, fp(rewards), dones.ctypes.data_as(U8), fp(values), fp(f32(np.zeros(n))), 0.96, 0.95, fp(ret), fp(adv), 1)
+        assert np.isfinite(ret).all() and abs(float(adv.mean())) < 1e-4 and abs(float(adv.std(ddof=1)) - 1) < 1e-3
+    obs = eng.tensor("obs")
+    assert np.any(obs[:, 28:52] != 0)                                      # foot sensors reach the observation
+    assert total_resets > 0
+    eng.close()
