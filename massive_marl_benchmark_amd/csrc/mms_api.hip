@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -35,6 +36,7 @@ struct mms_engine {
     mms_config* d_cfg = nullptr;
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
     float* obs_out = nullptr;
+    int packing = 1;
     std::vector<mms_buffer> bufs;
     std::string err;
 };
@@ -97,6 +99,7 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
     MMS_HIP(nullptr, hipSetDevice(cfg->device));
     mms_engine* e = new mms_engine();
     e->cfg = *cfg;
+    if (const char* pk = getenv("MMS_PACKING")) e->packing = atoi(pk);   // A/B switch for profiling
     const int N = cfg->num_envs, A = cfg->num_agents;
     if (cfg->task == MMS_TASK_TEN_ANT) { e->actors = A + 1; e->dofs = 8 * A; e->num_actions = 8 * A; e->obs_dim = 38 * A + 8; e->prev_dim = 4 * A + 2; }
     else if (cfg->task == MMS_TASK_ONE_ANT) { e->actors = 2; e->dofs = 8; e->num_actions = 8; e->obs_dim = 60; e->prev_dim = 6; }
@@ -229,6 +232,7 @@ static int do_step(mms_handle h, void* stream, int physics) {
     a.num_agents = h->cfg.num_agents;
     a.obs_dim = h->obs_dim;
     a.prev_dim = h->prev_dim;
+    a.packing = h->packing;
     MMS_HIP(h, mms::launch_step(a, h->cfg.task, (hipStream_t)stream));
     return 0;
 }

@@ -71,11 +71,6 @@ __device__ __forceinline__ void store_rigid(float* r, const RigidState& B) {
     r[10] = B.ang.x; r[11] = B.ang.y; r[12] = B.ang.z;
 }
 
-// Barrier only when the workgroup has more than one wave (inside a branch that every lane of the box's wave takes
-// together; multi-wave blocks place the box lanes in one wave, and the other waves do not touch s_box / s_bp here).
-template <int BLOCK>
-__device__ __forceinline__ void __syncthreads_if_multiwave() {}
-
 // write the staged observation row: raw, clamped, and the optional bound rollout slot
 __device__ __forceinline__ void write_obs_row(const float* s_obs, int obs_dim, float clip, float* obs, float* obs_clip,
                                               float* obs_out, int tid, int nthreads) {
@@ -100,20 +95,34 @@ __device__ __forceinline__ void write_obs_row(const float* s_obs, int obs_dim, f
 }
 
 // ---------------------------------------------------------------------------------------------
-// ant tasks.  TASK: MMS_TASK_TEN_ANT or MMS_TASK_ONE_ANT.  BLOCK: threads per env (64 for A <= 14).
-// dynamic LDS: [obs_dim rounded to 4][6*(BLOCK+1) wrench partials][8 wrench total][16 box state][RP_STRIDE*A] floats,
-// then LegConst[4] and one BoxPose
+// ant tasks.  TASK: MMS_TASK_TEN_ANT or MMS_TASK_ONE_ANT.
+// BLOCK threads hold EPB environments of LPE = BLOCK / EPB lanes each (LPE >= 4A rounded up to 8, plus 8):
+//   <64, 1>   one env per wave (any A <= 14)
+//   <192, 4>  TenAnt, A = 10: LPE = 48 = 40 leg lanes + 8 box-corner lanes -> all 64 lanes of the three waves are live
+//   <64, 4>   OneAnt: LPE = 16, four envs per wave
+//   <512, 1>  up to 126 ants per env (the 100-agent swarm), LDS reductions across the eight waves
+// Quads (one ant) and 8-lane box groups never straddle a wave; an env may, so everything that crosses lanes of an env
+// other than quad / 8-lane DPP goes through LDS and __syncthreads.
+// dynamic LDS: LegConst[4], then per env: [obs_dim rounded to 4] obs row, [16] box state, BoxPose, [RP_STRIDE*A] reward
+// partials, [6*A] per-ant box reactions, [8] reaction total.
 // ---------------------------------------------------------------------------------------------
 #ifndef MMS_WAVES_PER_EU
 #define MMS_WAVES_PER_EU 2      // one-wave envs: 2 waves per SIMD; 3 and 4 need spills and measured slower (profiles/r01_v3_bench_wpe*.json)
 #endif
-template <int TASK, int BLOCK>
+__host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
+    return (size_t)((obs_dim + 3) & ~3) + 16 + (sizeof(BoxPose) + 3) / 4 + RP_STRIDE * A + 6 * A + 8;
+}
+template <int TASK, int BLOCK, int EPB>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LPE = BLOCK / EPB;
     const mms_config* __restrict__ C = a.cfg;
     const mms_model* __restrict__ M = &C->model;
-    const int env = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int e_loc = threadIdx.x / LPE;
+    const int tid = threadIdx.x - e_loc * LPE;               // lane within the env
+    const int env_raw = blockIdx.x * EPB + e_loc;
+    const bool live = env_raw < a.num_envs;                  // a partial last block still runs every barrier
+    const int env = live ? env_raw : a.num_envs - 1;
     const int A = a.num_agents;
     const int n_ant_lanes = 4 * A;
     const int box_base = (n_ant_lanes + 7) & ~7;
@@ -123,15 +132,16 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
     const int obs_dim = a.obs_dim;
     const int obs_pad = (obs_dim + 3) & ~3;
 
-    float* s_obs = lds;
-    float* s_wr = s_obs + obs_pad;                 // [6][BLOCK + 1]
-    float* s_wtot = s_wr + 6 * (BLOCK + 1);        // [8]
-    float* s_box = s_wtot + 8;                     // [16] box rigid state (home of the box between phases)
-    float* s_red = s_box + 16;                     // [A][RP_STRIDE]
     // per-leg constants and the box pose live in LDS and are read at the point of use: keeping them in registers
     // costs ~55 VGPRs per lane for values that are wave-uniform or 4-periodic
-    LegConst* s_leg = reinterpret_cast<LegConst*>(s_red + RP_STRIDE * A);          // [4]
-    BoxPose* s_bp = reinterpret_cast<BoxPose*>(s_leg + 4);
+    LegConst* s_leg = reinterpret_cast<LegConst*>(lds);                            // [4], shared by the block
+    float* env_lds = lds + (4 * sizeof(LegConst) + 15) / 16 * 4 + (size_t)e_loc * ((ant_env_lds_floats(obs_dim, A) + 3) & ~(size_t)3);
+    float* s_obs = env_lds;
+    float* s_box = s_obs + obs_pad;                // [16] box rigid state (home of the box between phases)
+    BoxPose* s_bp = reinterpret_cast<BoxPose*>(s_box + 16);
+    float* s_red = s_box + 16 + (sizeof(BoxPose) + 3) / 4;   // [A][RP_STRIDE]
+    float* s_wr = s_red + RP_STRIDE * A;           // [6][A] per-ant reactions on the box
+    float* s_wtot = s_wr + 6 * A;                  // [8]
 
     const int actors = A + 1;
     float* root_env = a.root_states + (size_t)env * actors * 13;
@@ -142,10 +152,11 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
     const V3 origin = V3{a.env_origin[3 * env], a.env_origin[3 * env + 1], a.env_origin[3 * env + 2]};
     const int64_t reset_flag = a.reset[env];
     int64_t progress = a.progress[env];
+    const int64_t reset_count = a.reset_count[env];              // read before the first barrier, bumped by lane 0 at the end
     const uint64_t env_global = (uint64_t)(C->env_offset + env);
 
     // ---- load state -------------------------------------------------------------------------
-    if (tid < 4) s_leg[tid] = load_leg_const(M, tid);
+    if (threadIdx.x < 4) s_leg[threadIdx.x] = load_leg_const(M, threadIdx.x);
     if (tid == box_base) {
         RigidState B0 = load_rigid(root_env + 13 * A);
         store_rigid(s_box, B0);
@@ -175,8 +186,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
         for (int i = 0; i < 6; i++) sens[i] = fs[i];
     }
 
-    // ---- physics: skipped for envs flagged for reset (their state is overwritten below) ------
-    if (a.do_physics && reset_flag == 0) {
+    // ---- physics: skipped per env for envs flagged for reset (their state is overwritten below) ---------------
+    // (the loop itself is block-uniform so that every lane reaches every barrier)
+    const bool simulate = a.do_physics && reset_flag == 0;
+    if (a.do_physics) {
         const float h = C->dt / (float)C->substeps;
         for (int s = 0; s < C->substeps; s++) {
             constexpr bool kSensors = (TASK == MMS_TASK_ONE_ANT);
@@ -184,25 +197,29 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
             S6 pA0;
             LegPass P;
             SensorPass SP;
-            if (is_ant) {
+            if (is_ant && simulate) {
                 const float tau1 = act0 * L.gear[0] * C->power_scale;    // ten_ant.py:889
                 const float tau2 = act1 * L.gear[1] * C->power_scale;
                 leg_inward<kSensors>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0);
             } else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
             quad_sum(IA0, pA0);
             S6 wr = S6{V3{0, 0, 0}, V3{0, 0, 0}};
-            if (is_ant) leg_outward<kSensors>(M, h, S, P, &SP, IA0, pA0, wr, sens);
+            if (is_ant && simulate) leg_outward<kSensors>(M, h, S, P, &SP, IA0, pA0, wr, sens);
             S6 w;
-            if (BLOCK == 64) {                                           // one wave per env: the reaction wrench by DPP / permute
+            if (BLOCK == 64 && EPB == 1) {                               // one wave per env: the reaction wrench by DPP / permute
                 w = S6{V3{wave_sum(wr.a.x), wave_sum(wr.a.y), wave_sum(wr.a.z)}, V3{wave_sum(wr.l.x), wave_sum(wr.l.y), wave_sum(wr.l.z)}};
-            } else {                                                     // several waves: through LDS, column c summed by box lane c
-                s_wr[0 * (BLOCK + 1) + tid] = wr.a.x; s_wr[1 * (BLOCK + 1) + tid] = wr.a.y; s_wr[2 * (BLOCK + 1) + tid] = wr.a.z;
-                s_wr[3 * (BLOCK + 1) + tid] = wr.l.x; s_wr[4 * (BLOCK + 1) + tid] = wr.l.y; s_wr[5 * (BLOCK + 1) + tid] = wr.l.z;
+            } else {                                                     // envs straddle waves: per-ant sums (DPP), then LDS
+                wr.a.x = quad_sum(wr.a.x); wr.a.y = quad_sum(wr.a.y); wr.a.z = quad_sum(wr.a.z);
+                wr.l.x = quad_sum(wr.l.x); wr.l.y = quad_sum(wr.l.y); wr.l.z = quad_sum(wr.l.z);
+                if (is_ant && leg == 0) {
+                    s_wr[0 * A + ant] = wr.a.x; s_wr[1 * A + ant] = wr.a.y; s_wr[2 * A + ant] = wr.a.z;
+                    s_wr[3 * A + ant] = wr.l.x; s_wr[4 * A + ant] = wr.l.y; s_wr[5 * A + ant] = wr.l.z;
+                }
                 __syncthreads();
-                if (is_box && tid - box_base < 6) {
-                    const float* col = s_wr + (tid - box_base) * (BLOCK + 1);
+                if (is_box && tid - box_base < 6) {                      // column c summed in ant order by box lane c
+                    const float* col = s_wr + (tid - box_base) * A;
                     float t = 0.f;
-                    for (int i = 0; i < n_ant_lanes; i++) t += col[i];
+                    for (int i = 0; i < A; i++) t += col[i];
                     s_wtot[tid - box_base] = t;
                 }
                 __syncthreads();
@@ -213,8 +230,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
                 M3 R = s_bp->R;
                 BoxCorner bc = box_corner(M, h, B, R, tid - box_base);
                 oct_sum(bc);
-                box_finish(M, h, B, R, bc, w);
-                __syncthreads_if_multiwave<BLOCK>();                     // (no-op for one wave) everyone has read s_box / s_bp
+                if (simulate) box_finish(M, h, B, R, bc, w);
                 if (tid == box_base) {
                     store_rigid(s_box, B);
                     s_bp->pos = B.pos; s_bp->R = quat_to_mat(B.qx, B.qy, B.qz, B.qw); s_bp->v = B.vel; s_bp->w = B.ang;
@@ -228,16 +244,15 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
     progress += 1;
     RigidState B;
     if (reset_flag != 0) {
-        if (is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env, env_global, (uint64_t)a.reset_count[env]);
+        if (is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env, env_global, (uint64_t)reset_count);
         B = load_rigid(init_env + 13 * A);
         progress = 0;
-        __syncthreads();                               // every lane has read reset_count before it is bumped
-        if (tid == 0) a.reset_count[env] += 1;
+        if (tid == 0 && live) a.reset_count[env] = reset_count + 1;
     } else {
         B = load_rigid(s_box);
     }
     // ---- write the state back ---------------------------------------------------------------
-    if (is_ant) {
+    if (is_ant && live) {
         reinterpret_cast<float4*>(dof_env)[tid] = make_float4(S.q[0], S.qd[0], S.q[1], S.qd[1]);
         if (leg == 0) {
             float* r = root_env + 13 * ant;
@@ -245,7 +260,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
             r[7] = S.vel.x; r[8] = S.vel.y; r[9] = S.vel.z; r[10] = S.ang.x; r[11] = S.ang.y; r[12] = S.ang.z;
         }
     }
-    if (tid == box_base) store_rigid(root_env + 13 * A, B);
+    if (tid == box_base && live) store_rigid(root_env + 13 * A, B);
 
     // ---- observations + reward --------------------------------------------------------------
     const float bgx = B.pos.x + origin.x, bgy = B.pos.y + origin.y;      // global frame
@@ -262,6 +277,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
                 float* r = s_red + RP_STRIDE * ant;
                 r[RP_ADR] = o.adr; r[RP_GDR] = o.gdr; r[RP_GAR] = o.gar; r[RP_UP] = o.up; r[RP_EC] = ec; r[RP_LIM] = lim;
                 r[RP_FALLEN] = o.fallen; r[RP_ACOST] = ac;
+            }
+            if (leg == 0 && live) {
                 prev_env[2 * ant] = o.px; prev_env[2 * ant + 1] = o.py;                 // ten_ant.py:906-926
                 prev_env[2 * A + 2 * ant] = o.gx; prev_env[2 * A + 2 * ant + 1] = o.gy;
             }
@@ -269,10 +286,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
         if (tid == box_base) {
             float* t = s_obs + 38 * A;
             t[0] = bgx; t[1] = bgy; t[2] = B.qx; t[3] = B.qy; t[4] = B.qz; t[5] = B.qw; t[6] = 0.f; t[7] = 0.f;
-            prev_env[4 * A] = bgx; prev_env[4 * A + 1] = bgy;
+            if (live) { prev_env[4 * A] = bgx; prev_env[4 * A + 1] = bgy; }
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0 && live) {
             float rew;
             int64_t rs;
             tenant_reward_finish(C, A, s_red, B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
@@ -287,12 +304,12 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
             V3 pg;
             OneAntLaneOut o = oneant_obs_lane(C, L, S, leg, origin, act0, act1, sens, s_obs, core, pg);
             float ec = quad_sum(o.ec), lim = quad_sum(o.lim), ac = quad_sum(o.acost);
-            if (a.do_physics && reset_flag == 0) {
+            if (simulate && live) {
                 float* fs = a.foot_sensors + ((size_t)env * A + ant) * 24 + 6 * leg;
 #pragma unroll
                 for (int i = 0; i < 6; i++) fs[i] = sens[i];
             }
-            if (tid == 0) {
+            if (tid == 0 && live) {
                 const float pbx = prev_env[0], pby = prev_env[1], bbx = prev_env[2], bby = prev_env[3];
                 float tbx = 0.f - bgx, tby = 0.f - bgy;
                 float pot = -sqrtf(tbx * tbx + tby * tby + 0.f * 0.f) / C->dt;          // one_ant.py:583-587
@@ -310,8 +327,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
         __syncthreads();
     }
     // ---- coalesced observation row(s) --------------------------------------------------------
-    write_obs_row(s_obs, obs_dim, C->clip_obs, a.obs + (size_t)env * obs_dim, a.obs_clipped + (size_t)env * obs_dim,
-                  a.obs_out ? a.obs_out + (size_t)env * obs_dim : nullptr, tid, BLOCK);
+    if (live)
+        write_obs_row(s_obs, obs_dim, C->clip_obs, a.obs + (size_t)env * obs_dim, a.obs_clipped + (size_t)env * obs_dim,
+                      a.obs_out ? a.obs_out + (size_t)env * obs_dim : nullptr, tid, LPE);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,9 +426,12 @@ __global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
-size_t ant_step_lds_bytes(int block, int obs_dim, int num_agents) {
-    int obs_pad = (obs_dim + 3) & ~3;
-    return sizeof(float) * (size_t)(obs_pad + 6 * (block + 1) + 8 + 16 + RP_STRIDE * num_agents) + 4 * sizeof(LegConst) + sizeof(BoxPose) + 16;
+template <int TASK, int BLOCK, int EPB>
+static hipError_t launch_ant(const StepArgs& a, hipStream_t stream) {
+    size_t lds = (4 * sizeof(LegConst) + 15) / 16 * 16 + (size_t)EPB * ((ant_env_lds_floats(a.obs_dim, a.num_agents) + 3) & ~(size_t)3) * sizeof(float);
+    int grid = (a.num_envs + EPB - 1) / EPB;
+    hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {
@@ -420,18 +441,13 @@ hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {
         hipLaunchKernelGGL(ingenuity_step_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a);
         return hipGetLastError();
     }
-    const int lanes = ((4 * a.num_agents + 7) & ~7) + 8;
-    if (lanes <= 64) {
-        size_t lds = ant_step_lds_bytes(64, a.obs_dim, a.num_agents);
-        if (task == MMS_TASK_TEN_ANT) hipLaunchKernelGGL((ant_step_kernel<MMS_TASK_TEN_ANT, 64>), dim3(a.num_envs), dim3(64), lds, stream, a);
-        else hipLaunchKernelGGL((ant_step_kernel<MMS_TASK_ONE_ANT, 64>), dim3(a.num_envs), dim3(64), lds, stream, a);
-    } else if (lanes <= 512 && task == MMS_TASK_TEN_ANT) {
-        size_t lds = ant_step_lds_bytes(512, a.obs_dim, a.num_agents);
-        hipLaunchKernelGGL((ant_step_kernel<MMS_TASK_TEN_ANT, 512>), dim3(a.num_envs), dim3(512), lds, stream, a);
-    } else {
-        return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+    const int lpe = ((4 * a.num_agents + 7) & ~7) + 8;        // lanes one env needs
+    if (task == MMS_TASK_ONE_ANT) return (a.packing != 0) ? launch_ant<MMS_TASK_ONE_ANT, 64, 4>(a, stream) : launch_ant<MMS_TASK_ONE_ANT, 64, 1>(a, stream);
+    if (task != MMS_TASK_TEN_ANT) return hipErrorInvalidValue;
+    if (lpe == 48 && a.packing != 0) return launch_ant<MMS_TASK_TEN_ANT, 192, 4>(a, stream);
+    if (lpe <= 64) return launch_ant<MMS_TASK_TEN_ANT, 64, 1>(a, stream);
+    if (lpe <= 512) return launch_ant<MMS_TASK_TEN_ANT, 512, 1>(a, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace mms

@@ -98,7 +98,9 @@ def compare_step(task, eng, ora, what, verr, perr, flips):
     flips.append(int(np.sum(np.abs(ora.tensor("rew") - to_np(eng.tensor("rew"))) > rew_tol)))
 
 
-@pytest.mark.parametrize("task,n,steps", [("TenAnt", 64, 150), ("OneAnt", 64, 150), ("MultiIngenuity", 64, 150)])
+# (6 and 7 envs: a partial last workgroup of the packed layouts -- 4 envs per 192-thread block / per wave)
+@pytest.mark.parametrize("task,n,steps", [("TenAnt", 64, 150), ("OneAnt", 64, 150), ("MultiIngenuity", 64, 150),
+                                           ("TenAnt", 6, 60), ("OneAnt", 7, 60), ("MultiIngenuity", 5, 60)])
 def test_teacher_forced_parity_vs_oracle(torch_cuda, task, n, steps):
     """K >= 100 steps, step for step on identical state and actions, resets included."""
     torch = torch_cuda
@@ -119,7 +121,7 @@ def test_teacher_forced_parity_vs_oracle(torch_cuda, task, n, steps):
         resets += int(ora.tensor("reset").sum())
     check_distribution(verr, perr)
     check_reward_flips(flips, n * steps)
-    assert resets > 0
+    assert resets > 0 or n < 16
     eng.close()
 
 
