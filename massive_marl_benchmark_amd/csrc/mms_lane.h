@@ -361,11 +361,6 @@ MMS_HD bool ant_near_box(V3 Ow, const BoxPose& box, float reach) {
     return dx * dx + dy * dy + dz * dz < reach * reach;
 }
 
-// A box contact as kept between the passes: the normal force is f = f0 - hgn * (wn . a_body) and its reaction on
-// the box is -f * (wba, wn.l).  All zero when the contact is inactive.
-struct BoxContact { S6 wn; V3 wba; float f0, hgn; };
-MMS_HD BoxContact box_contact_none() { return BoxContact{S6{V3{0, 0, 0}, V3{0, 0, 0}}, V3{0, 0, 0}, 0.f, 0.f}; }
-
 // ground contact fold, n = (0,0,1), G = diag(ct, ct, gn): the sparse form of I^A += h P^T G P
 MMS_HD void contact_fold_ground(const Contact& c, float h, Sym6& IA, S6& pA) {
     if (c.active == 0.f) return;
@@ -384,29 +379,69 @@ MMS_HD void contact_fold_ground(const Contact& c, float h, Sym6& IA, S6& pA) {
     pA.a = pA.a - cross(c.xc, f0);
     pA.l = pA.l - f0;
 }
-// frictionless box contact fold (rank 1) + the record kept for the outward pass
-MMS_HD BoxContact contact_fold_box(const Contact& c, float h, V3 Ow, const BoxPose& box, Sym6& IA, S6& pA) {
-    BoxContact b = box_contact_none();
-    if (c.active == 0.f) return b;
-    b.wn = S6{cross(c.xc, c.n), c.n};
-    b.hgn = h * c.gn;
-    b.f0 = c.kd - c.gn * dot(c.n, c.vrel);
-    b.wba = cross(Ow + c.xc - box.pos, c.n);
-    sym_rank1(IA, b.hgn, b.wn);
-    pA = pA + (-b.f0) * b.wn;
-    return b;
+// frictionless box contact fold (rank 1): I^A += h gn wn wn^T, p^A -= (kd - gn vn) wn,  wn = (xc x n, n)
+MMS_HD void contact_fold_box(const Contact& c, float h, Sym6& IA, S6& pA) {
+    if (c.active == 0.f) return;
+    S6 wn = S6{cross(c.xc, c.n), c.n};
+    sym_rank1(IA, h * c.gn, wn);
+    pA = pA + (-(c.kd - c.gn * dot(c.n, c.vrel))) * wn;
 }
-MMS_HD float box_contact_force(const BoxContact& b, S6 acc) { return b.f0 - b.hgn * dot(b.wn, acc); }
-MMS_HD void acc_box(const BoxContact& b, float f, S6& w) {
-    w.a = w.a - f * b.wba;
-    w.l = w.l - f * b.wn.l;
+// reaction of one (re-evaluated) box contact on the box, given the body's acceleration:
+// f = (kd - gn vn) - h gn (wn . a);  wrench -= f ((O + xc - box) x n, n)
+MMS_HD void box_reaction(const Contact& c, float h, V3 Ow, const BoxPose& box, S6 acc, S6& w) {
+    if (c.active == 0.f) return;
+    S6 wn = S6{cross(c.xc, c.n), c.n};
+    float f = (c.kd - c.gn * dot(c.n, c.vrel)) - (h * c.gn) * dot(wn, acc);
+    w.a = w.a - f * cross(Ow + c.xc - box.pos, c.n);
+    w.l = w.l - f * c.n;
 }
 
-// What a leg lane keeps between the inward and the outward pass
+// Compiler fences used by the step kernel to stop it from keeping recomputable values alive across the
+// quad reduction and the root solve (register pressure decides how many waves are resident at once).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MMS_REG_FENCE(x) asm volatile("" : "+v"(x))
+#define MMS_MEM_FENCE() asm volatile("" ::: "memory")
+#else
+#define MMS_REG_FENCE(x) ((void)0)
+#define MMS_MEM_FENCE() ((void)0)
+#endif
+
+// kinematics of one leg chain; a pure function of (S, L), evaluated in BOTH passes instead of being kept alive
+struct LegKin {
+    V3 J1, J2, tip, ul, uf;
+    S6 s1, s2, vl, vf, c1, c2;
+};
+MMS_HD LegKin leg_kinematics(const mms_model* M, const LegConst& L, const AntLane& S, const M3& Rt) {
+    LegKin K;
+    S6 v0 = S6{S.ang, S.vel};
+    float s1q, c1q, s2q, c2q;
+    sincos_joint(S.q[0], s1q, c1q);
+    sincos_joint(S.q[1], s2q, c2q);
+    // R_leg = R_t Rz(q1), R_foot = R_leg Rot(ankle_axis, q2); only the vectors that are needed
+    V3 a1 = Rt.c2;
+    K.J1 = mul(Rt, L.hip_pos);
+    K.ul = mul(Rt, rot_z(L.limb_dir, s1q, c1q));
+    V3 a2 = mul(Rt, rot_z(L.ankle_axis, s1q, c1q));
+    V3 pw = mul(Rt, rot_z(L.limb_perp, s1q, c1q));
+    K.J2 = K.J1 + M->leg_len * K.ul;
+    K.uf = c2q * K.ul + s2q * pw + ((1.f - c2q) * L.axis_dot_dir) * a2;    // Rodrigues applied to limb_dir
+    K.tip = K.J2 + M->foot_len * K.uf;
+    K.s1 = S6{a1, cross(K.J1, a1)};
+    K.s2 = S6{a2, cross(K.J2, a2)};
+    S6 sq1 = S.qd[0] * K.s1;
+    K.vl = v0 + sq1;
+    K.c1 = cross_motion(v0, sq1);
+    S6 sq2 = S.qd[1] * K.s2;
+    K.vf = K.vl + sq2;
+    K.c2 = cross_motion(K.vl, sq2);
+    return K;
+}
+
+// What a leg lane keeps between the inward and the outward pass: 16 values + the broad-phase flag
 struct LegPass {
-    S6 s1, s2, c1, c2, U1, U2;
+    S6 U1, U2;
     float D1, D2, u1, u2;
-    BoxContact hip_b, knee_b, tip_b, torso_b;
+    bool near_box;
 };
 // extra state for the foot force sensors (OneAnt only)
 struct SensorPass { Contact tip_g, tip_b; M3 Rf; V3 J2; };
@@ -427,6 +462,12 @@ MMS_HD float joint_tau(const mms_model* M, float h, float q, float qd, float lo,
     return t;
 }
 
+MMS_HD float ant_reach(const mms_model* M, const LegConst& L) {
+    // hip offset + leg + foot + sphere radius + activation margin
+    float r = sqrtf(dot(L.hip_pos, L.hip_pos)) + M->leg_len + M->foot_len + M->limb_radius + kContactMargin;
+    return fmaxf(r, M->torso_radius + kContactMargin);
+}
+
 // Phase A (inward pass of one leg chain).  Returns this lane's contribution (Ia, pa) to the torso's
 // articulated inertia; lane l == 0 also adds the torso body itself and the torso sphere contacts.
 template <bool SENSORS>
@@ -435,88 +476,71 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
     M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
     V3 Ow = S.pos;
     S6 v0 = S6{S.ang, S.vel};
-    // kinematics: R_leg = R_t Rz(q1), R_foot = R_leg Rot(ankle_axis, q2); only the vectors that are needed
-    float s1q, c1q, s2q, c2q;
-    sincos_joint(S.q[0], s1q, c1q);
-    sincos_joint(S.q[1], s2q, c2q);
-    V3 J1 = mul(Rt, L.hip_pos), a1 = Rt.c2;
-    V3 ul = mul(Rt, rot_z(L.limb_dir, s1q, c1q));
-    V3 a2 = mul(Rt, rot_z(L.ankle_axis, s1q, c1q));
-    V3 pw = mul(Rt, rot_z(L.limb_perp, s1q, c1q));
-    V3 J2 = J1 + M->leg_len * ul;
-    V3 uf = c2q * ul + s2q * pw + ((1.f - c2q) * L.axis_dot_dir) * a2;     // Rodrigues applied to limb_dir
-    V3 cl = J1 + (0.5f * M->leg_len) * ul, cf = J2 + (0.5f * M->foot_len) * uf, tip = J2 + M->foot_len * uf;
-    // motion subspaces, velocities, velocity-product accelerations
-    P.s1 = S6{a1, cross(J1, a1)};
-    P.s2 = S6{a2, cross(J2, a2)};
-    S6 sq1 = S.qd[0] * P.s1;
-    S6 vl = v0 + sq1;
-    P.c1 = cross_motion(v0, sq1);
-    S6 sq2 = S.qd[1] * P.s2;
-    S6 vf = vl + sq2;
-    P.c2 = cross_motion(vl, sq2);
-    // body inertias and bias forces
-    Sym6 IAl, IAf;
-    spatial_inertia_axisym(M->leg_mass, cl, ul, M->leg_ia, M->leg_it, IAl);
-    S6 pAl = bias_force_axisym(vl, M->leg_mass, cl, ul, M->leg_ia, M->leg_it, M->gravity);
-    spatial_inertia_axisym(M->foot_mass, cf, uf, M->foot_ia, M->foot_it, IAf);
-    S6 pAf = bias_force_axisym(vf, M->foot_mass, cf, uf, M->foot_ia, M->foot_it, M->gravity);
-    // contacts: hip and knee spheres on the leg body, tip sphere on the foot body
+    LegKin K = leg_kinematics(M, L, S, Rt);
+    P.near_box = has_box && ant_near_box(Ow, box, ant_reach(M, L));
+    // ---- foot body: inertia, bias force, tip contacts, joint 2 -------------------------------------------------
+    Sym6 IAf;
+    V3 cf = K.J2 + (0.5f * M->foot_len) * K.uf;
+    spatial_inertia_axisym(M->foot_mass, cf, K.uf, M->foot_ia, M->foot_it, IAf);
+    S6 pAf = bias_force_axisym(K.vf, M->foot_mass, cf, K.uf, M->foot_ia, M->foot_it, M->gravity);
     {
-        Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, J1, M->limb_radius, vl);
-        contact_fold_ground(g, h, IAl, pAl);
-        g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, J2, M->limb_radius, vl);
-        contact_fold_ground(g, h, IAl, pAl);
-        g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, tip, M->limb_radius, vf);
+        Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf);
         contact_fold_ground(g, h, IAf, pAf);
-        if (SENSORS) SP->tip_g = g;
+        if (SENSORS) { SP->tip_g = g; SP->tip_b = contact_none(); }
+        if (P.near_box) {
+            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box);
+            contact_fold_box(b, h, IAf, pAf);
+            if (SENSORS) SP->tip_b = b;
+        }
     }
-    P.hip_b = box_contact_none(); P.knee_b = box_contact_none(); P.tip_b = box_contact_none(); P.torso_b = box_contact_none();
-    if (SENSORS) SP->tip_b = contact_none();
-    // reach: hip offset + leg + foot + sphere radius + activation margin; farther ants skip the narrow phase
-    const float reach = sqrtf(dot(L.hip_pos, L.hip_pos)) + M->leg_len + M->foot_len + M->limb_radius + kContactMargin;
-    has_box = has_box && ant_near_box(Ow, box, fmaxf(reach, M->torso_radius + kContactMargin));
-    if (has_box) {
-        Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, J1, M->limb_radius, vl, box);
-        P.hip_b = contact_fold_box(b, h, Ow, box, IAl, pAl);
-        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, J2, M->limb_radius, vl, box);
-        P.knee_b = contact_fold_box(b, h, Ow, box, IAl, pAl);
-        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, tip, M->limb_radius, vf, box);
-        P.tip_b = contact_fold_box(b, h, Ow, box, IAf, pAf);
-        if (SENSORS) SP->tip_b = b;
+    float De1, De2;
+    float t2 = joint_tau(M, h, S.q[1], S.qd[1], L.lower[1], L.upper[1], tau2, De2);
+    P.U2 = sym_mul(IAf, K.s2);
+    P.D2 = De2 + dot(K.s2, P.U2);
+    P.u2 = t2 - dot(K.s2, pAf);
+    S6 pa_f;
+    {
+        float invD = 1.f / P.D2;
+        sym_rank1(IAf, -invD, P.U2);                       // Ia = IA - U U^T / D
+        S6 Iac = sym_mul(IAf, K.c2);
+        pa_f = pAf + Iac + (P.u2 * invD) * P.U2;
+    }
+    // ---- leg body: inertia, bias force, hip / knee contacts, joint 1 -------------------------------------------
+    Sym6 IAl;
+    V3 cl = K.J1 + (0.5f * M->leg_len) * K.ul;
+    spatial_inertia_axisym(M->leg_mass, cl, K.ul, M->leg_ia, M->leg_it, IAl);
+    S6 pAl = bias_force_axisym(K.vl, M->leg_mass, cl, K.ul, M->leg_ia, M->leg_it, M->gravity);
+    sym_add(IAl, IAf);                                     // the foot's articulated inertia joins before the leg's contacts are
+    pAl = pAl + pa_f;                                      // folded in: 27 fewer live values at the register-pressure peak
+    {
+        Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl);
+        contact_fold_ground(g, h, IAl, pAl);
+        g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl);
+        contact_fold_ground(g, h, IAl, pAl);
+        if (P.near_box) {
+            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box);
+            contact_fold_box(b, h, IAl, pAl);
+            b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box);
+            contact_fold_box(b, h, IAl, pAl);
+        }
+    }
+    float t1 = joint_tau(M, h, S.q[0], S.qd[0], L.lower[0], L.upper[0], tau1, De1);
+    P.U1 = sym_mul(IAl, K.s1);
+    P.D1 = De1 + dot(K.s1, P.U1);
+    P.u1 = t1 - dot(K.s1, pAl);
+    {
+        float invD = 1.f / P.D1;
+        sym_rank1(IAl, -invD, P.U1);
+        S6 Iac = sym_mul(IAl, K.c1);
+        IA0 = IAl;
+        pA0 = pAl + Iac + (P.u1 * invD) * P.U1;
     }
     if (SENSORS) {
         M3 Rl = mul(Rt, axis_angle_to_mat(V3{0.f, 0.f, 1.f}, S.q[0]));
         SP->Rf = mul(Rl, axis_angle_to_mat(L.ankle_axis, S.q[1]));
-        SP->J2 = J2;
+        SP->J2 = K.J2;
     }
-    // joints
-    float De1, De2;
-    float t1 = joint_tau(M, h, S.q[0], S.qd[0], L.lower[0], L.upper[0], tau1, De1);
-    float t2 = joint_tau(M, h, S.q[1], S.qd[1], L.lower[1], L.upper[1], tau2, De2);
-    // inward: foot -> leg
-    P.U2 = sym_mul(IAf, P.s2);
-    P.D2 = De2 + dot(P.s2, P.U2);
-    P.u2 = t2 - dot(P.s2, pAf);
-    {
-        float invD = 1.f / P.D2;
-        sym_rank1(IAf, -invD, P.U2);                       // Ia = IA - U U^T / D
-        S6 Iac = sym_mul(IAf, P.c2);
-        sym_add(IAl, IAf);
-        pAl = pAl + pAf + Iac + (P.u2 * invD) * P.U2;
-    }
-    // inward: leg -> torso contribution
-    P.U1 = sym_mul(IAl, P.s1);
-    P.D1 = De1 + dot(P.s1, P.U1);
-    P.u1 = t1 - dot(P.s1, pAl);
-    {
-        float invD = 1.f / P.D1;
-        sym_rank1(IAl, -invD, P.U1);
-        S6 Iac = sym_mul(IAl, P.c1);
-        IA0 = IAl;
-        pA0 = pAl + Iac + (P.u1 * invD) * P.U1;
-    }
-    // the torso body itself (lane 0 of the quad adds it once)
+    // ---- the torso body itself (lane 0 of the quad adds it once) ------------------------------------------------
     if (leg == 0) {
         Sym6 It;
         V3 zero = V3{0, 0, 0};
@@ -524,9 +548,9 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         S6 pt = bias_force_axisym(v0, M->torso_mass, zero, Rt.c2, M->torso_izz, M->torso_ixx, M->gravity);
         Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, zero, M->torso_radius, v0);
         contact_fold_ground(g, h, It, pt);
-        if (has_box) {
+        if (P.near_box) {
             Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, zero, M->torso_radius, v0, box);
-            P.torso_b = contact_fold_box(b, h, Ow, box, It, pt);
+            contact_fold_box(b, h, It, pt);
         }
         sym_add(IA0, It);
         pA0 = pA0 + pt;
@@ -535,22 +559,43 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
 
 // Phase B (after the quad reduction): root solve, outward pass, contact forces, integration.
 // `wrench` returns this lane's reaction on the box; `sens` the foot sensor (force, torque) in the foot frame.
+// The kinematics and the (rare) box contacts are evaluated again from the unchanged state: bit-identical to the
+// inward pass, and it keeps only 16 values per lane alive across the reduction and the solve (the register count
+// decides whether the whole 4096-env grid is resident at once).
 template <bool SENSORS>
-MMS_HD void leg_outward(const mms_model* M, float h, AntLane& S, const LegPass& P, const SensorPass* SP, const Sym6& IA0, S6 pA0,
-                        S6& wrench, float* sens) {
+MMS_HD void leg_outward(const mms_model* M, const LegConst& L, float h, AntLane& S, int leg, const BoxPose& box, const LegPass& P,
+                        const SensorPass* SP, const Sym6& IA0, S6 pA0, S6& wrench, float* sens) {
     S6 rhs = S6{V3{-pA0.a.x, -pA0.a.y, -pA0.a.z}, V3{-pA0.l.x, -pA0.l.y, -pA0.l.z}};
     S6 a0 = solve6(IA0, rhs);
-    wrench = S6{V3{0, 0, 0}, V3{0, 0, 0}};
-    acc_box(P.torso_b, box_contact_force(P.torso_b, a0), wrench);       // zero record on lanes with leg != 0
-    S6 al = a0 + P.c1;
+    MMS_REG_FENCE(S.pos.x); MMS_REG_FENCE(S.pos.y); MMS_REG_FENCE(S.pos.z);
+    MMS_REG_FENCE(S.qx); MMS_REG_FENCE(S.qy); MMS_REG_FENCE(S.qz); MMS_REG_FENCE(S.qw);
+    MMS_REG_FENCE(S.vel.x); MMS_REG_FENCE(S.vel.y); MMS_REG_FENCE(S.vel.z);
+    MMS_REG_FENCE(S.ang.x); MMS_REG_FENCE(S.ang.y); MMS_REG_FENCE(S.ang.z);
+    MMS_REG_FENCE(S.q[0]); MMS_REG_FENCE(S.q[1]); MMS_REG_FENCE(S.qd[0]); MMS_REG_FENCE(S.qd[1]);
+    MMS_MEM_FENCE();
+    M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
+    LegKin K = leg_kinematics(M, L, S, Rt);
+    V3 Ow = S.pos;
+    S6 al = a0 + K.c1;
     float qdd1 = (P.u1 - dot(P.U1, al)) / P.D1;
-    al = al + qdd1 * P.s1;
-    S6 af = al + P.c2;
+    al = al + qdd1 * K.s1;
+    S6 af = al + K.c2;
     float qdd2 = (P.u2 - dot(P.U2, af)) / P.D2;
-    af = af + qdd2 * P.s2;
-    acc_box(P.hip_b, box_contact_force(P.hip_b, al), wrench);
-    acc_box(P.knee_b, box_contact_force(P.knee_b, al), wrench);
-    acc_box(P.tip_b, box_contact_force(P.tip_b, af), wrench);
+    af = af + qdd2 * K.s2;
+    wrench = S6{V3{0, 0, 0}, V3{0, 0, 0}};
+    if (P.near_box) {
+        S6 v0 = S6{S.ang, S.vel};
+        Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box);
+        box_reaction(b, h, Ow, box, al, wrench);
+        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box);
+        box_reaction(b, h, Ow, box, al, wrench);
+        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box);
+        box_reaction(b, h, Ow, box, af, wrench);
+        if (leg == 0) {
+            b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, V3{0, 0, 0}, M->torso_radius, v0, box);
+            box_reaction(b, h, Ow, box, a0, wrench);
+        }
+    }
     if (SENSORS) {
         V3 f_tip_g = contact_force(SP->tip_g, h, af), f_tip_b = contact_force(SP->tip_b, h, af);
         V3 F = V3{0, 0, 0}, T = V3{0, 0, 0};

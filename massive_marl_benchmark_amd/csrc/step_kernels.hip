@@ -110,10 +110,15 @@ __device__ __forceinline__ void write_obs_row(const float* s_obs, int obs_dim, f
 #define MMS_WAVES_PER_EU 2      // one-wave envs: 2 waves per SIMD; 3 and 4 need spills and measured slower (profiles/r01_v3_bench_wpe*.json)
 #endif
 __host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
-    return (size_t)((obs_dim + 3) & ~3) + 16 + (sizeof(BoxPose) + 3) / 4 + RP_STRIDE * A + 6 * A + 8;
+    return (size_t)((obs_dim + 3) & ~3) + 16 + (sizeof(BoxPose) + 15) / 16 * 4 + 8 + (size_t)(((RP_STRIDE + 6) * A + 3) & ~3);
 }
+// Residency target: TenAnt at 4096 envs is 1024 blocks x 3 waves = 3072 waves = exactly 3 per SIMD on 256 CUs, so the whole
+// grid is resident at once when the kernel fits in 168 VGPRs (the unpacked layout needs 4096 waves = 4 per SIMD = 128 VGPRs).
+#ifndef MMS_WAVES_PER_EU_PACKED
+#define MMS_WAVES_PER_EU_PACKED 3
+#endif
 template <int TASK, int BLOCK, int EPB>
-__global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK == 192 ? MMS_WAVES_PER_EU_PACKED : 1)) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LPE = BLOCK / EPB;
     const mms_config* __restrict__ C = a.cfg;
@@ -135,30 +140,25 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
     // per-leg constants and the box pose live in LDS and are read at the point of use: keeping them in registers
     // costs ~55 VGPRs per lane for values that are wave-uniform or 4-periodic
     LegConst* s_leg = reinterpret_cast<LegConst*>(lds);                            // [4], shared by the block
+    // per-env LDS block: the fixed-size parts first, at compile-time offsets from one lane-varying base
+    constexpr int kBoxOff = 0, kBpOff = 16, kWtotOff = kBpOff + (int)((sizeof(BoxPose) + 15) / 16 * 4), kRedOff = kWtotOff + 8;
     float* env_lds = lds + (4 * sizeof(LegConst) + 15) / 16 * 4 + (size_t)e_loc * ((ant_env_lds_floats(obs_dim, A) + 3) & ~(size_t)3);
-    float* s_obs = env_lds;
-    float* s_box = s_obs + obs_pad;                // [16] box rigid state (home of the box between phases)
-    BoxPose* s_bp = reinterpret_cast<BoxPose*>(s_box + 16);
-    float* s_red = s_box + 16 + (sizeof(BoxPose) + 3) / 4;   // [A][RP_STRIDE]
+    float* s_box = env_lds + kBoxOff;              // [16] box rigid state (home of the box between phases)
+    BoxPose* s_bp = reinterpret_cast<BoxPose*>(env_lds + kBpOff);
+    float* s_wtot = env_lds + kWtotOff;            // [8] total reaction of the ants on the box
+    float* s_red = env_lds + kRedOff;              // [A][RP_STRIDE] reward partials
     float* s_wr = s_red + RP_STRIDE * A;           // [6][A] per-ant reactions on the box
-    float* s_wtot = s_wr + 6 * A;                  // [8]
+    float* s_obs = env_lds + ((kRedOff + (RP_STRIDE + 6) * A + 3) & ~3);   // [obs_pad] observation row (16-B aligned)
 
     const int actors = A + 1;
-    float* root_env = a.root_states + (size_t)env * actors * 13;
-    const float* init_env = a.initial_root_states + (size_t)env * actors * 13;
-    float* dof_env = a.dof_state + (size_t)env * A * 16;
-    const float* act_env = a.actions + (size_t)env * A * 8;
-    float* prev_env = a.prev + (size_t)env * a.prev_dim;
-    const V3 origin = V3{a.env_origin[3 * env], a.env_origin[3 * env + 1], a.env_origin[3 * env + 2]};
-    const int64_t reset_flag = a.reset[env];
-    int64_t progress = a.progress[env];
-    const int64_t reset_count = a.reset_count[env];              // read before the first barrier, bumped by lane 0 at the end
-    const uint64_t env_global = (uint64_t)(C->env_offset + env);
+    const bool reset_now = a.reset[env] != 0;
 
     // ---- load state -------------------------------------------------------------------------
+    // (per-env addresses are lane-varying in the packed layouts: they are formed where they are used, not kept alive
+    // across the physics loop -- see the fence before the epilogue)
     if (threadIdx.x < 4) s_leg[threadIdx.x] = load_leg_const(M, threadIdx.x);
     if (tid == box_base) {
-        RigidState B0 = load_rigid(root_env + 13 * A);
+        RigidState B0 = load_rigid(a.root_states + ((size_t)env * actors + A) * 13);
         store_rigid(s_box, B0);
         s_bp->pos = B0.pos; s_bp->R = quat_to_mat(B0.qx, B0.qy, B0.qz, B0.qw); s_bp->v = B0.vel; s_bp->w = B0.ang;
         s_bp->half = V3{M->box_half[0], M->box_half[1], M->box_half[2]};
@@ -168,14 +168,14 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
     AntLane S = {};
     float act0 = 0.f, act1 = 0.f;
     if (is_ant) {
-        const float* r = root_env + 13 * ant;
+        const float* r = a.root_states + ((size_t)env * actors + ant) * 13;
         S.pos = V3{r[0], r[1], r[2]};
         S.qx = r[3]; S.qy = r[4]; S.qz = r[5]; S.qw = r[6];
         S.vel = V3{r[7], r[8], r[9]};
         S.ang = V3{r[10], r[11], r[12]};
-        float4 d = reinterpret_cast<const float4*>(dof_env)[tid];       // (q1, qd1, q2, qd2): coalesced 16 B / lane
+        float4 d = reinterpret_cast<const float4*>(a.dof_state + (size_t)env * A * 16)[tid];   // (q1, qd1, q2, qd2): coalesced 16 B / lane
         S.q[0] = d.x; S.qd[0] = d.y; S.q[1] = d.z; S.qd[1] = d.w;
-        float2 ac = reinterpret_cast<const float2*>(act_env)[tid];      // this lane's two actions
+        float2 ac = reinterpret_cast<const float2*>(a.actions + (size_t)env * A * 8)[tid];     // this lane's two actions
         act0 = clampf(ac.x, -C->clip_actions, C->clip_actions);         // vec_task.py:127
         act1 = clampf(ac.y, -C->clip_actions, C->clip_actions);
     }
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
 
     // ---- physics: skipped per env for envs flagged for reset (their state is overwritten below) ---------------
     // (the loop itself is block-uniform so that every lane reaches every barrier)
-    const bool simulate = a.do_physics && reset_flag == 0;
+    const bool simulate = a.do_physics && !reset_now;
     if (a.do_physics) {
         const float h = C->dt / (float)C->substeps;
         for (int s = 0; s < C->substeps; s++) {
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
             } else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
             quad_sum(IA0, pA0);
             S6 wr = S6{V3{0, 0, 0}, V3{0, 0, 0}};
-            if (is_ant && simulate) leg_outward<kSensors>(M, h, S, P, &SP, IA0, pA0, wr, sens);
+            if (is_ant && simulate) leg_outward<kSensors>(M, L, h, S, leg, *s_bp, P, &SP, IA0, pA0, wr, sens);
             S6 w;
             if (BLOCK == 64 && EPB == 1) {                               // one wave per env: the reaction wrench by DPP / permute
                 w = S6{V3{wave_sum(wr.a.x), wave_sum(wr.a.y), wave_sum(wr.a.z)}, V3{wave_sum(wr.l.x), wave_sum(wr.l.y), wave_sum(wr.l.z)}};
@@ -241,13 +241,23 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
     }
 
     // ---- post_physics_step: progress, reset_idx (ten_ant.py:894-901) --------------------------
+    int env_e = env;
+    asm volatile("" : "+v"(env_e));                 // opaque copy: per-env addresses are re-formed here, not carried through the loop
+    float* root_env = a.root_states + (size_t)env_e * actors * 13;
+    const float* init_env = a.initial_root_states + (size_t)env_e * actors * 13;
+    float* dof_env = a.dof_state + (size_t)env_e * A * 16;
+    float* prev_env = a.prev + (size_t)env_e * a.prev_dim;
+    const V3 origin = V3{a.env_origin[3 * env_e], a.env_origin[3 * env_e + 1], a.env_origin[3 * env_e + 2]};
+    int64_t progress = a.progress[env_e];
+    const int64_t reset_count = a.reset_count[env_e];            // bumped by lane 0 after the last barrier of the epilogue
+    const uint64_t env_global = (uint64_t)(C->env_offset + env_e);
+    const int64_t reset_flag = reset_now ? 1 : 0;
     progress += 1;
     RigidState B;
     if (reset_flag != 0) {
-        if (is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env, env_global, (uint64_t)reset_count);
+        if (is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env_e, env_global, (uint64_t)reset_count);
         B = load_rigid(init_env + 13 * A);
         progress = 0;
-        if (tid == 0 && live) a.reset_count[env] = reset_count + 1;
     } else {
         B = load_rigid(s_box);
     }
@@ -293,9 +303,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
             float rew;
             int64_t rs;
             tenant_reward_finish(C, A, s_red, B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
-            a.rew[env] = rew;
-            a.reset[env] = rs;
-            a.progress[env] = progress;
+            a.rew[env_e] = rew;
+            a.reset[env_e] = rs;
+            a.progress[env_e] = progress;
         }
     } else {  // OneAnt
         float pot_in = prev_env[4];
@@ -305,7 +315,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
             OneAntLaneOut o = oneant_obs_lane(C, L, S, leg, origin, act0, act1, sens, s_obs, core, pg);
             float ec = quad_sum(o.ec), lim = quad_sum(o.lim), ac = quad_sum(o.acost);
             if (simulate && live) {
-                float* fs = a.foot_sensors + ((size_t)env * A + ant) * 24 + 6 * leg;
+                float* fs = a.foot_sensors + ((size_t)env_e * A + ant) * 24 + 6 * leg;
 #pragma unroll
                 for (int i = 0; i < 6; i++) fs[i] = sens[i];
             }
@@ -317,9 +327,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
                 int64_t rs;
                 oneant_reward(C, pg.z, core.up_proj, ec, lim, ac, pbx, pby, bbx, bby, pg.x, pg.y, bgx, bgy, B.qx, B.qy, B.qz, B.qw,
                               progress, rew, rs);
-                a.rew[env] = rew;
-                a.reset[env] = rs;
-                a.progress[env] = progress;
+                a.rew[env_e] = rew;
+                a.reset[env_e] = rs;
+                a.progress[env_e] = progress;
                 prev_env[0] = pg.x; prev_env[1] = pg.y; prev_env[2] = bgx; prev_env[3] = bgy;   // one_ant.py:432-433
                 prev_env[4] = pot; prev_env[5] = pot_in;
             }
@@ -327,9 +337,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : 1) ant
         __syncthreads();
     }
     // ---- coalesced observation row(s) --------------------------------------------------------
+    if (reset_now && tid == 0 && live) a.reset_count[env_e] = reset_count + 1;   // every lane of the env read it before the barrier above
     if (live)
-        write_obs_row(s_obs, obs_dim, C->clip_obs, a.obs + (size_t)env * obs_dim, a.obs_clipped + (size_t)env * obs_dim,
-                      a.obs_out ? a.obs_out + (size_t)env * obs_dim : nullptr, tid, LPE);
+        write_obs_row(s_obs, obs_dim, C->clip_obs, a.obs + (size_t)env_e * obs_dim, a.obs_clipped + (size_t)env_e * obs_dim,
+                      a.obs_out ? a.obs_out + (size_t)env_e * obs_dim : nullptr, tid, LPE);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -83,8 +83,8 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
                 for (int j = 0; j < 4; j++) { IA[q + j] = sum; pA[q + j] = ps; }
             }
             for (int t = 0; t < nl; t++) {
-                if (task == MMS_TASK_ONE_ANT) leg_outward<true>(M, h, S[t], P[t], &SP[t], IA[t], pA[t], wr[t], &sens[6 * t]);
-                else leg_outward<false>(M, h, S[t], P[t], &SP[t], IA[t], pA[t], wr[t], nullptr);
+                if (task == MMS_TASK_ONE_ANT) leg_outward<true>(M, L[t], h, S[t], t & 3, bp, P[t], &SP[t], IA[t], pA[t], wr[t], &sens[6 * t]);
+                else leg_outward<false>(M, L[t], h, S[t], t & 3, bp, P[t], &SP[t], IA[t], pA[t], wr[t], nullptr);
             }
             float wt[6];
             for (int c = 0; c < 6; c++) { float tsum = 0.f; for (int t = 0; t < nl; t++) tsum += get(wr[t], c); wt[c] = tsum; }
