@@ -110,14 +110,16 @@ __device__ __forceinline__ void write_obs_row(const float* s_obs, int obs_dim, f
 #define MMS_WAVES_PER_EU 2      // one-wave envs: 2 waves per SIMD; 3 and 4 need spills and measured slower (profiles/r01_v3_bench_wpe*.json)
 #endif
 __host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
-    return (size_t)((obs_dim + 3) & ~3) + 16 + (sizeof(BoxPose) + 15) / 16 * 4 + 8 + (size_t)(((RP_STRIDE + 6) * A + 3) & ~3);
+    return (size_t)((obs_dim + 3) & ~3) + 16 + (sizeof(BoxPose) + 15) / 16 * 4 + 8 + (size_t)(((RP_STRIDE + 6) * A + 3) & ~3) +
+           (size_t)((4 * A + 2 + 7 + 3) & ~3);     // + staging of the epilogue's inputs (prev_dim <= 4A+2, origin, progress, reset count)
 }
 // Residency target: TenAnt at 4096 envs is 1024 blocks x 3 waves = 3072 waves = exactly 3 per SIMD on 256 CUs, so the whole
 // grid is resident at once when the kernel fits in 168 VGPRs (the unpacked layout needs 4096 waves = 4 per SIMD = 128 VGPRs).
 #ifndef MMS_WAVES_PER_EU_PACKED
 #define MMS_WAVES_PER_EU_PACKED 3
 #endif
-template <int TASK, int BLOCK, int EPB>
+// AT > 0 fixes the number of ants at compile time (LDS offsets become immediates, the per-ant loops unroll); 0 = runtime.
+template <int TASK, int BLOCK, int EPB, int AT>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK == 192 ? MMS_WAVES_PER_EU_PACKED : 1)) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LPE = BLOCK / EPB;
@@ -128,13 +130,14 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     const int env_raw = blockIdx.x * EPB + e_loc;
     const bool live = env_raw < a.num_envs;                  // a partial last block still runs every barrier
     const int env = live ? env_raw : a.num_envs - 1;
-    const int A = a.num_agents;
+    const int A = AT > 0 ? AT : a.num_agents;
     const int n_ant_lanes = 4 * A;
     const int box_base = (n_ant_lanes + 7) & ~7;
     const bool is_ant = tid < n_ant_lanes;
     const bool is_box = tid >= box_base && tid < box_base + 8;
     const int ant = tid >> 2, leg = tid & 3;
-    const int obs_dim = a.obs_dim;
+    const int obs_dim = AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim;
+    const int prev_dim = AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 4 * AT + 2 : 6) : a.prev_dim;
     const int obs_pad = (obs_dim + 3) & ~3;
 
     // per-leg constants and the box pose live in LDS and are read at the point of use: keeping them in registers
@@ -149,6 +152,12 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     float* s_red = env_lds + kRedOff;              // [A][RP_STRIDE] reward partials
     float* s_wr = s_red + RP_STRIDE * A;           // [6][A] per-ant reactions on the box
     float* s_obs = env_lds + ((kRedOff + (RP_STRIDE + 6) * A + 3) & ~3);   // [obs_pad] observation row (16-B aligned)
+    // The epilogue's inputs (caches, env origin, progress, reset count) are fetched together with the state and parked in
+    // the observation row's LDS space (free until the epilogue) so that the kernel pays ONE HBM round trip at the top.
+    float* s_stage = s_obs + obs_pad;              // [prev_dim][3 origin][2 progress][2 reset_count]
+    // The clamped actions go straight into their slots of the observation row (ten_ant.py:1346, one_ant.py:615) and are
+    // read back from there by the substeps: no registers held across the physics loop for them.
+    float* s_act = s_obs + (TASK == MMS_TASK_TEN_ANT ? 38 * ant + 30 + 2 * leg : 52 + 2 * leg);
 
     const int actors = A + 1;
     const bool reset_now = a.reset[env] != 0;
@@ -163,10 +172,17 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
         s_bp->pos = B0.pos; s_bp->R = quat_to_mat(B0.qx, B0.qy, B0.qz, B0.qw); s_bp->v = B0.vel; s_bp->w = B0.ang;
         s_bp->half = V3{M->box_half[0], M->box_half[1], M->box_half[2]};
     }
+    for (int i = tid; i < prev_dim; i += LPE) s_stage[i] = a.prev[(size_t)env * prev_dim + i];
+    if (tid == box_base + 1) {
+        s_stage[prev_dim + 0] = a.env_origin[3 * env]; s_stage[prev_dim + 1] = a.env_origin[3 * env + 1];
+        s_stage[prev_dim + 2] = a.env_origin[3 * env + 2];
+        int64_t pr = a.progress[env], rc = a.reset_count[env];
+        int* si = reinterpret_cast<int*>(s_stage + prev_dim + 3);
+        si[0] = (int)(pr & 0xffffffff); si[1] = (int)(pr >> 32); si[2] = (int)(rc & 0xffffffff); si[3] = (int)(rc >> 32);
+    }
     __syncthreads();
     const LegConst& L = s_leg[leg];
     AntLane S = {};
-    float act0 = 0.f, act1 = 0.f;
     if (is_ant) {
         const float* r = a.root_states + ((size_t)env * actors + ant) * 13;
         S.pos = V3{r[0], r[1], r[2]};
@@ -176,8 +192,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
         float4 d = reinterpret_cast<const float4*>(a.dof_state + (size_t)env * A * 16)[tid];   // (q1, qd1, q2, qd2): coalesced 16 B / lane
         S.q[0] = d.x; S.qd[0] = d.y; S.q[1] = d.z; S.qd[1] = d.w;
         float2 ac = reinterpret_cast<const float2*>(a.actions + (size_t)env * A * 8)[tid];     // this lane's two actions
-        act0 = clampf(ac.x, -C->clip_actions, C->clip_actions);         // vec_task.py:127
-        act1 = clampf(ac.y, -C->clip_actions, C->clip_actions);
+        s_act[0] = clampf(ac.x, -C->clip_actions, C->clip_actions);     // vec_task.py:127
+        s_act[1] = clampf(ac.y, -C->clip_actions, C->clip_actions);
     }
     float sens[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (TASK == MMS_TASK_ONE_ANT && is_ant) {      // sensors of the last simulated substep persist across a skipped step
@@ -198,8 +214,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             LegPass P;
             SensorPass SP;
             if (is_ant && simulate) {
-                const float tau1 = act0 * L.gear[0] * C->power_scale;    // ten_ant.py:889
-                const float tau2 = act1 * L.gear[1] * C->power_scale;
+                const float tau1 = s_act[0] * L.gear[0] * C->power_scale;    // ten_ant.py:889
+                const float tau2 = s_act[1] * L.gear[1] * C->power_scale;
                 leg_inward<kSensors>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0);
             } else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
             quad_sum(IA0, pA0);
@@ -216,14 +232,15 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
                     s_wr[3 * A + ant] = wr.l.x; s_wr[4 * A + ant] = wr.l.y; s_wr[5 * A + ant] = wr.l.z;
                 }
                 __syncthreads();
+                float t = 0.f;
                 if (is_box && tid - box_base < 6) {                      // column c summed in ant order by box lane c
                     const float* col = s_wr + (tid - box_base) * A;
-                    float t = 0.f;
                     for (int i = 0; i < A; i++) t += col[i];
-                    s_wtot[tid - box_base] = t;
                 }
-                __syncthreads();
-                w = S6{V3{s_wtot[0], s_wtot[1], s_wtot[2]}, V3{s_wtot[3], s_wtot[4], s_wtot[5]}};
+                // the eight box lanes of an env sit in one wave, 8-aligned: lane c hands its column to all of them
+                const int g0 = (int)(threadIdx.x & 63u) & ~7;
+                w = S6{V3{__shfl(t, g0 + 0, 64), __shfl(t, g0 + 1, 64), __shfl(t, g0 + 2, 64)},
+                       V3{__shfl(t, g0 + 3, 64), __shfl(t, g0 + 4, 64), __shfl(t, g0 + 5, 64)}};
             }
             if (is_box) {
                 RigidState B = load_rigid(s_box);
@@ -246,10 +263,11 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     float* root_env = a.root_states + (size_t)env_e * actors * 13;
     const float* init_env = a.initial_root_states + (size_t)env_e * actors * 13;
     float* dof_env = a.dof_state + (size_t)env_e * A * 16;
-    float* prev_env = a.prev + (size_t)env_e * a.prev_dim;
-    const V3 origin = V3{a.env_origin[3 * env_e], a.env_origin[3 * env_e + 1], a.env_origin[3 * env_e + 2]};
-    int64_t progress = a.progress[env_e];
-    const int64_t reset_count = a.reset_count[env_e];            // bumped by lane 0 after the last barrier of the epilogue
+    float* prev_env = a.prev + (size_t)env_e * prev_dim;
+    const V3 origin = V3{s_stage[prev_dim + 0], s_stage[prev_dim + 1], s_stage[prev_dim + 2]};
+    const unsigned* si = reinterpret_cast<const unsigned*>(s_stage + prev_dim + 3);
+    int64_t progress = (int64_t)(((uint64_t)si[1] << 32) | si[0]);
+    const int64_t reset_count = (int64_t)(((uint64_t)si[3] << 32) | si[2]);   // bumped by lane 0 after the last barrier
     const uint64_t env_global = (uint64_t)(C->env_offset + env_e);
     const int64_t reset_flag = reset_now ? 1 : 0;
     progress += 1;
@@ -277,10 +295,14 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     if (TASK == MMS_TASK_TEN_ANT) {
         const float ang = box_angle(B.qz, B.qw);
         const float sv = sinf(ang), cv = -cosf(ang);
+        // caches: previous step's values; mms_create fills them from the construction-time poses (ten_ant.py:870-882)
+        float pbx = 0.f, pby = 0.f, gbx = 0.f, gby = 0.f;
         if (is_ant) {
-            // caches: previous step's values; mms_create fills them from the construction-time poses (ten_ant.py:870-882)
-            const float pbx = prev_env[2 * ant], pby = prev_env[2 * ant + 1];
-            const float gbx = prev_env[2 * A + 2 * ant], gby = prev_env[2 * A + 2 * ant + 1];
+            pbx = s_stage[2 * ant]; pby = s_stage[2 * ant + 1];
+            gbx = s_stage[2 * A + 2 * ant]; gby = s_stage[2 * A + 2 * ant + 1];
+        }
+        if (is_ant) {
+            const float act0 = s_act[0], act1 = s_act[1];
             TenAntLaneOut o = tenant_obs_reward_lane(C, L, S, ant, leg, origin, act0, act1, bgx, bgy, sv, cv, pbx, pby, gbx, gby, s_obs);
             float ec = quad_sum(o.ec), lim = quad_sum(o.lim), ac = quad_sum(o.acost);
             if (leg == 0) {
@@ -308,8 +330,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             a.progress[env_e] = progress;
         }
     } else {  // OneAnt
-        float pot_in = prev_env[4];
+        const float pot_in = s_stage[4];
+        const float pbx = s_stage[0], pby = s_stage[1], bbx = s_stage[2], bby = s_stage[3];
         if (is_ant) {
+            const float act0 = s_act[0], act1 = s_act[1];
             AntObsCore core;
             V3 pg;
             OneAntLaneOut o = oneant_obs_lane(C, L, S, leg, origin, act0, act1, sens, s_obs, core, pg);
@@ -320,7 +344,6 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
                 for (int i = 0; i < 6; i++) fs[i] = sens[i];
             }
             if (tid == 0 && live) {
-                const float pbx = prev_env[0], pby = prev_env[1], bbx = prev_env[2], bby = prev_env[3];
                 float tbx = 0.f - bgx, tby = 0.f - bgy;
                 float pot = -sqrtf(tbx * tbx + tby * tby + 0.f * 0.f) / C->dt;          // one_ant.py:583-587
                 float rew;
@@ -437,11 +460,11 @@ __global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
-template <int TASK, int BLOCK, int EPB>
+template <int TASK, int BLOCK, int EPB, int AT>
 static hipError_t launch_ant(const StepArgs& a, hipStream_t stream) {
     size_t lds = (4 * sizeof(LegConst) + 15) / 16 * 16 + (size_t)EPB * ((ant_env_lds_floats(a.obs_dim, a.num_agents) + 3) & ~(size_t)3) * sizeof(float);
     int grid = (a.num_envs + EPB - 1) / EPB;
-    hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT>), dim3(grid), dim3(BLOCK), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -453,11 +476,11 @@ hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {
         return hipGetLastError();
     }
     const int lpe = ((4 * a.num_agents + 7) & ~7) + 8;        // lanes one env needs
-    if (task == MMS_TASK_ONE_ANT) return (a.packing != 0) ? launch_ant<MMS_TASK_ONE_ANT, 64, 4>(a, stream) : launch_ant<MMS_TASK_ONE_ANT, 64, 1>(a, stream);
+    if (task == MMS_TASK_ONE_ANT) return (a.packing != 0) ? launch_ant<MMS_TASK_ONE_ANT, 64, 4, 1>(a, stream) : launch_ant<MMS_TASK_ONE_ANT, 64, 1, 1>(a, stream);
     if (task != MMS_TASK_TEN_ANT) return hipErrorInvalidValue;
-    if (lpe == 48 && a.packing != 0) return launch_ant<MMS_TASK_TEN_ANT, 192, 4>(a, stream);
-    if (lpe <= 64) return launch_ant<MMS_TASK_TEN_ANT, 64, 1>(a, stream);
-    if (lpe <= 512) return launch_ant<MMS_TASK_TEN_ANT, 512, 1>(a, stream);
+    if (a.num_agents == 10 && a.packing != 0) return launch_ant<MMS_TASK_TEN_ANT, 192, 4, 10>(a, stream);
+    if (lpe <= 64) return launch_ant<MMS_TASK_TEN_ANT, 64, 1, 0>(a, stream);
+    if (lpe <= 512) return launch_ant<MMS_TASK_TEN_ANT, 512, 1, 0>(a, stream);
     return hipErrorInvalidValue;
 }
 
