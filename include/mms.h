@@ -165,6 +165,13 @@ int mms_gae_marl(int device, const float* rewards, const float* value_preds, con
                  float* returns, int32_t T, int64_t N, float gamma, float lam,
                  int32_t use_norm, const float* norm_mean, const float* norm_var, void* hip_stream);
 
+/* The same for all A agents of all envs in one launch (rollout-buffer fusion):
+ * value_preds / returns [T+1,N,A] (agent fastest), rewards [T,N] and masks [T+1,N] stored once per env instead of
+ * once per agent buffer (runner.py:250-255 inserts the same reward / mask into ten buffers); norm_mean / norm_var [A]. */
+int mms_gae_marl_agents(int device, const float* rewards, const float* value_preds, const float* masks,
+                        float* returns, int32_t T, int64_t N, int32_t A, float gamma, float lam,
+                        int32_t use_norm, const float* norm_mean, const float* norm_var, void* hip_stream);
+
 const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
 int mms_abi_version(void);
 

@@ -11,7 +11,7 @@ _lib = None
 
 # every symbol include/mms.h declares (tests check that the library exports all of them)
 SYMBOLS = ["mms_create", "mms_destroy", "mms_get_tensor", "mms_step", "mms_post_step", "mms_reset_all", "mms_set_state",
-           "mms_bind_obs_out", "mms_marl_views", "mms_gae_ppo", "mms_adv_normalize", "mms_gae_marl",
+           "mms_bind_obs_out", "mms_marl_views", "mms_gae_ppo", "mms_adv_normalize", "mms_gae_marl", "mms_gae_marl_agents",
            "mms_last_error", "mms_abi_version"]
 
 
@@ -40,6 +40,7 @@ def lib():
     L.mms_gae_ppo.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, c64, cf, cf, vp]
     L.mms_adv_normalize.argtypes = [ci, vp, vp, c64, vp]
     L.mms_gae_marl.argtypes = [ci, vp, vp, vp, vp, ctypes.c_int32, c64, cf, cf, ctypes.c_int32, vp, vp, vp]
+    L.mms_gae_marl_agents.argtypes = [ci, vp, vp, vp, vp, ctypes.c_int32, c64, ctypes.c_int32, cf, cf, ctypes.c_int32, vp, vp, vp]
     L.mms_last_error.argtypes = [vp]
     L.mms_last_error.restype = ctypes.c_char_p
     L.mms_abi_version.restype = ci

@@ -1,0 +1,191 @@
+"""Rollout-buffer fusion for the MARL runners.
+
+The reference keeps one SeparatedReplayBuffer per agent (agents/algorithms/marl/runner.py:100-112) and, every step,
+copies the SAME 388-wide centralised-critic row, the same reward and the same mask into each of the ten buffers
+(runner.py:250-255, separated_buffer.py:67-85): ten copies of `share_obs [T+1, N, 388]` = 570 MB at 4096 envs.  It then
+walks the envs in a Python loop with a device sync per step (runner.py:141-144).
+
+`SharedRolloutBuffers` owns ONE set of tensors and hands out per-agent objects with the SeparatedReplayBuffer attribute
+set (`share_obs`, `obs`, `value_preds`, `returns`, `rewards`, `masks`, `actions`, ... and `insert`, `compute_returns`,
+`after_update`) whose tensors are VIEWS of the shared storage, so the reference's collect / train code runs unchanged:
+
+  * `share_obs`  one [T+1, N, 388] tensor; the engine writes the clamped row of step t straight into slot t+1
+                 (mms_bind_obs_out): zero copies, stored once instead of A times;
+  * `obs`        one [T+1, N, A, 46] tensor filled by mms_marl_views; agent k sees `obs[:, :, k]`;
+  * `rewards`, `masks`  stored once ([T, N, 1], [T+1, N, 1]); every agent's view is the same tensor;
+  * `value_preds`, `returns`  [T+1, N, A]; one GAE launch for all agents (mms_gae_marl_agents);
+  * `insert_step` does the runner's `insert` for all agents at once, and `finished_episode_rewards` replaces the per-env loop.
+"""
+import ctypes
+
+import torch
+
+from .... import _lib
+from ....engine import current_stream_ptr
+
+
+class _AgentView:
+    """Per-agent facade with the SeparatedReplayBuffer attribute names (separated_buffer.py:36-60)."""
+
+    def __init__(self, parent, k):
+        self._p, self._k = parent, k
+        p = parent
+        self.episode_length, self.n_rollout_threads = p.T, p.N
+        self.share_obs = p.share_obs
+        self.obs = p.obs[:, :, k]
+        self.rnn_states = p.rnn_states[:, :, k]
+        self.rnn_states_critic = p.rnn_states_critic[:, :, k]
+        self.value_preds = p.value_preds[:, :, k:k + 1]
+        self.returns = p.returns[:, :, k:k + 1]
+        self.actions = p.actions[:, :, k]
+        self.action_log_probs = p.action_log_probs[:, :, k]
+        self.rewards = p.rewards
+        self.masks = p.masks
+        self.bad_masks = p.bad_masks
+        self.active_masks = p.active_masks[:, :, k]
+        self.factor = p.factor[:, :, k]
+        self.available_actions = None
+
+    @property
+    def step(self):
+        return self._p.step
+
+    def update_factor(self, factor):
+        self.factor.copy_(factor)
+
+    def insert(self, share_obs, obs, rnn_states, rnn_states_critic, actions, action_log_probs, value_preds, rewards, masks,
+               bad_masks=None, active_masks=None, available_actions=None):
+        """API-compatible per-agent insert (separated_buffer.py:67-85).  The shared parts are written by whichever
+        agent comes first in a step; prefer SharedRolloutBuffers.insert_step."""
+        p, k, s = self._p, self._k, self._p.step
+        if k == 0:
+            if share_obs.data_ptr() != p.share_obs[s + 1].data_ptr():
+                p.share_obs[s + 1].copy_(share_obs)
+            p.rewards[s].copy_(rewards)
+            p.masks[s + 1].copy_(masks)
+        self.obs[s + 1].copy_(obs)
+        self.rnn_states[s + 1].copy_(rnn_states)
+        self.rnn_states_critic[s + 1].copy_(rnn_states_critic)
+        self.actions[s].copy_(actions)
+        self.action_log_probs[s].copy_(action_log_probs)
+        self.value_preds[s].copy_(value_preds)
+        if active_masks is not None:
+            self.active_masks[s + 1].copy_(active_masks)
+        if k == p.A - 1:
+            p.step = (s + 1) % p.T
+
+    def after_update(self):
+        if self._k == 0:
+            self._p.after_update()
+
+    def compute_returns(self, next_value, value_normalizer=None):
+        self._p._pending[self._k] = (next_value, value_normalizer)
+        if len(self._p._pending) == self._p.A:
+            nv = torch.cat([self._p._pending[k][0].reshape(-1, 1) for k in range(self._p.A)], 1)
+            norms = [self._p._pending[k][1] for k in range(self._p.A)]
+            self._p._pending = {}
+            self._p.compute_returns(nv, norms)
+
+
+class SharedRolloutBuffers:
+    def __init__(self, config, env, device):
+        self.T = config["episode_length"]
+        self.N = config["n_rollout_threads"]
+        self.gamma, self.gae_lambda = config["gamma"], config["gae_lambda"]
+        self._use_norm = bool(config["use_popart"] or config["use_valuenorm"])
+        if config["use_proper_time_limits"] or not config["use_gae"]:
+            raise NotImplementedError("only use_gae=True, use_proper_time_limits=False (the shipped configs)")
+        self.device = torch.device(device)
+        self.env = env
+        self.A = env.num_agents
+        T, N, A = self.T, self.N, self.A
+        od, sd, ad = env.num_observations, env.nums_share_observations, env.action_space[0].shape[0]
+        rn, hs = config["recurrent_N"], config["hidden_size"]
+        z = lambda *s: torch.zeros(*s, device=self.device)
+        self.share_obs = z(T + 1, N, sd)
+        self.obs = z(T + 1, N, A, od)
+        self.rnn_states = z(T + 1, N, A, rn, hs)
+        self.rnn_states_critic = z(T + 1, N, A, rn, hs)
+        self.value_preds = z(T + 1, N, A)
+        self.returns = z(T + 1, N, A)
+        self.actions = z(T, N, A, ad)
+        self.action_log_probs = z(T, N, A, ad)
+        self.rewards = z(T, N, 1)
+        self.masks = torch.ones(T + 1, N, 1, device=self.device)
+        self.bad_masks = torch.ones_like(self.masks)
+        self.active_masks = torch.ones(T + 1, N, A, 1, device=self.device)
+        self.factor = torch.ones(T, N, A, 1, device=self.device)
+        self.step = 0
+        self._pending = {}
+        self.agents = [_AgentView(self, k) for k in range(A)]
+
+    # -- environment side ----------------------------------------------------------------------------------------
+    def warmup(self):
+        """Runner.warmup (runner.py:187-197): reset the envs, slot 0 of share_obs / obs."""
+        self._bind(0)
+        self.env.task.step(torch.zeros(self.N, self.env.task.engine.num_actions, device=self.device))   # multi_vec_task.py:147
+        self._views(0)
+
+    def env_step(self, actions):
+        """envs.step + the observation part of insert: the engine writes share_obs[t+1] and obs[t+1] in place.
+        Returns (rewards [N], dones [N]) as views of engine memory (valid until the next step)."""
+        s = self.step
+        if isinstance(actions, (list, tuple)):
+            actions = torch.hstack(list(actions))
+        self._bind(s + 1)
+        self.env.task.step(actions)
+        self._views(s + 1)
+        return self.env.task.rew_buf, self.env.task.reset_buf
+
+    def _bind(self, slot):
+        self.env.task.engine.bind_obs_out(self.share_obs[slot])
+
+    def _views(self, slot):
+        e = self.env.task.engine
+        _lib.check(_lib.lib().mms_marl_views(e.device_index, ctypes.c_void_p(self.share_obs[slot].data_ptr()),
+                                             ctypes.c_void_p(self.obs[slot].data_ptr()), self.N, self.A, self.env.num_ant_obs,
+                                             self.env.shared_obs, current_stream_ptr(e.device)), None, "mms_marl_views")
+
+    def insert_step(self, rewards, dones, values, actions, action_log_probs):
+        """Runner.insert for all agents (runner.py:222-255) without the per-agent copies of shared data.
+        rewards [N], dones [N]; values [N, A]; actions / action_log_probs [N, A, act_dim] (or lists of A tensors)."""
+        s = self.step
+        if isinstance(actions, (list, tuple)):
+            actions = torch.stack(list(actions), 1)
+            action_log_probs = torch.stack(list(action_log_probs), 1)
+        self.rewards[s].copy_(rewards.view(-1, 1))
+        self.masks[s + 1].copy_((dones == 0).to(torch.float32).view(-1, 1))        # dones are per env: dones_env == dones
+        self.value_preds[s].copy_(values.reshape(self.N, self.A))
+        self.actions[s].copy_(actions)
+        self.action_log_probs[s].copy_(action_log_probs)
+        self.step = (s + 1) % self.T
+
+    def finished_episode_rewards(self, running, reward_env, dones_env):
+        """The per-env Python loop of runner.py:141-144 as tensor ops without a host sync: adds this step's reward to
+        `running` [N], returns (sum, count) of the returns of episodes that ended, and zeroes them in `running`."""
+        running += reward_env
+        done = dones_env != 0
+        total, count = (running * done).sum(), done.sum()
+        running.mul_((~done).to(running.dtype))
+        return total, count
+
+    # -- learner side --------------------------------------------------------------------------------------------
+    def after_update(self):
+        for t in (self.share_obs, self.obs, self.rnn_states, self.rnn_states_critic, self.masks, self.bad_masks, self.active_masks):
+            t[0].copy_(t[-1])
+
+    def compute_returns(self, next_values, value_normalizers=None):
+        """next_values [N, A]; value_normalizers: list of A PopArt / ValueNorm objects (or None)."""
+        self.value_preds[-1].copy_(next_values.reshape(self.N, self.A))
+        dev = self.device
+        if self._use_norm:
+            mv = [n.running_mean_var() for n in value_normalizers]
+            mean = torch.stack([m.reshape(()) for m, _ in mv]).to(dev).float().contiguous()
+            var = torch.stack([v.reshape(()) for _, v in mv]).to(dev).float().contiguous()
+        else:
+            mean = var = self.rewards
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().mms_gae_marl_agents(idx, p(self.rewards), p(self.value_preds), p(self.masks), p(self.returns), self.T,
+                                                  self.N, self.A, float(self.gamma), float(self.gae_lambda), 1 if self._use_norm else 0,
+                                                  p(mean), p(var), current_stream_ptr(dev)), None, "mms_gae_marl_agents")

@@ -19,6 +19,7 @@ hipError_t launch_gae_ppo(const float*, const uint8_t*, const float*, const floa
 hipError_t launch_adv_normalize(float*, const double*, int64_t, hipStream_t);
 hipError_t launch_gae_marl(const float*, const float*, const float*, float*, int, int64_t, float, float, int, const float*, const float*, hipStream_t);
 hipError_t launch_marl_views(const float*, float*, int64_t, int, int, int, hipStream_t);
+hipError_t launch_gae_marl_agents(const float*, const float*, const float*, float*, int, int64_t, int, float, float, int, const float*, const float*, hipStream_t);
 }  // namespace mms
 
 struct mms_buffer {
@@ -304,6 +305,14 @@ __attribute__((visibility("default"))) int mms_gae_marl(int device, const float*
                  float gamma, float lam, int32_t use_norm, const float* norm_mean, const float* norm_var, void* s) {
     if (dev_guard(device)) return 1;
     MMS_FREE(mms::launch_gae_marl(rewards, value_preds, masks, returns, T, N, gamma, lam, use_norm, norm_mean, norm_var, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_gae_marl_agents(int device, const float* rewards, const float* value_preds, const float* masks,
+                                                               float* returns, int32_t T, int64_t N, int32_t A, float gamma, float lam,
+                                                               int32_t use_norm, const float* norm_mean, const float* norm_var, void* s) {
+    if (dev_guard(device)) return 1;
+    MMS_FREE(mms::launch_gae_marl_agents(rewards, value_preds, masks, returns, T, N, A, gamma, lam, use_norm, norm_mean, norm_var, (hipStream_t)s));
     return 0;
 }
 

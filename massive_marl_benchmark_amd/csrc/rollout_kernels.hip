@@ -90,6 +90,34 @@ __global__ void __launch_bounds__(256) gae_marl_kernel(const float* __restrict__
     }
 }
 
+// All agents of all envs in one launch: value_preds / returns are [T+1, N, A] (agent fastest), rewards and
+// masks are shared per env ([T, N], [T+1, N]: the reference stores the same reward / mask once per agent buffer), the
+// normaliser statistics are per agent.  Column (i, k) = env i, agent k.
+__global__ void __launch_bounds__(256) gae_marl_agents_kernel(const float* __restrict__ rewards, const float* __restrict__ value_preds,
+                                                              const float* __restrict__ masks, float* __restrict__ returns, int T, int64_t N,
+                                                              int A, float gamma, float lam, int use_norm,
+                                                              const float* __restrict__ norm_mean, const float* __restrict__ norm_var) {
+    const int64_t cols = N * A;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = c / A;
+        const int k = (int)(c - i * A);
+        float mean = 0.f, sd = 1.f;
+        if (use_norm) { mean = norm_mean[k]; sd = sqrtf(norm_var[k]); }
+        float gae = 0.f;
+        float v1 = value_preds[(int64_t)T * cols + c];
+        if (use_norm) v1 = v1 * sd + mean;
+        for (int t = T - 1; t >= 0; t--) {
+            float v0 = value_preds[(int64_t)t * cols + c];
+            if (use_norm) v0 = v0 * sd + mean;
+            float m = masks[(int64_t)(t + 1) * N + i];
+            float delta = rewards[(int64_t)t * N + i] + gamma * v1 * m - v0;
+            gae = delta + gamma * lam * m * gae;
+            returns[(int64_t)t * cols + c] = gae + v0;
+            v1 = v0;
+        }
+    }
+}
+
 // obs_all[n][k][0:per] = obs[n][k*per : (k+1)*per], obs_all[n][k][per:] = obs[n][agents*per:]; input already clamped
 __global__ void __launch_bounds__(256) marl_views_kernel(const float* __restrict__ obs, float* __restrict__ obs_all, int64_t n,
                                                          int agents, int per, int shared) {
@@ -123,6 +151,11 @@ hipError_t launch_adv_normalize(float* advantages, const double* stats, int64_t 
 hipError_t launch_gae_marl(const float* rewards, const float* value_preds, const float* masks, float* returns, int T, int64_t N, float gamma,
                            float lam, int use_norm, const float* mean, const float* var, hipStream_t s) {
     hipLaunchKernelGGL(gae_marl_kernel, dim3(grid_for(N)), dim3(256), 0, s, rewards, value_preds, masks, returns, T, N, gamma, lam, use_norm, mean, var);
+    return hipGetLastError();
+}
+hipError_t launch_gae_marl_agents(const float* rewards, const float* value_preds, const float* masks, float* returns, int T, int64_t N, int A,
+                                  float gamma, float lam, int use_norm, const float* mean, const float* var, hipStream_t s) {
+    hipLaunchKernelGGL(gae_marl_agents_kernel, dim3(grid_for(N * A)), dim3(256), 0, s, rewards, value_preds, masks, returns, T, N, A, gamma, lam, use_norm, mean, var);
     return hipGetLastError();
 }
 hipError_t launch_marl_views(const float* obs, float* obs_all, int64_t n, int agents, int per, int shared, hipStream_t s) {

@@ -1,6 +1,13 @@
 """BaseTask: the step protocol and buffer set of agents/tasks/agent_base/base_task.py:24-149, with the
 Isaac Gym calls replaced by one fused engine step (Engine.step = pre_physics_step + simulate +
-post_physics_step).  Domain randomisation and the viewer are out of scope."""
+post_physics_step).
+
+Domain randomisation (base_task.py:216-410): the non-physical part -- observation and action noise lambdas,
+gaussian / uniform, additive / scaling, with the linear / constant schedules and the correlated term
+(base_task.py:246-316) -- is implemented with the same parameters and semantics.  Per-actor physical randomisation
+(mass, damping, limits) and the viewer are out of scope this round."""
+import operator
+
 import torch
 
 from ...engine import Engine
@@ -47,12 +54,105 @@ class BaseTask:
         self.extras = {}
         self.viewer = None
         self.dt = cfg["sim"]["dt"]
+        # domain randomisation state (base_task.py:70-80)
+        self.dr_randomizations = {}
+        self.first_randomization = True
+        self.last_step = -1
+        self.last_rand_step = -1
+        self.frame_count = 0
+        self._engine_obs = self.obs_buf
+        self._engine_obs_clipped = self.obs_buf_clipped
+        self._clip_obs = clip_obs
+        task_cfg = cfg.get("task", {}) or {}
+        self.randomize = bool(task_cfg.get("randomize", False))
+        self.randomization_params = task_cfg.get("randomization_params", {})
+        if self.randomize:
+            self.apply_randomizations(self.randomization_params)          # ten_ant.py:226-227
 
     def step(self, actions):
         """base_task.py:129-149.  `actions`: [num_envs, engine action width]; clamping happens in the kernel."""
+        if self.dr_randomizations.get('actions', None):
+            actions = self.dr_randomizations['actions']['noise_lambda'](actions)
         if actions.data_ptr() != self._actions.data_ptr():
             self._actions.copy_(actions.reshape(self._actions.shape))
+        if self.randomize and bool(self.reset_buf.any()):
+            self.apply_randomizations(self.randomization_params)          # reset_idx does this (ten_ant.py:812-813)
         self.engine.step()
+        self.frame_count += 1
+        self.randomize_buf += 1
+        if self.dr_randomizations.get('observations', None):
+            self.obs_buf = self.dr_randomizations['observations']['noise_lambda'](self._engine_obs)
+            self.obs_buf_clipped = torch.clamp(self.obs_buf, -self._clip_obs, self._clip_obs)
+        else:
+            self.obs_buf, self.obs_buf_clipped = self._engine_obs, self._engine_obs_clipped
+
+    def apply_randomizations(self, dr_params):
+        """The 'observations' / 'actions' branch of base_task.py:216-316 (same parameters, schedules and lambdas)."""
+        rand_freq = dr_params.get("frequency", 1)
+        self.last_step = self.frame_count                                  # gym.get_frame_count
+        if self.first_randomization:
+            do_nonenv_randomize = True
+        else:
+            do_nonenv_randomize = (self.last_step - self.last_rand_step) >= rand_freq
+            rand_envs = torch.logical_and(self.randomize_buf >= rand_freq, self.reset_buf.bool())
+            self.randomize_buf[rand_envs] = 0
+        if do_nonenv_randomize:
+            self.last_rand_step = self.last_step
+        for name in ("observations", "actions"):
+            if name in dr_params and do_nonenv_randomize:
+                prm = dr_params[name]
+                dist, op_type = prm["distribution"], prm["operation"]
+                sched_type = prm.get("schedule", None)
+                sched_step = prm.get("schedule_steps", None) if "schedule" in prm else None
+                op = operator.add if op_type == 'additive' else operator.mul
+                if sched_type == 'linear':
+                    sched_scaling = 1.0 / sched_step * min(self.last_step, sched_step)
+                elif sched_type == 'constant':
+                    sched_scaling = 0 if self.last_step < sched_step else 1
+                else:
+                    sched_scaling = 1
+                if dist == 'gaussian':
+                    mu, var = prm["range"]
+                    mu_corr, var_corr = prm.get("range_correlated", [0., 0.])
+                    if op_type == 'additive':
+                        mu, var, mu_corr, var_corr = (x * sched_scaling for x in (mu, var, mu_corr, var_corr))
+                    elif op_type == 'scaling':
+                        var = var * sched_scaling
+                        mu = mu * sched_scaling + 1.0 * (1.0 - sched_scaling)
+                        var_corr = var_corr * sched_scaling
+                        mu_corr = mu_corr * sched_scaling + 1.0 * (1.0 - sched_scaling)
+
+                    def noise_lambda(tensor, param_name=name, op=op):
+                        params = self.dr_randomizations[param_name]
+                        corr = params.get('corr', None)
+                        if corr is None:
+                            corr = torch.randn_like(tensor)
+                            params['corr'] = corr
+                        corr = corr * params['var_corr'] + params['mu_corr']
+                        return op(tensor, corr + torch.randn_like(tensor) * params['var'] + params['mu'])
+
+                    self.dr_randomizations[name] = {'mu': mu, 'var': var, 'mu_corr': mu_corr, 'var_corr': var_corr,
+                                                    'noise_lambda': noise_lambda}
+                elif dist == 'uniform':
+                    lo, hi = prm["range"]
+                    lo_corr, hi_corr = prm.get("range_correlated", [0., 0.])
+                    if op_type == 'additive':
+                        lo, hi, lo_corr, hi_corr = (x * sched_scaling for x in (lo, hi, lo_corr, hi_corr))
+                    elif op_type == 'scaling':
+                        lo, hi, lo_corr, hi_corr = (x * sched_scaling + 1.0 * (1.0 - sched_scaling) for x in (lo, hi, lo_corr, hi_corr))
+
+                    def noise_lambda(tensor, param_name=name, op=op):
+                        params = self.dr_randomizations[param_name]
+                        corr = params.get('corr', None)
+                        if corr is None:
+                            corr = torch.randn_like(tensor)
+                            params['corr'] = corr
+                        corr = corr * (params['hi_corr'] - params['lo_corr']) + params['lo_corr']
+                        return op(tensor, corr + torch.rand_like(tensor) * (params['hi'] - params['lo']) + params['lo'])
+
+                    self.dr_randomizations[name] = {'lo': lo, 'hi': hi, 'lo_corr': lo_corr, 'hi_corr': hi_corr,
+                                                    'noise_lambda': noise_lambda}
+        self.first_randomization = False
 
     def get_states(self):
         return self.states_buf
