@@ -162,63 +162,73 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / 256.0
 
     # ---- PPO rollout series -----------------------------------------------------------------------------------
-    def rollout_step():
-        t = storage.step
-        cur_obs = obs_clipped                                            # current observation (clamped +-5, vec_task.py:131)
-        with torch.no_grad():
-            x = cur_obs.to(pdtype)
-            mean = actor(x).float()                                      # module.py:73-87
-            value = critic(x).float()
-            noise = torch.randn_like(mean)
-            act = mean + std * noise
-            logp = (-0.5 * noise * noise - log_std - half_log_2pi).sum(-1)
-        storage.observations[t].copy_(cur_obs)                           # the obs the action was computed from
-        actions_buf.copy_(act)
-        eng.step()
-        storage.add_transitions(storage.observations[t], states, act, rew, reset, value, logp, mean, sigma)
-        if storage.step == NSTEPS:
+    def measure_rollout(pdtype, K_req, W_req):
+        actor_, critic_ = (actor, critic) if pdtype == torch.float32 else (actor_bf16, critic_bf16)
+
+        def rollout_step():
+            t = storage.step
+            cur_obs = obs_clipped                                            # current observation (clamped +-5, vec_task.py:131)
             with torch.no_grad():
-                last_values = critic(obs_clipped.to(pdtype)).float()
-            storage.compute_returns(last_values, GAMMA, LAM)
-            storage.clear()
+                x = cur_obs.to(pdtype)
+                mean = actor_(x).float()                                     # module.py:73-87
+                value = critic_(x).float()
+                noise = torch.randn_like(mean)
+                act = mean + std * noise
+                logp = (-0.5 * noise * noise - log_std - half_log_2pi).sum(-1)
+            storage.observations[t].copy_(cur_obs)                           # the obs the action was computed from
+            actions_buf.copy_(act)
+            eng.step()
+            storage.add_transitions(storage.observations[t], states, act, rew, reset, value, logp, mean, sigma)
+            if storage.step == NSTEPS:
+                with torch.no_grad():
+                    last_values = critic_(obs_clipped.to(pdtype)).float()
+                storage.compute_returns(last_values, GAMMA, LAM)
+                storage.clear()
 
-    graph = None
-    for _ in range(NSTEPS):                      # eager warm-up (allocator, rocBLAS handles)
-        rollout_step()
-    torch.cuda.synchronize()
-    if not args.no_graph:
-        # one graph = one full PPO iteration's rollout (8 steps + GAE): launch-bound inner loop -> hipGraph
-        side = torch.cuda.Stream(device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                for _ in range(NSTEPS):
-                    rollout_step()
-        torch.cuda.current_stream(device).wait_stream(side)
+        graph = None
+        for _ in range(NSTEPS):                      # eager warm-up (allocator, rocBLAS handles)
+            rollout_step()
         torch.cuda.synchronize()
+        if not args.no_graph:
+            # one graph = one full PPO iteration's rollout (8 steps + GAE): launch-bound inner loop -> hipGraph
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(NSTEPS):
+                        rollout_step()
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize()
 
-    def run_steps(k):
-        if graph is None:
-            for _ in range(k):
-                rollout_step()
-        else:
-            assert k % NSTEPS == 0
-            for _ in range(k // NSTEPS):
-                graph.replay()
+        def run_steps(k):
+            if graph is None:
+                for _ in range(k):
+                    rollout_step()
+            else:
+                for _ in range(k // NSTEPS):
+                    graph.replay()
 
-    K = args.steps if graph is None else max(NSTEPS, (args.steps // NSTEPS) * NSTEPS)
-    W = args.warmup if graph is None else max(NSTEPS, ((args.warmup + NSTEPS - 1) // NSTEPS) * NSTEPS)
-    run_steps(W)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(K)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed, sim_wall, kernel_ms], dtype=torch.float64, device=device)
+        K = K_req if graph is None else max(NSTEPS, (K_req // NSTEPS) * NSTEPS)
+        W = W_req if graph is None else max(NSTEPS, ((W_req + NSTEPS - 1) // NSTEPS) * NSTEPS)
+        run_steps(W)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(K)
+        barrier()
+        return time.perf_counter() - t0, K, W, graph is not None
+
+    actor_bf16 = critic_bf16 = None
+    if args.policy_dtype == "fp32":
+        import copy
+        actor_bf16, critic_bf16 = copy.deepcopy(actor).to(torch.bfloat16), copy.deepcopy(critic).to(torch.bfloat16)
+        bf_elapsed, bf_K, _, _ = measure_rollout(torch.bfloat16, min(args.steps, 128), 16)     # informational series
+    elapsed, K, W, graphed = measure_rollout(pdtype, args.steps, args.warmup)
+    graph = graphed or None
+    tmax = torch.tensor([elapsed, sim_wall, kernel_ms, bf_elapsed if actor_bf16 is not None else 0.0], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed, sim_wall, kernel_ms = [float(x) for x in tmax.tolist()]
+    elapsed, sim_wall, kernel_ms, bf_elapsed = [float(x) for x in tmax.tolist()]
     finite = bool(torch.isfinite(obs_clipped).all().item()) and bool(torch.isfinite(rew).all().item())
     resets_seen = int(eng.tensor("reset_count").sum().item())
 
@@ -240,7 +250,7 @@ def main():
             "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
                                    "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "hipgraph": graph is not None, "finite": finite, "resets_total": resets_seen},
+                       "hipgraph": bool(graph), "finite": finite, "resets_total": resets_seen},
             "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
                          "note": "engine step with pre-drawn actions (ring of 16)", "hipgraph": sim_graph is not None},
             "roofline": {"bound": "hbm", "kernel": "mms::ant_step_kernel<TEN_ANT,64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -249,6 +259,9 @@ def main():
                          "bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "launch_ms": kernel_ms},
             "cpu_baseline": cpu,
         }
+        if actor_bf16 is not None:
+            line["rollout_bf16_policy"] = {"value": world * N * bf_K / bf_elapsed, "unit": "env-steps/s", "steps": bf_K,
+                                           "note": "same rollout with the policy MLPs in bf16 (fp32 accumulate); informational, not the headline"}
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
