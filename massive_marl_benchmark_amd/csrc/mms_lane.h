@@ -411,12 +411,11 @@ struct LegKin {
     V3 J1, J2, tip, ul, uf;
     S6 s1, s2, vl, vf, c1, c2;
 };
-MMS_HD LegKin leg_kinematics(const mms_model* M, const LegConst& L, const AntLane& S, const M3& Rt) {
+// sc = (sin q1, cos q1, sin q2, cos q2)
+MMS_HD LegKin leg_kinematics(const mms_model* M, const LegConst& L, const AntLane& S, const M3& Rt, const float sc[4]) {
     LegKin K;
     S6 v0 = S6{S.ang, S.vel};
-    float s1q, c1q, s2q, c2q;
-    sincos_joint(S.q[0], s1q, c1q);
-    sincos_joint(S.q[1], s2q, c2q);
+    const float s1q = sc[0], c1q = sc[1], s2q = sc[2], c2q = sc[3];
     // R_leg = R_t Rz(q1), R_foot = R_leg Rot(ankle_axis, q2); only the vectors that are needed
     V3 a1 = Rt.c2;
     K.J1 = mul(Rt, L.hip_pos);
@@ -437,10 +436,11 @@ MMS_HD LegKin leg_kinematics(const mms_model* M, const LegConst& L, const AntLan
     return K;
 }
 
-// What a leg lane keeps between the inward and the outward pass: 16 values + the broad-phase flag
+// What a leg lane keeps between the inward and the outward pass: 20 values + the broad-phase flag
 struct LegPass {
     S6 U1, U2;
     float D1, D2, u1, u2;
+    float sc[4];          // sin / cos of the two joint angles (the rest of the kinematics is evaluated again)
     bool near_box;
 };
 // extra state for the foot force sensors (OneAnt only)
@@ -476,7 +476,9 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
     M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
     V3 Ow = S.pos;
     S6 v0 = S6{S.ang, S.vel};
-    LegKin K = leg_kinematics(M, L, S, Rt);
+    sincos_joint(S.q[0], P.sc[0], P.sc[1]);
+    sincos_joint(S.q[1], P.sc[2], P.sc[3]);
+    LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
     P.near_box = has_box && ant_near_box(Ow, box, ant_reach(M, L));
     // ---- foot body: inertia, bias force, tip contacts, joint 2 -------------------------------------------------
     Sym6 IAf;
@@ -574,7 +576,7 @@ MMS_HD void leg_outward(const mms_model* M, const LegConst& L, float h, AntLane&
     MMS_REG_FENCE(S.q[0]); MMS_REG_FENCE(S.q[1]); MMS_REG_FENCE(S.qd[0]); MMS_REG_FENCE(S.qd[1]);
     MMS_MEM_FENCE();
     M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
-    LegKin K = leg_kinematics(M, L, S, Rt);
+    LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
     V3 Ow = S.pos;
     S6 al = a0 + K.c1;
     float qdd1 = (P.u1 - dot(P.U1, al)) / P.D1;

@@ -7,10 +7,10 @@
 // emulation test); this file holds only what needs the GPU: the lane -> work mapping, DPP / LDS
 // reductions, and the HBM traffic.
 //
-// Mapping.  One workgroup = one environment.  For the ant tasks:
-//   lanes 0 .. 4A-1      : (ant a = tid >> 2, leg l = tid & 3); the quad shares the torso state
-//   lanes B .. B+7       : the 8 box corners (B = 4A rounded up to a multiple of 8)
-// TenAnt at A = 10 is one wave64 per env (48 live lanes); 4096 envs = 4096 waves = 4 per SIMD.
+// Mapping.  A workgroup holds EPB environments.  For the ant tasks the ant lanes come first,
+//   (env e, ant a, leg l) = e * 4A + 4a + l; the quad of an ant shares the torso state,
+// followed (8-aligned) by the box-corner lanes, 8 per env.  TenAnt at A = 10 packs 4 envs into 192 threads: 160 ant lanes
+// and 32 box lanes; 4096 envs = 1024 blocks = 3072 waves = 3 per SIMD, all resident at once.
 // HBM traffic per env-step is the env's own contiguous blocks: root_states 572 B, dof_state 640 B,
 // actions 320 B, caches 168 B in; the same state plus the 1552 B observation row(s) out.
 #include <hip/hip_runtime.h>
@@ -71,46 +71,25 @@ __device__ __forceinline__ void store_rigid(float* r, const RigidState& B) {
     r[10] = B.ang.x; r[11] = B.ang.y; r[12] = B.ang.z;
 }
 
-// write the staged observation row: raw, clamped, and the optional bound rollout slot
-__device__ __forceinline__ void write_obs_row(const float* s_obs, int obs_dim, float clip, float* obs, float* obs_clip,
-                                              float* obs_out, int tid, int nthreads) {
-    if ((obs_dim & 3) == 0) {
-        const float4* s4 = reinterpret_cast<const float4*>(s_obs);
-        for (int i = tid; i < (obs_dim >> 2); i += nthreads) {
-            float4 v = s4[i];
-            reinterpret_cast<float4*>(obs)[i] = v;
-            float4 c = make_float4(clampf(v.x, -clip, clip), clampf(v.y, -clip, clip), clampf(v.z, -clip, clip), clampf(v.w, -clip, clip));
-            reinterpret_cast<float4*>(obs_clip)[i] = c;
-            if (obs_out) reinterpret_cast<float4*>(obs_out)[i] = c;
-        }
-    } else {
-        for (int i = tid; i < obs_dim; i += nthreads) {
-            float v = s_obs[i];
-            obs[i] = v;
-            float c = clampf(v, -clip, clip);
-            obs_clip[i] = c;
-            if (obs_out) obs_out[i] = c;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // ant tasks.  TASK: MMS_TASK_TEN_ANT or MMS_TASK_ONE_ANT.
-// BLOCK threads hold EPB environments of LPE = BLOCK / EPB lanes each (LPE >= 4A rounded up to 8, plus 8):
-//   <64, 1>   one env per wave (any A <= 14)
-//   <192, 4>  TenAnt, A = 10: LPE = 48 = 40 leg lanes + 8 box-corner lanes -> all 64 lanes of the three waves are live
-//   <64, 4>   OneAnt: LPE = 16, four envs per wave
-//   <512, 1>  up to 126 ants per env (the 100-agent swarm), LDS reductions across the eight waves
-// Quads (one ant) and 8-lane box groups never straddle a wave; an env may, so everything that crosses lanes of an env
-// other than quad / 8-lane DPP goes through LDS and __syncthreads.
-// dynamic LDS: LegConst[4], then per env: [obs_dim rounded to 4] obs row, [16] box state, BoxPose, [RP_STRIDE*A] reward
-// partials, [6*A] per-ant box reactions, [8] reaction total.
+// A block of BLOCK threads holds EPB environments.  Thread layout: the ant lanes of all EPB envs first (4A per env,
+// lane = (ant, leg), a quad per ant), then -- 8-aligned -- the box-corner lanes (8 per env):
+//   <64, 1>    one env per wave (any A <= 14)
+//   <192, 4>   TenAnt, A = 10: 160 ant lanes (two full waves + half of the third) + 32 box lanes: all 64 lanes of the three
+//              waves are live, and the box phase and the reward finish issue on one wave in three instead of on every wave.
+//              (<384, 8> -- five full ant waves + one box wave -- measured 42.6 us against 30.5 us: the six-wave blocks do not
+//              all become resident at three waves per SIMD; profiles/r01_v6_layout_ab.txt)
+//   <64, 4>    OneAnt: 16 ant lanes + 32 box lanes in one wave
+//   <512, 1>   up to 126 ants per env (the 100-agent swarm)
+// Quads (one ant) and 8-lane box groups never straddle a wave; everything else that crosses lanes goes through LDS and
+// __syncthreads.  dynamic LDS: LegConst[4], then per env the block described by ant_env_lds_floats().
 // ---------------------------------------------------------------------------------------------
 #ifndef MMS_WAVES_PER_EU
 #define MMS_WAVES_PER_EU 2      // one-wave envs: 2 waves per SIMD; 3 and 4 need spills and measured slower (profiles/r01_v3_bench_wpe*.json)
 #endif
 __host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
-    return (size_t)((obs_dim + 3) & ~3) + 16 + (sizeof(BoxPose) + 15) / 16 * 4 + 8 + (size_t)(((RP_STRIDE + 6) * A + 3) & ~3) +
+    return (size_t)((obs_dim + 3) & ~3) + 16 + (sizeof(BoxPose) + 15) / 16 * 4 + 8 + 8 + (size_t)(((RP_STRIDE + 6) * A + 3) & ~3) +
            (size_t)((4 * A + 2 + 7 + 3) & ~3);     // + staging of the epilogue's inputs (prev_dim <= 4A+2, origin, progress, reset count)
 }
 // Residency target: TenAnt at 4096 envs is 1024 blocks x 3 waves = 3072 waves = exactly 3 per SIMD on 256 CUs, so the whole
@@ -122,19 +101,22 @@ __host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
 template <int TASK, int BLOCK, int EPB, int AT>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK == 192 ? MMS_WAVES_PER_EU_PACKED : 1)) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int LPE = BLOCK / EPB;
     const mms_config* __restrict__ C = a.cfg;
     const mms_model* __restrict__ M = &C->model;
-    const int e_loc = threadIdx.x / LPE;
-    const int tid = threadIdx.x - e_loc * LPE;               // lane within the env
+    const int A = AT > 0 ? AT : a.num_agents;
+    const int LA = 4 * A;                                     // ant lanes per env
+    const int ant_region = EPB * LA;
+    const int box_region = (ant_region + 7) & ~7;
+    const int bt = (int)threadIdx.x - box_region;             // index among the box lanes
+    const bool is_ant = (int)threadIdx.x < ant_region;
+    const bool is_box = bt >= 0 && bt < 8 * EPB;
+    const int e_loc = EPB == 1 ? 0 : (is_ant ? (int)threadIdx.x / LA : (is_box ? bt >> 3 : 0));
+    const int tid = is_ant ? (int)threadIdx.x - e_loc * LA : 0;   // ant lane within its env
+    const int corner = bt & 7;
+    const bool box_lead = is_box && corner == 0;
     const int env_raw = blockIdx.x * EPB + e_loc;
     const bool live = env_raw < a.num_envs;                  // a partial last block still runs every barrier
     const int env = live ? env_raw : a.num_envs - 1;
-    const int A = AT > 0 ? AT : a.num_agents;
-    const int n_ant_lanes = 4 * A;
-    const int box_base = (n_ant_lanes + 7) & ~7;
-    const bool is_ant = tid < n_ant_lanes;
-    const bool is_box = tid >= box_base && tid < box_base + 8;
     const int ant = tid >> 2, leg = tid & 3;
     const int obs_dim = AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim;
     const int prev_dim = AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 4 * AT + 2 : 6) : a.prev_dim;
@@ -144,16 +126,18 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     // costs ~55 VGPRs per lane for values that are wave-uniform or 4-periodic
     LegConst* s_leg = reinterpret_cast<LegConst*>(lds);                            // [4], shared by the block
     // per-env LDS block: the fixed-size parts first, at compile-time offsets from one lane-varying base
-    constexpr int kBoxOff = 0, kBpOff = 16, kWtotOff = kBpOff + (int)((sizeof(BoxPose) + 15) / 16 * 4), kRedOff = kWtotOff + 8;
-    float* env_lds = lds + (4 * sizeof(LegConst) + 15) / 16 * 4 + (size_t)e_loc * ((ant_env_lds_floats(obs_dim, A) + 3) & ~(size_t)3);
+    constexpr int kBoxOff = 0, kBpOff = 16, kWtotOff = kBpOff + (int)((sizeof(BoxPose) + 15) / 16 * 4), kEpiOff = kWtotOff + 8, kRedOff = kEpiOff + 8;
+    const size_t env_stride = (ant_env_lds_floats(obs_dim, A) + 3) & ~(size_t)3;
+    float* lds_envs = lds + (4 * sizeof(LegConst) + 15) / 16 * 4;
+    float* env_lds = lds_envs + (size_t)e_loc * env_stride;
     float* s_box = env_lds + kBoxOff;              // [16] box rigid state (home of the box between phases)
     BoxPose* s_bp = reinterpret_cast<BoxPose*>(env_lds + kBpOff);
-    float* s_wtot = env_lds + kWtotOff;            // [8] total reaction of the ants on the box
+    float* s_epi = env_lds + kEpiOff;              // [8] box values the ant lanes need in the epilogue: global x, y, sin, -cos of the yaw
     float* s_red = env_lds + kRedOff;              // [A][RP_STRIDE] reward partials
     float* s_wr = s_red + RP_STRIDE * A;           // [6][A] per-ant reactions on the box
     float* s_obs = env_lds + ((kRedOff + (RP_STRIDE + 6) * A + 3) & ~3);   // [obs_pad] observation row (16-B aligned)
-    // The epilogue's inputs (caches, env origin, progress, reset count) are fetched together with the state and parked in
-    // the observation row's LDS space (free until the epilogue) so that the kernel pays ONE HBM round trip at the top.
+    // The epilogue's inputs (caches, env origin, progress, reset count) are fetched together with the state and parked
+    // behind the observation row so that the kernel pays ONE HBM round trip at the top.
     float* s_stage = s_obs + obs_pad;              // [prev_dim][3 origin][2 progress][2 reset_count]
     // The clamped actions go straight into their slots of the observation row (ten_ant.py:1346, one_ant.py:615) and are
     // read back from there by the substeps: no registers held across the physics loop for them.
@@ -166,14 +150,18 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     // (per-env addresses are lane-varying in the packed layouts: they are formed where they are used, not kept alive
     // across the physics loop -- see the fence before the epilogue)
     if (threadIdx.x < 4) s_leg[threadIdx.x] = load_leg_const(M, threadIdx.x);
-    if (tid == box_base) {
+    if (box_lead) {
         RigidState B0 = load_rigid(a.root_states + ((size_t)env * actors + A) * 13);
         store_rigid(s_box, B0);
         s_bp->pos = B0.pos; s_bp->R = quat_to_mat(B0.qx, B0.qy, B0.qz, B0.qw); s_bp->v = B0.vel; s_bp->w = B0.ang;
         s_bp->half = V3{M->box_half[0], M->box_half[1], M->box_half[2]};
     }
-    for (int i = tid; i < prev_dim; i += LPE) s_stage[i] = a.prev[(size_t)env * prev_dim + i];
-    if (tid == box_base + 1) {
+    for (int i = threadIdx.x; i < EPB * prev_dim; i += BLOCK) {       // the caches of the block's envs are contiguous in HBM
+        const int e = i / prev_dim, k = i - e * prev_dim;
+        const int en = min((int)(blockIdx.x * EPB + e), a.num_envs - 1);
+        (lds_envs + (size_t)e * env_stride + (s_stage - env_lds))[k] = a.prev[(size_t)en * prev_dim + k];
+    }
+    if (is_box && corner == 1) {
         s_stage[prev_dim + 0] = a.env_origin[3 * env]; s_stage[prev_dim + 1] = a.env_origin[3 * env + 1];
         s_stage[prev_dim + 2] = a.env_origin[3 * env + 2];
         int64_t pr = a.progress[env], rc = a.reset_count[env];
@@ -203,12 +191,14 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     }
 
     // ---- physics: skipped per env for envs flagged for reset (their state is overwritten below) ---------------
-    // (the loop itself is block-uniform so that every lane reaches every barrier)
     const bool simulate = a.do_physics && !reset_now;
     if (a.do_physics) {
         const float h = C->dt / (float)C->substeps;
-        for (int s = 0; s < C->substeps; s++) {
-            constexpr bool kSensors = (TASK == MMS_TASK_ONE_ANT);
+        constexpr bool kSensors = (TASK == MMS_TASK_ONE_ANT);
+        constexpr bool kOneWave = (BLOCK == 64 && EPB == 1);
+        // inward pass, quad reduction, root solve, outward pass; returns this lane's reaction on the box
+        auto ant_phase = [&]() -> S6 {
+            S6 wr = S6{V3{0, 0, 0}, V3{0, 0, 0}};
             Sym6 IA0;
             S6 pA0;
             LegPass P;
@@ -219,39 +209,52 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
                 leg_inward<kSensors>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0);
             } else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
             quad_sum(IA0, pA0);
-            S6 wr = S6{V3{0, 0, 0}, V3{0, 0, 0}};
             if (is_ant && simulate) leg_outward<kSensors>(M, L, h, S, leg, *s_bp, P, &SP, IA0, pA0, wr, sens);
-            S6 w;
-            if (BLOCK == 64 && EPB == 1) {                               // one wave per env: the reaction wrench by DPP / permute
-                w = S6{V3{wave_sum(wr.a.x), wave_sum(wr.a.y), wave_sum(wr.a.z)}, V3{wave_sum(wr.l.x), wave_sum(wr.l.y), wave_sum(wr.l.z)}};
-            } else {                                                     // envs straddle waves: per-ant sums (DPP), then LDS
-                wr.a.x = quad_sum(wr.a.x); wr.a.y = quad_sum(wr.a.y); wr.a.z = quad_sum(wr.a.z);
-                wr.l.x = quad_sum(wr.l.x); wr.l.y = quad_sum(wr.l.y); wr.l.z = quad_sum(wr.l.z);
-                if (is_ant && leg == 0) {
-                    s_wr[0 * A + ant] = wr.a.x; s_wr[1 * A + ant] = wr.a.y; s_wr[2 * A + ant] = wr.a.z;
-                    s_wr[3 * A + ant] = wr.l.x; s_wr[4 * A + ant] = wr.l.y; s_wr[5 * A + ant] = wr.l.z;
-                }
-                __syncthreads();
-                float t = 0.f;
-                if (is_box && tid - box_base < 6) {                      // column c summed in ant order by box lane c
-                    const float* col = s_wr + (tid - box_base) * A;
-                    for (int i = 0; i < A; i++) t += col[i];
-                }
-                // the eight box lanes of an env sit in one wave, 8-aligned: lane c hands its column to all of them
-                const int g0 = (int)(threadIdx.x & 63u) & ~7;
-                w = S6{V3{__shfl(t, g0 + 0, 64), __shfl(t, g0 + 1, 64), __shfl(t, g0 + 2, 64)},
-                       V3{__shfl(t, g0 + 3, 64), __shfl(t, g0 + 4, 64), __shfl(t, g0 + 5, 64)}};
+            return wr;
+        };
+        // envs straddle waves: per-ant sums of the reactions (DPP) into LDS
+        auto stage_wrench = [&](S6 wr) {
+            wr.a.x = quad_sum(wr.a.x); wr.a.y = quad_sum(wr.a.y); wr.a.z = quad_sum(wr.a.z);
+            wr.l.x = quad_sum(wr.l.x); wr.l.y = quad_sum(wr.l.y); wr.l.z = quad_sum(wr.l.z);
+            if (is_ant && leg == 0) {
+                s_wr[0 * A + ant] = wr.a.x; s_wr[1 * A + ant] = wr.a.y; s_wr[2 * A + ant] = wr.a.z;
+                s_wr[3 * A + ant] = wr.l.x; s_wr[4 * A + ant] = wr.l.y; s_wr[5 * A + ant] = wr.l.z;
             }
-            if (is_box) {
+        };
+        // total reaction on the box: column c of the staged per-ant sums is added up in ant order by box lane c; the eight
+        // box lanes of an env sit in one wave, 8-aligned, and lane c hands its column to all of them
+        auto gather_wrench = [&]() -> S6 {
+            float t = 0.f;
+            if (corner < 6) {
+                const float* col = s_wr + corner * A;
+                for (int i = 0; i < A; i++) t += col[i];
+            }
+            const int g0 = (int)(threadIdx.x & 63u) & ~7;
+            return S6{V3{__shfl(t, g0 + 0, 64), __shfl(t, g0 + 1, 64), __shfl(t, g0 + 2, 64)},
+                      V3{__shfl(t, g0 + 3, 64), __shfl(t, g0 + 4, 64), __shfl(t, g0 + 5, 64)}};
+        };
+        auto box_store = [&](const RigidState& B) {
+            store_rigid(s_box, B);
+            s_bp->pos = B.pos; s_bp->R = quat_to_mat(B.qx, B.qy, B.qz, B.qw); s_bp->v = B.vel; s_bp->w = B.ang;
+        };
+        // (the loop itself is block-uniform so that every lane reaches every barrier)
+        for (int s = 0; s < C->substeps; s++) {
+            S6 wr = ant_phase();
+            S6 w = S6{V3{0, 0, 0}, V3{0, 0, 0}};
+            if (kOneWave) {                                          // one wave per env: the reaction wrench by DPP / permute
+                w = S6{V3{wave_sum(wr.a.x), wave_sum(wr.a.y), wave_sum(wr.a.z)}, V3{wave_sum(wr.l.x), wave_sum(wr.l.y), wave_sum(wr.l.z)}};
+            } else {
+                stage_wrench(wr);
+                __syncthreads();
+            }
+            if (is_box) {                                            // waves without box lanes skip the whole box phase
+                if (!kOneWave) w = gather_wrench();
                 RigidState B = load_rigid(s_box);
                 M3 R = s_bp->R;
-                BoxCorner bc = box_corner(M, h, B, R, tid - box_base);
+                BoxCorner bc = box_corner(M, h, B, R, corner);
                 oct_sum(bc);
                 if (simulate) box_finish(M, h, B, R, bc, w);
-                if (tid == box_base) {
-                    store_rigid(s_box, B);
-                    s_bp->pos = B.pos; s_bp->R = quat_to_mat(B.qx, B.qy, B.qz, B.qw); s_bp->v = B.vel; s_bp->w = B.ang;
-                }
+                if (corner == 0) box_store(B);
             }
             __syncthreads();
         }
@@ -267,18 +270,11 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     const V3 origin = V3{s_stage[prev_dim + 0], s_stage[prev_dim + 1], s_stage[prev_dim + 2]};
     const unsigned* si = reinterpret_cast<const unsigned*>(s_stage + prev_dim + 3);
     int64_t progress = (int64_t)(((uint64_t)si[1] << 32) | si[0]);
-    const int64_t reset_count = (int64_t)(((uint64_t)si[3] << 32) | si[2]);   // bumped by lane 0 after the last barrier
+    const int64_t reset_count = (int64_t)(((uint64_t)si[3] << 32) | si[2]);   // bumped by the box lead after the last barrier
     const uint64_t env_global = (uint64_t)(C->env_offset + env_e);
-    const int64_t reset_flag = reset_now ? 1 : 0;
     progress += 1;
-    RigidState B;
-    if (reset_flag != 0) {
-        if (is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env_e, env_global, (uint64_t)reset_count);
-        B = load_rigid(init_env + 13 * A);
-        progress = 0;
-    } else {
-        B = load_rigid(s_box);
-    }
+    if (reset_now) progress = 0;
+    if (reset_now && is_ant) ant_reset_lane(C, L, S, init_env + 13 * ant, leg, a.reset_noise + 16 * (size_t)env_e, env_global, (uint64_t)reset_count);
     // ---- write the state back ---------------------------------------------------------------
     if (is_ant && live) {
         reinterpret_cast<float4*>(dof_env)[tid] = make_float4(S.q[0], S.qd[0], S.q[1], S.qd[1]);
@@ -288,20 +284,31 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             r[7] = S.vel.x; r[8] = S.vel.y; r[9] = S.vel.z; r[10] = S.ang.x; r[11] = S.ang.y; r[12] = S.ang.z;
         }
     }
-    if (tid == box_base && live) store_rigid(root_env + 13 * A, B);
+    // The box lead owns the box in the epilogue: state write-back, its observation entries, and the values the ant lanes
+    // need (global position, yaw direction), handed over through LDS.
+    RigidState B = {};
+    if (box_lead) {
+        B = reset_now ? load_rigid(init_env + 13 * A) : load_rigid(s_box);
+        if (live) store_rigid(root_env + 13 * A, B);
+        const float bgx = B.pos.x + origin.x, bgy = B.pos.y + origin.y;      // global frame
+        s_epi[0] = bgx; s_epi[1] = bgy;
+        if (TASK == MMS_TASK_TEN_ANT) {
+            const float ang = box_angle(B.qz, B.qw);
+            s_epi[2] = sinf(ang); s_epi[3] = -cosf(ang);
+            float* t = s_obs + 38 * A;
+            t[0] = bgx; t[1] = bgy; t[2] = B.qx; t[3] = B.qy; t[4] = B.qz; t[5] = B.qw; t[6] = 0.f; t[7] = 0.f;
+        }
+    }
+    __syncthreads();
 
     // ---- observations + reward --------------------------------------------------------------
-    const float bgx = B.pos.x + origin.x, bgy = B.pos.y + origin.y;      // global frame
+    const float bgx = s_epi[0], bgy = s_epi[1];
     if (TASK == MMS_TASK_TEN_ANT) {
-        const float ang = box_angle(B.qz, B.qw);
-        const float sv = sinf(ang), cv = -cosf(ang);
-        // caches: previous step's values; mms_create fills them from the construction-time poses (ten_ant.py:870-882)
-        float pbx = 0.f, pby = 0.f, gbx = 0.f, gby = 0.f;
         if (is_ant) {
-            pbx = s_stage[2 * ant]; pby = s_stage[2 * ant + 1];
-            gbx = s_stage[2 * A + 2 * ant]; gby = s_stage[2 * A + 2 * ant + 1];
-        }
-        if (is_ant) {
+            const float sv = s_epi[2], cv = s_epi[3];
+            // caches: previous step's values; mms_create fills them from the construction-time poses (ten_ant.py:870-882)
+            const float pbx = s_stage[2 * ant], pby = s_stage[2 * ant + 1];
+            const float gbx = s_stage[2 * A + 2 * ant], gby = s_stage[2 * A + 2 * ant + 1];
             const float act0 = s_act[0], act1 = s_act[1];
             TenAntLaneOut o = tenant_obs_reward_lane(C, L, S, ant, leg, origin, act0, act1, bgx, bgy, sv, cv, pbx, pby, gbx, gby, s_obs);
             float ec = quad_sum(o.ec), lim = quad_sum(o.lim), ac = quad_sum(o.acost);
@@ -315,13 +322,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
                 prev_env[2 * A + 2 * ant] = o.gx; prev_env[2 * A + 2 * ant + 1] = o.gy;
             }
         }
-        if (tid == box_base) {
-            float* t = s_obs + 38 * A;
-            t[0] = bgx; t[1] = bgy; t[2] = B.qx; t[3] = B.qy; t[4] = B.qz; t[5] = B.qw; t[6] = 0.f; t[7] = 0.f;
-            if (live) { prev_env[4 * A] = bgx; prev_env[4 * A + 1] = bgy; }
-        }
         __syncthreads();
-        if (tid == 0 && live) {
+        if (box_lead && live) {
+            prev_env[4 * A] = bgx; prev_env[4 * A + 1] = bgy;
             float rew;
             int64_t rs;
             tenant_reward_finish(C, A, s_red, B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
@@ -329,9 +332,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             a.reset[env_e] = rs;
             a.progress[env_e] = progress;
         }
-    } else {  // OneAnt
-        const float pot_in = s_stage[4];
-        const float pbx = s_stage[0], pby = s_stage[1], bbx = s_stage[2], bby = s_stage[3];
+    } else {  // OneAnt: the four leg lanes stage their reward partials, the box lead finishes
         if (is_ant) {
             const float act0 = s_act[0], act1 = s_act[1];
             AntObsCore core;
@@ -343,27 +344,59 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
 #pragma unroll
                 for (int i = 0; i < 6; i++) fs[i] = sens[i];
             }
-            if (tid == 0 && live) {
-                float tbx = 0.f - bgx, tby = 0.f - bgy;
-                float pot = -sqrtf(tbx * tbx + tby * tby + 0.f * 0.f) / C->dt;          // one_ant.py:583-587
-                float rew;
-                int64_t rs;
-                oneant_reward(C, pg.z, core.up_proj, ec, lim, ac, pbx, pby, bbx, bby, pg.x, pg.y, bgx, bgy, B.qx, B.qy, B.qz, B.qw,
-                              progress, rew, rs);
-                a.rew[env_e] = rew;
-                a.reset[env_e] = rs;
-                a.progress[env_e] = progress;
-                prev_env[0] = pg.x; prev_env[1] = pg.y; prev_env[2] = bgx; prev_env[3] = bgy;   // one_ant.py:432-433
-                prev_env[4] = pot; prev_env[5] = pot_in;
+            if (leg == 0) {
+                float* r = s_red;
+                r[0] = pg.x; r[1] = pg.y; r[2] = pg.z; r[3] = core.up_proj; r[4] = ec; r[5] = lim; r[6] = ac;
             }
         }
         __syncthreads();
+        if (box_lead && live) {
+            const float pot_in = s_stage[4];
+            const float pbx = s_stage[0], pby = s_stage[1], bbx = s_stage[2], bby = s_stage[3];
+            const float* r = s_red;
+            float tbx = 0.f - bgx, tby = 0.f - bgy;
+            float pot = -sqrtf(tbx * tbx + tby * tby + 0.f * 0.f) / C->dt;          // one_ant.py:583-587
+            float rew;
+            int64_t rs;
+            oneant_reward(C, r[2], r[3], r[4], r[5], r[6], pbx, pby, bbx, bby, r[0], r[1], bgx, bgy, B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
+            a.rew[env_e] = rew;
+            a.reset[env_e] = rs;
+            a.progress[env_e] = progress;
+            prev_env[0] = r[0]; prev_env[1] = r[1]; prev_env[2] = bgx; prev_env[3] = bgy;   // one_ant.py:432-433
+            prev_env[4] = pot; prev_env[5] = pot_in;
+        }
     }
-    // ---- coalesced observation row(s) --------------------------------------------------------
-    if (reset_now && tid == 0 && live) a.reset_count[env_e] = reset_count + 1;   // every lane of the env read it before the barrier above
-    if (live)
-        write_obs_row(s_obs, obs_dim, C->clip_obs, a.obs + (size_t)env_e * obs_dim, a.obs_clipped + (size_t)env_e * obs_dim,
-                      a.obs_out ? a.obs_out + (size_t)env_e * obs_dim : nullptr, tid, LPE);
+    if (reset_now && box_lead && live) a.reset_count[env_e] = reset_count + 1;   // every lane of the env read it before the barriers above
+    // ---- coalesced observation row(s): the block's EPB rows are contiguous in HBM ---------------------------------
+    {
+        const int e0 = blockIdx.x * EPB;
+        const int n_live = min(EPB, a.num_envs - e0);
+        const float clip = C->clip_obs;
+        float* obs = a.obs + (size_t)e0 * obs_dim;
+        float* obs_clip = a.obs_clipped + (size_t)e0 * obs_dim;
+        float* obs_out = a.obs_out ? a.obs_out + (size_t)e0 * obs_dim : nullptr;
+        const float* rows = lds_envs + (s_obs - env_lds);
+        if ((obs_dim & 3) == 0) {
+            const int q = obs_dim >> 2;
+            for (int i = threadIdx.x; i < n_live * q; i += BLOCK) {
+                const int e = EPB == 1 ? 0 : i / q, k = i - e * q;
+                float4 v = reinterpret_cast<const float4*>(rows + (size_t)e * env_stride)[k];
+                reinterpret_cast<float4*>(obs)[i] = v;
+                float4 c = make_float4(clampf(v.x, -clip, clip), clampf(v.y, -clip, clip), clampf(v.z, -clip, clip), clampf(v.w, -clip, clip));
+                reinterpret_cast<float4*>(obs_clip)[i] = c;
+                if (obs_out) reinterpret_cast<float4*>(obs_out)[i] = c;
+            }
+        } else {
+            for (int i = threadIdx.x; i < n_live * obs_dim; i += BLOCK) {
+                const int e = EPB == 1 ? 0 : i / obs_dim, k = i - e * obs_dim;
+                float v = rows[(size_t)e * env_stride + k];
+                obs[i] = v;
+                float c = clampf(v, -clip, clip);
+                obs_clip[i] = c;
+                if (obs_out) obs_out[i] = c;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
