@@ -6,9 +6,10 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one PPO rollout step over this rank's 4096 envs: actor + critic inference (the reference's
-ActorCritic, agents/algorithms/rl/ppo/module.py: two MLPs [1024,1024,512], ELU, fp32), Gaussian action
-sample + log-prob, the fused VecTask step (mms_step: physics substeps + reset + obs + reward in one HIP
-launch), RolloutStorage.add_transitions, and every nsteps=8 steps the GAE scan + advantage normalisation
+ActorCritic, agents/algorithms/rl/ppo/module.py: two MLPs [1024,1024,512], ELU, fp32 -- rocBLAS / hipBLASLt GEMMs),
+Gaussian action sample + log-prob + the add_transitions stores (mms_ppo_act, one HIP launch), the fused VecTask
+step (mms_step: physics substeps + reset + obs + reward in one HIP launch, writing observation / reward / done
+straight into the rollout slots), and every nsteps=8 steps the GAE scan + advantage normalisation
 (the span timed as collection_time in agents/algorithms/rl/ppo/ppo.py:123-161 plus compute_returns).
 Envs are sharded over ranks with no data-path collective (weak scaling); `value` = all ranks' env-steps
 divided by the slowest rank's time.  Inputs are synthetic and resident in HBM before the timed region.
@@ -54,15 +55,8 @@ def shard_for_rank(rank, world, envs_per_gpu):
     return rank * envs_per_gpu, world * envs_per_gpu
 
 
-def build_policy(torch, obs_dim, act_dim, device, dtype):
-    nn = torch.nn
-
-    def mlp(out):
-        return nn.Sequential(nn.Linear(obs_dim, 1024), nn.ELU(), nn.Linear(1024, 1024), nn.ELU(), nn.Linear(1024, 512), nn.ELU(),
-                             nn.Linear(512, out))
-    actor, critic = mlp(act_dim).to(device=device, dtype=dtype), mlp(1).to(device=device, dtype=dtype)
-    log_std = torch.full((act_dim,), float(torch.log(torch.tensor(0.8))), device=device)      # init_noise_std 0.8
-    return actor, critic, log_std
+POLICY_CFG = {"pi_hid_sizes": [1024, 1024, 512], "vf_hid_sizes": [1024, 1024, 512], "activation": "elu"}   # cfg/ppo/config.yaml:6-9
+INIT_NOISE_STD = 0.8                                                                                        # cfg/ppo/config.yaml:33
 
 
 def main():
@@ -73,6 +67,7 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--policy-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--unfused", action="store_true", help="A/B: torch sampling + add_transitions copies instead of mms_ppo_act and bound rollout slots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for the CPU baseline (0 = sized for ~15 s)")
     args = ap.parse_args()
@@ -105,13 +100,12 @@ def main():
     obs_dim, act_dim = eng.obs_dim, eng.num_actions
     pdtype = torch.float32 if args.policy_dtype == "fp32" else torch.bfloat16
     torch.manual_seed(1234 + rank)
-    actor, critic, log_std = build_policy(torch, obs_dim, act_dim, device, pdtype)
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
+    ac = ActorCritic((obs_dim,), (0,), (act_dim,), INIT_NOISE_STD, POLICY_CFG, seed=1234, row_offset=env_offset).to(device)
     storage = RolloutStorage(N, NSTEPS, (obs_dim,), (0,), (act_dim,), device=str(device))
     states = torch.zeros(N, 0, device=device)
     actions_buf, rew, reset = eng.tensor("actions"), eng.tensor("rew"), eng.tensor("reset")
     obs_clipped = eng.tensor("obs_clipped")
-    std = log_std.exp()
-    sigma = std.repeat(N, 1)
     half_log_2pi = 0.9189385332046727
 
     def barrier():
@@ -163,27 +157,54 @@ def main():
 
     # ---- PPO rollout series -----------------------------------------------------------------------------------
     def measure_rollout(pdtype, K_req, W_req):
-        actor_, critic_ = (actor, critic) if pdtype == torch.float32 else (actor_bf16, critic_bf16)
+        ac_ = ac if pdtype == torch.float32 else ac_bf16
+        ac_.bind_rollout(None if args.unfused else storage, None if args.unfused else actions_buf)
 
-        def rollout_step():
+        def rollout_step_fused():
+            # Zero-copy rollout: the engine writes observation t+1, reward t and done t into the storage slots, mms_ppo_act
+            # writes the action into the engine and action / log-prob / value / mu / sigma into slot t; add_transitions
+            # recognises the slots by address and has nothing left to copy.
+            t = storage.step
+            obs_t = storage.observations[t]
+            if t == 0:
+                obs_t.copy_(obs_clipped)                                     # the first slot of a rollout: the current observation
+            act, logp, value, mu, sigma = ac_.act(obs_t, states)             # module.py:73-87
+            eng.bind_obs_out(storage.observations[t + 1] if t + 1 < NSTEPS else None)
+            eng.bind_rollout_out(storage.rewards[t].view(-1), storage.dones[t].view(-1))
+            eng.step()
+            storage.add_transitions(obs_t, states, act, storage.rewards[t], storage.dones[t], value, logp, mu, sigma)
+            if storage.step == NSTEPS:
+                with torch.no_grad():
+                    last_values = ac_.critic(obs_clipped.to(pdtype)).float()
+                storage.compute_returns(last_values, GAMMA, LAM)
+                storage.clear()
+
+        def rollout_step_unfused():
             t = storage.step
             cur_obs = obs_clipped                                            # current observation (clamped +-5, vec_task.py:131)
             with torch.no_grad():
                 x = cur_obs.to(pdtype)
-                mean = actor_(x).float()                                     # module.py:73-87
-                value = critic_(x).float()
+                mean = ac_.actor(x).float()
+                value = ac_.critic(x).float()
+                log_std = ac_.log_std.detach().float()
+                std = log_std.exp()
                 noise = torch.randn_like(mean)
                 act = mean + std * noise
                 logp = (-0.5 * noise * noise - log_std - half_log_2pi).sum(-1)
             storage.observations[t].copy_(cur_obs)                           # the obs the action was computed from
             actions_buf.copy_(act)
             eng.step()
-            storage.add_transitions(storage.observations[t], states, act, rew, reset, value, logp, mean, sigma)
+            storage.add_transitions(storage.observations[t], states, act, rew, reset, value, logp, mean, std.repeat(N, 1))
             if storage.step == NSTEPS:
                 with torch.no_grad():
-                    last_values = critic_(obs_clipped.to(pdtype)).float()
+                    last_values = ac_.critic(obs_clipped.to(pdtype)).float()
                 storage.compute_returns(last_values, GAMMA, LAM)
                 storage.clear()
+
+        rollout_step = rollout_step_unfused if args.unfused else rollout_step_fused
+        eng.bind_obs_out(None)
+        eng.bind_rollout_out(None, None)
+        storage.clear()
 
         graph = None
         for _ in range(NSTEPS):                      # eager warm-up (allocator, rocBLAS handles)
@@ -218,14 +239,17 @@ def main():
         barrier()
         return time.perf_counter() - t0, K, W, graph is not None
 
-    actor_bf16 = critic_bf16 = None
+    ac_bf16 = None
+    bf_elapsed, bf_K = 0.0, 0
     if args.policy_dtype == "fp32":
         import copy
-        actor_bf16, critic_bf16 = copy.deepcopy(actor).to(torch.bfloat16), copy.deepcopy(critic).to(torch.bfloat16)
+        ac_bf16 = copy.deepcopy(ac).to(torch.bfloat16)
         bf_elapsed, bf_K, _, _ = measure_rollout(torch.bfloat16, min(args.steps, 128), 16)     # informational series
+    else:
+        ac_bf16 = ac.to(torch.bfloat16)
     elapsed, K, W, graphed = measure_rollout(pdtype, args.steps, args.warmup)
     graph = graphed or None
-    tmax = torch.tensor([elapsed, sim_wall, kernel_ms, bf_elapsed if actor_bf16 is not None else 0.0], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed, sim_wall, kernel_ms, bf_elapsed], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, sim_wall, kernel_ms, bf_elapsed = [float(x) for x in tmax.tolist()]
@@ -250,7 +274,7 @@ def main():
             "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
                                    "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "hipgraph": bool(graph), "finite": finite, "resets_total": resets_seen},
+                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "finite": finite, "resets_total": resets_seen},
             "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
                          "note": "engine step with pre-drawn actions (ring of 16)", "hipgraph": sim_graph is not None},
             "roofline": {"bound": "hbm", "kernel": "mms::ant_step_kernel<TEN_ANT,64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -259,7 +283,7 @@ def main():
                          "bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "launch_ms": kernel_ms},
             "cpu_baseline": cpu,
         }
-        if actor_bf16 is not None:
+        if bf_K:
             line["rollout_bf16_policy"] = {"value": world * N * bf_K / bf_elapsed, "unit": "env-steps/s", "steps": bf_K,
                                            "note": "same rollout with the policy MLPs in bf16 (fp32 accumulate); informational, not the headline"}
         print(json.dumps(line))

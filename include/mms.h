@@ -26,6 +26,8 @@
  *     (algorithms/marl/utils/separated_buffer.py:153-164)
  *   MultiVecTaskPython.step slicing (agent_base/multi_vec_task.py:       mms_marl_views
  *     105-142)
+ *   ActorCritic.act sampling tail + RolloutStorage.add_transitions       mms_ppo_act,
+ *     (algorithms/rl/ppo/module.py:73-87; storage.py:33-47)              mms_bind_rollout_out
  *
  * Ownership: the engine owns every buffer it reports through mms_get_tensor for the lifetime of the
  * handle; callers wrap them as NON-owning views and must keep the handle alive while any view exists.
@@ -144,6 +146,11 @@ int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_ho
  * [T,N,obs_dim]; NULL disables.  The pointer must stay valid until the next bind. */
 int mms_bind_obs_out(mms_handle h, void* dst);
 
+/* Optional extra destinations for the step's reward (f32 [N]) and done flag (u8 [N], = reset_buf after the step), e.g.
+ * RolloutStorage.rewards[t] / dones[t] (storage.py:40-41): add_transitions then has nothing left to copy for them.
+ * NULL disables either.  Pointers must stay valid until the next bind. */
+int mms_bind_rollout_out(mms_handle h, float* rew_out, uint8_t* done_out);
+
 /* MARL wrapper views (multi_vec_task.py:105-142): obs_all [N,A,per_agent+shared] from a clamped
  * observation buffer [N, A*per_agent+shared]. */
 int mms_marl_views(int device, const float* obs_clipped, float* obs_all, int64_t n, int32_t agents,
@@ -171,6 +178,19 @@ int mms_gae_marl(int device, const float* rewards, const float* value_preds, con
 int mms_gae_marl_agents(int device, const float* rewards, const float* value_preds, const float* masks,
                         float* returns, int32_t T, int64_t N, int32_t A, float gamma, float lam,
                         int32_t use_norm, const float* norm_mean, const float* norm_var, void* hip_stream);
+
+/* The tail of ActorCritic.act (algorithms/rl/ppo/module.py:73-87) fused with RolloutStorage.add_transitions
+ * (storage.py:33-47): Gaussian sample, log-probability and the stores of one rollout step in ONE launch
+ * (SURVEY.md section 8f item 4).  mean [N,A] and value [N] are the outputs of the actor / critic MLPs.
+ *   noise_ij ~ N(0,1): counter-based (seed, global row = row_offset + i, counters[i], j), Box-Muller; counters[i] += 1
+ *   scale_j  = exp(log_std_j)^2 when reference_scale != 0 -- module.py:76-77 hands diag(sigma^2) to scale_tril -- else exp(log_std_j)
+ *   action   = mean + scale * noise;   log_prob_i = sum_j (-0.5 noise_ij^2 - log(scale_j) - 0.5 log(2 pi))
+ * Destinations (any may be NULL): actions_out [N,A] (e.g. the engine's "actions" buffer), act_slot / mu_slot / sigma_slot
+ * [N,A], logp_slot / value_slot [N].  sigma_slot receives log_std broadcast, which is what module.py:87 returns as sigma.
+ * counters is a device array [N] of int64 so that a captured hipGraph draws fresh noise on every replay. */
+int mms_ppo_act(int device, const float* mean, const float* value, const float* log_std, uint64_t seed, int64_t* counters,
+                int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot, float* logp_slot,
+                float* value_slot, float* mu_slot, float* sigma_slot, int64_t N, int32_t A, void* hip_stream);
 
 const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
 int mms_abi_version(void);

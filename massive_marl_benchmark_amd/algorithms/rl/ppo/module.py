@@ -1,0 +1,117 @@
+"""ActorCritic (agents/algorithms/rl/ppo/module.py:9-109) with the sampling tail of `act` as one HIP kernel.
+
+Same constructor, attributes (`actor`, `critic`, `log_std`) and methods (`act`, `act_inference`, `evaluate`) as the
+reference, so PPO (agents/algorithms/rl/ppo/ppo.py) uses it unchanged.  The MLPs stay torch modules (rocBLAS / hipBLASLt
+GEMMs); what `act` does after them -- Gaussian sample, log-probability, and optionally the stores that
+`RolloutStorage.add_transitions` would make -- is `mms_ppo_act`.
+
+Reference semantics kept: `MultivariateNormal(mean, scale_tril=diag(exp(log_std) * exp(log_std)))` (module.py:76-77), i.e.
+the scale is sigma squared, and the "sigma" that `act` / `evaluate` return is `log_std.repeat(N, 1)` (:87, :109).  The
+noise stream is this build's counter-based generator (seed, global env row, per-row draw counter), not torch's Philox:
+sampled actions differ from the reference's draw for the same torch seed, their distribution and log-probabilities do not.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .... import _lib
+from ....engine import current_stream_ptr
+
+
+def get_activation(act_name):
+    table = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh,
+             "sigmoid": nn.Sigmoid}
+    if act_name not in table:
+        print("invalid activation function!")          # module.py:129-131 prints and returns None
+        return None
+    return table[act_name]()
+
+
+def _mlp(in_dim, hidden, out_dim, activation):
+    layers, d = [], in_dim
+    for h in hidden:
+        layers += [nn.Linear(d, h), activation]
+        d = h
+    layers.append(nn.Linear(d, out_dim))
+    return nn.Sequential(*layers)
+
+
+class ActorCritic(nn.Module):
+    def __init__(self, obs_shape, states_shape, actions_shape, initial_std, model_cfg, asymmetric=False, seed=0, row_offset=0):
+        super().__init__()
+        self.asymmetric = asymmetric
+        if model_cfg is None:
+            actor_hidden, critic_hidden, activation = [256, 256, 256], [256, 256, 256], get_activation("selu")
+        else:
+            actor_hidden, critic_hidden = model_cfg["pi_hid_sizes"], model_cfg["vf_hid_sizes"]
+            activation = get_activation(model_cfg["activation"])
+        self.actor = _mlp(obs_shape[0], actor_hidden, actions_shape[0], activation)
+        self.critic = _mlp(states_shape[0] if asymmetric else obs_shape[0], critic_hidden, 1, activation)
+        self.log_std = nn.Parameter(np.log(initial_std) * torch.ones(*actions_shape))
+        self.init_weights(self.actor, [np.sqrt(2)] * len(actor_hidden) + [0.01])       # module.py:58-63
+        self.init_weights(self.critic, [np.sqrt(2)] * len(critic_hidden) + [1.0])
+        self.seed, self.row_offset = int(seed), int(row_offset)     # noise stream key; row_offset = global index of env 0
+        self._counters = None
+        self._bound = None
+
+    @staticmethod
+    def init_weights(sequential, scales):
+        for idx, module in enumerate(m for m in sequential if isinstance(m, nn.Linear)):
+            torch.nn.init.orthogonal_(module.weight, gain=scales[idx])
+
+    def forward(self):
+        raise NotImplementedError
+
+    # -- fused sampling ----------------------------------------------------------------------
+    def bind_rollout(self, storage=None, actions_out=None):
+        """Optional zero-copy destinations: `storage` (a RolloutStorage: `act` then writes actions / log-prob / value /
+        mu / sigma into slot `storage.step` and returns views of those slots, which `add_transitions` recognises and does
+        not copy again) and `actions_out` (e.g. the engine's "actions" buffer)."""
+        self._bound = (storage, actions_out)
+
+    def _sample(self, mean, value):
+        N, A = mean.shape
+        dev = mean.device
+        if dev.type != "cuda":
+            raise _lib.MmsError("ActorCritic.act samples on the HIP device only (no CPU fallback)")
+        if self._counters is None or self._counters.numel() != N or self._counters.device != dev:
+            self._counters = torch.zeros(N, dtype=torch.int64, device=dev)
+        storage, actions_out = self._bound if self._bound is not None else (None, None)
+        if storage is not None:
+            s = storage.step
+            act, logp, val = storage.actions[s], storage.actions_log_prob[s], storage.values[s]
+            mu, sigma = storage.mu[s], storage.sigma[s]
+        else:
+            act, mu, sigma = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+            logp, val = torch.empty(N, 1, device=dev), torch.empty(N, 1, device=dev)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        mean, value = mean.contiguous().float(), value.contiguous().float()
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        log_std = self.log_std.detach().float().contiguous()
+        _lib.check(_lib.lib().mms_ppo_act(idx, p(mean), p(value), p(log_std), self.seed, p(self._counters),
+                                          self.row_offset, 1, p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A,
+                                          current_stream_ptr(dev)), None, "mms_ppo_act")
+        return act, logp.view(-1), val, mu, sigma
+
+    def act(self, observations, states):
+        with torch.no_grad():
+            dtype = self.log_std.dtype                              # a bf16 copy of the module takes fp32 observations
+            mean = self.actor(observations.to(dtype))
+            value = self.critic((states if self.asymmetric else observations).to(dtype))
+            return self._sample(mean, value)
+
+    def act_inference(self, observations):
+        return self.actor(observations)
+
+    def evaluate(self, observations, states, actions):
+        """module.py:93-109 without building the [A, A] covariance: the diagonal Gaussian in closed form (differentiable)."""
+        mean = self.actor(observations)
+        scale_log = 2.0 * self.log_std                               # log of the scale_tril diagonal, sigma^2
+        z = (actions - mean) * torch.exp(-scale_log)
+        log_prob = (-0.5 * z * z - scale_log - 0.5 * math.log(2.0 * math.pi)).sum(-1)
+        entropy = (0.5 + 0.5 * math.log(2.0 * math.pi) + scale_log).sum(-1).expand(mean.shape[0])
+        value = self.critic(states if self.asymmetric else observations)
+        return log_prob, entropy, value, mean, self.log_std.repeat(mean.shape[0], 1)

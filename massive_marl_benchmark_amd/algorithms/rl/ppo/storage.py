@@ -45,16 +45,20 @@ class RolloutStorage:
         if self.step >= self.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         s = self.step
-        if observations.data_ptr() != self.observations[s].data_ptr():      # already written in place by the engine?
-            self.observations[s].copy_(observations)
-        self.states[s].copy_(states)
-        self.actions[s].copy_(actions)
-        self.rewards[s].copy_(rewards.view(-1, 1))
-        self.dones[s].copy_(dones.view(-1, 1))
-        self.values[s].copy_(values)
-        self.actions_log_prob[s].copy_(actions_log_prob.view(-1, 1))
-        self.mu[s].copy_(mu)
-        self.sigma[s].copy_(sigma)
+        # rows that the engine (bind_obs_out / bind_rollout_out) or ActorCritic.act (bind_rollout) already wrote in place
+        # are recognised by their address and not copied again
+        def put(dst, src):
+            if src.data_ptr() != dst.data_ptr() or src.numel() == 0:
+                dst.copy_(src.view(dst.shape))
+        put(self.observations[s], observations)
+        put(self.states[s], states)
+        put(self.actions[s], actions)
+        put(self.rewards[s], rewards)
+        put(self.dones[s], dones)
+        put(self.values[s], values)
+        put(self.actions_log_prob[s], actions_log_prob)
+        put(self.mu[s], mu)
+        put(self.sigma[s], sigma)
         self.step += 1
 
     def clear(self):

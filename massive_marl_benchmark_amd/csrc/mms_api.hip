@@ -20,6 +20,7 @@ hipError_t launch_adv_normalize(float*, const double*, int64_t, hipStream_t);
 hipError_t launch_gae_marl(const float*, const float*, const float*, float*, int, int64_t, float, float, int, const float*, const float*, hipStream_t);
 hipError_t launch_marl_views(const float*, float*, int64_t, int, int, int, hipStream_t);
 hipError_t launch_gae_marl_agents(const float*, const float*, const float*, float*, int, int64_t, int, float, float, int, const float*, const float*, hipStream_t);
+hipError_t launch_ppo_act(const float*, const float*, const float*, uint64_t, int64_t*, int64_t, int, float*, float*, float*, float*, float*, float*, int64_t, int, hipStream_t);
 }  // namespace mms
 
 struct mms_buffer {
@@ -37,6 +38,8 @@ struct mms_engine {
     mms_config* d_cfg = nullptr;
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
     float* obs_out = nullptr;
+    float* rew_out = nullptr;
+    uint8_t* done_out = nullptr;
     int packing = 1;
     std::vector<mms_buffer> bufs;
     std::string err;
@@ -187,11 +190,11 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
 
 __attribute__((visibility("default"))) int mms_destroy(mms_handle h) {
     if (!h) return 0;
-    hipSetDevice(h->cfg.device);
-    hipDeviceSynchronize();
+    (void)hipSetDevice(h->cfg.device);                 // teardown: nothing useful to do with an error here
+    (void)hipDeviceSynchronize();
     for (auto& b : h->bufs)
-        if (b.ptr) hipFree(b.ptr);
-    if (h->d_cfg) hipFree(h->d_cfg);
+        if (b.ptr) (void)hipFree(b.ptr);
+    if (h->d_cfg) (void)hipFree(h->d_cfg);
     delete h;
     return 0;
 }
@@ -217,6 +220,8 @@ static int do_step(mms_handle h, void* stream, int physics) {
     a.obs = (float*)find(h, "obs")->ptr;
     a.obs_clipped = (float*)find(h, "obs_clipped")->ptr;
     a.obs_out = h->obs_out;
+    a.rew_out = h->rew_out;
+    a.done_out = h->done_out;
     a.rew = (float*)find(h, "rew")->ptr;
     a.reset = (int64_t*)find(h, "reset")->ptr;
     a.progress = (int64_t*)find(h, "progress")->ptr;
@@ -273,6 +278,13 @@ __attribute__((visibility("default"))) int mms_bind_obs_out(mms_handle h, void* 
     return 0;
 }
 
+__attribute__((visibility("default"))) int mms_bind_rollout_out(mms_handle h, float* rew_out, uint8_t* done_out) {
+    if (!h) return fail(nullptr, "mms_bind_rollout_out: null handle");
+    h->rew_out = rew_out;
+    h->done_out = done_out;
+    return 0;
+}
+
 static int dev_guard(int device) {
     if (device < 0) { g_create_error = "no CPU path: device must be a HIP ordinal"; return 1; }
     hipError_t e = hipSetDevice(device);
@@ -313,6 +325,17 @@ __attribute__((visibility("default"))) int mms_gae_marl_agents(int device, const
                                                                int32_t use_norm, const float* norm_mean, const float* norm_var, void* s) {
     if (dev_guard(device)) return 1;
     MMS_FREE(mms::launch_gae_marl_agents(rewards, value_preds, masks, returns, T, N, A, gamma, lam, use_norm, norm_mean, norm_var, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_ppo_act(int device, const float* mean, const float* value, const float* log_std, uint64_t seed,
+                                                       int64_t* counters, int64_t row_offset, int32_t reference_scale, float* actions_out,
+                                                       float* act_slot, float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot,
+                                                       int64_t N, int32_t A, void* s) {
+    if (dev_guard(device)) return 1;
+    if (!mean || !log_std || !counters || N < 0 || A <= 0 || A > 128) { g_create_error = "mms_ppo_act: bad arguments (A must be in 1..128)"; return 1; }
+    MMS_FREE(mms::launch_ppo_act(mean, value, log_std, seed, counters, row_offset, reference_scale, actions_out, act_slot, logp_slot, value_slot,
+                                 mu_slot, sigma_slot, N, A, (hipStream_t)s));
     return 0;
 }
 

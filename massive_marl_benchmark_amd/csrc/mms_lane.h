@@ -804,6 +804,13 @@ MMS_HD float rand_uniform(uint64_t seed, uint64_t env_global, uint64_t step, uin
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
+// standard normal by Box-Muller from two counter-based uniforms (oracle: mo_rand_normal); the first is moved off zero
+MMS_HD float rand_normal(uint64_t seed, uint64_t row, uint64_t counter, uint32_t k) {
+    float u1 = rand_uniform(seed, row, counter, 2u * k) + (0.5f / 16777216.0f);
+    float u2 = rand_uniform(seed, row, counter, 2u * k + 1u);
+    return sqrtf(-2.0f * logf(u1)) * cosf(kTwoPi * u2);
+}
+
 // ---------------------------------------------------------------------------------------------
 // epilogue of the ant tasks: reset, observation row, reward partials (per lane)
 // ---------------------------------------------------------------------------------------------

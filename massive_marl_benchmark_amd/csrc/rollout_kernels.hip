@@ -6,11 +6,15 @@
 //   gae_marl_kernel      SeparatedReplayBuffer.compute_returns, use_gae branch without proper time limits
 //                        (agents/algorithms/marl/utils/separated_buffer.py:153-164)
 //   marl_views_kernel    MultiVecTaskPython.step slicing  (agents/tasks/agent_base/multi_vec_task.py:105-142)
+//   ppo_act_kernel       the sampling tail of ActorCritic.act (agents/algorithms/rl/ppo/module.py:73-87) fused with the
+//                        stores of RolloutStorage.add_transitions (storage.py:33-47)
 //
 // All are HBM-bound streaming kernels: thread = env column, T serial steps, every load of a [T,N] plane is a
 // coalesced 256 B wave transaction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "mms_lane.h"
 
 namespace mms {
 
@@ -132,6 +136,43 @@ __global__ void __launch_bounds__(256) marl_views_kernel(const float* __restrict
     }
 }
 
+// One wave per row (env): lane j draws the noise of action j (and j + 64), the row's log-probability is a wave reduction.
+// The per-row draw counter lives in device memory so that a replayed hipGraph sees fresh noise; the store of c + 1 depends
+// on the load of c, which orders the two.
+__global__ void __launch_bounds__(256) ppo_act_kernel(const float* __restrict__ mean, const float* __restrict__ value,
+                                                      const float* __restrict__ log_std, uint64_t seed, int64_t* __restrict__ counters,
+                                                      int64_t row_offset, int ref_scale, float* __restrict__ actions_out,
+                                                      float* __restrict__ act_slot, float* __restrict__ logp_slot,
+                                                      float* __restrict__ value_slot, float* __restrict__ mu_slot,
+                                                      float* __restrict__ sigma_slot, int64_t N, int A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int64_t c = counters[row];
+    float lp = 0.f;
+    for (int j = lane; j < A; j += 64) {
+        const float ls = log_std[j];
+        float scale, lscale;
+        if (ref_scale) { float sd = expf(ls); scale = sd * sd; lscale = logf(scale); }   // module.py:76: diag(exp * exp) as scale_tril
+        else { scale = expf(ls); lscale = ls; }
+        const float z = rand_normal(seed, (uint64_t)(row_offset + row), (uint64_t)c, (uint32_t)j);
+        const float m = mean[row * A + j];
+        const float act = m + scale * z;
+        lp += -0.5f * z * z - lscale - 0.9189385332046727f;
+        if (actions_out) actions_out[row * A + j] = act;
+        if (act_slot) act_slot[row * A + j] = act;
+        if (mu_slot) mu_slot[row * A + j] = m;
+        if (sigma_slot) sigma_slot[row * A + j] = ls;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) lp += __shfl_xor(lp, m, 64);
+    if (lane == 0) {
+        if (logp_slot) logp_slot[row] = lp;
+        if (value_slot && value) value_slot[row] = value[row];
+        counters[row] = c + 1;
+    }
+}
+
 static int grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -156,6 +197,14 @@ hipError_t launch_gae_marl(const float* rewards, const float* value_preds, const
 hipError_t launch_gae_marl_agents(const float* rewards, const float* value_preds, const float* masks, float* returns, int T, int64_t N, int A,
                                   float gamma, float lam, int use_norm, const float* mean, const float* var, hipStream_t s) {
     hipLaunchKernelGGL(gae_marl_agents_kernel, dim3(grid_for(N * A)), dim3(256), 0, s, rewards, value_preds, masks, returns, T, N, A, gamma, lam, use_norm, mean, var);
+    return hipGetLastError();
+}
+hipError_t launch_ppo_act(const float* mean, const float* value, const float* log_std, uint64_t seed, int64_t* counters, int64_t row_offset,
+                          int ref_scale, float* actions_out, float* act_slot, float* logp_slot, float* value_slot, float* mu_slot,
+                          float* sigma_slot, int64_t N, int A, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(ppo_act_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, mean, value, log_std, seed, counters, row_offset, ref_scale,
+                       actions_out, act_slot, logp_slot, value_slot, mu_slot, sigma_slot, N, A);
     return hipGetLastError();
 }
 hipError_t launch_marl_views(const float* obs, float* obs_all, int64_t n, int agents, int per, int shared, hipStream_t s) {

@@ -13,6 +13,8 @@ struct StepArgs {
     float* obs_clipped;               // [N, obs_dim] clamped to +-clip_obs
     float* obs_out;                   // optional bound destination for the clamped row (may be null)
     float* rew;                       // [N]
+    float* rew_out;                   // optional bound destination for the reward (may be null)
+    uint8_t* done_out;                // optional bound destination for the done flag (may be null)
     int64_t* reset;                   // [N]
     int64_t* progress;                // [N]
     float* root_states;               // [N * actors, 13]  env-local frame

@@ -331,6 +331,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             a.rew[env_e] = rew;
             a.reset[env_e] = rs;
             a.progress[env_e] = progress;
+            if (a.rew_out) a.rew_out[env_e] = rew;
+            if (a.done_out) a.done_out[env_e] = (uint8_t)rs;
         }
     } else {  // OneAnt: the four leg lanes stage their reward partials, the box lead finishes
         if (is_ant) {
@@ -362,6 +364,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             a.rew[env_e] = rew;
             a.reset[env_e] = rs;
             a.progress[env_e] = progress;
+            if (a.rew_out) a.rew_out[env_e] = rew;
+            if (a.done_out) a.done_out[env_e] = (uint8_t)rs;
             prev_env[0] = r[0]; prev_env[1] = r[1]; prev_env[2] = bgx; prev_env[3] = bgy;   // one_ant.py:432-433
             prev_env[4] = pot; prev_env[5] = pot_in;
         }
@@ -489,6 +493,8 @@ __global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
         a.rew[env] = rew;
         a.reset[env] = rs;
         a.progress[env] = progress;
+        if (a.rew_out) a.rew_out[env] = rew;
+        if (a.done_out) a.done_out[env] = (uint8_t)rs;
     }
 }
 

@@ -79,6 +79,18 @@ class Engine:
         self._bound = tensor_or_none          # keep it alive
         _lib.check(_lib.lib().mms_bind_obs_out(self._h, ptr), self._h, "mms_bind_obs_out")
 
+    def bind_rollout_out(self, rewards=None, dones=None):
+        """Extra destinations for the step's reward (f32 [N]) and done flag (u8 [N]), e.g. RolloutStorage.rewards[t] /
+        dones[t]; None disables either."""
+        def ptr(t, dtype):
+            if t is None:
+                return None
+            assert t.is_cuda and t.dtype == dtype and t.is_contiguous() and t.numel() == self.num_envs
+            return ctypes.c_void_p(t.data_ptr())
+        self._bound_rollout = (rewards, dones)
+        _lib.check(_lib.lib().mms_bind_rollout_out(self._h, ptr(rewards, torch.float32), ptr(dones, torch.uint8)), self._h,
+                   "mms_bind_rollout_out")
+
     def set_state(self, name, src, env_ids=None):
         """Tests / fixtures: copy `src` (torch tensor on this device, or a numpy array) into a named buffer."""
         L = _lib.lib()

@@ -535,6 +535,59 @@ MO_EXPORT float mo_rand_uniform(uint64_t seed, uint64_t env_global, uint64_t ste
     return (float)(x >> 8) * (1.0f / 16777216.0f);             /* [0,1), 24 bits like torch.rand */
 }
 
+/* standard normal by Box-Muller from two counter-based uniforms; the first is moved off zero */
+MO_EXPORT float mo_rand_normal(uint64_t seed, uint64_t row, uint64_t counter, uint32_t k) {
+    float u1 = mo_rand_uniform(seed, row, counter, 2u * k) + (0.5f / 16777216.0f);
+    float u2 = mo_rand_uniform(seed, row, counter, 2u * k + 1u);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+/* The sampling tail of ActorCritic.act (agents/algorithms/rl/ppo/module.py:73-87):
+ *   covariance = diag(exp(log_std) * exp(log_std)); MultivariateNormal(mean, scale_tril=covariance)   (:76-77)
+ *   actions = sample(); log_prob(actions); sigma returned = log_std.repeat(N, 1)                      (:79-87)
+ * scale_tril = diag(s) gives x = mean + s * eps and log_prob = sum(-0.5 eps^2 - log s - 0.5 log 2 pi).
+ * reference_scale = 0 uses s = exp(log_std) (the conventional reading); the noise is this build's counter-based stream. */
+MO_EXPORT void mo_ppo_act(int64_t n, int A, const float* mean, const float* log_std, uint64_t seed, int64_t* counters, int64_t row_offset,
+                          int reference_scale, float* actions, float* logp, float* sigma) {
+    for (int64_t i = 0; i < n; i++) {
+        float lp = 0.f, part[64];
+        for (int l = 0; l < 64; l++) part[l] = 0.f;
+        for (int j = 0; j < A; j++) {
+            float ls = log_std[j], scale, lscale;
+            if (reference_scale) { float sd = expf(ls); scale = sd * sd; lscale = logf(scale); }
+            else { scale = expf(ls); lscale = ls; }
+            float z = mo_rand_normal(seed, (uint64_t)(row_offset + i), (uint64_t)counters[i], (uint32_t)j);
+            actions[i * A + j] = mean[i * A + j] + scale * z;
+            part[j & 63] += -0.5f * z * z - lscale - 0.9189385332046727f;
+            sigma[i * A + j] = ls;
+        }
+        for (int m = 32; m >= 1; m >>= 1)                    /* the kernel's butterfly order */
+            for (int l = 0; l < 64; l++) if ((l & m) == 0) { float t = part[l] + part[l | m]; part[l] = t; part[l | m] = t; }
+        lp = part[0];
+        logp[i] = lp;
+        counters[i] += 1;
+    }
+}
+
+/* log_prob and entropy of given actions under the same distribution (ActorCritic.evaluate, module.py:93-109):
+ * entropy of N(mean, diag(s^2)) = sum(0.5 + 0.5 log(2 pi) + log s), the same for every row. */
+MO_EXPORT void mo_ppo_log_prob(int64_t n, int A, const float* mean, const float* log_std, const float* actions, int reference_scale,
+                               float* logp, float* entropy) {
+    for (int64_t i = 0; i < n; i++) {
+        float lp = 0.f, ent = 0.f;
+        for (int j = 0; j < A; j++) {
+            float ls = log_std[j], scale, lscale;
+            if (reference_scale) { float sd = expf(ls); scale = sd * sd; lscale = logf(scale); }
+            else { scale = expf(ls); lscale = ls; }
+            float z = (actions[i * A + j] - mean[i * A + j]) / scale;
+            lp += -0.5f * z * z - lscale - 0.9189385332046727f;
+            ent += 0.5f + 0.9189385332046727f + lscale;
+        }
+        logp[i] = lp;
+        if (entropy) entropy[i] = ent;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* PHYSICS (this build's model; parity unpinned against Isaac Gym -- see header)               */
 /* ------------------------------------------------------------------------------------------ */

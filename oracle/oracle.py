@@ -39,6 +39,10 @@ def lib():
         _lib.mo_rand_uniform.restype = ctypes.c_float
         _lib.mo_rand_uniform.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
         cf, ci, c64 = ctypes.c_float, ctypes.c_int, ctypes.c_int64
+        _lib.mo_rand_normal.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
+        _lib.mo_rand_normal.restype = ctypes.c_float
+        _lib.mo_ppo_act.argtypes = [c64, ci, F, F, ctypes.c_uint64, I64, c64, ci, F, F, F]
+        _lib.mo_ppo_log_prob.argtypes = [c64, ci, F, F, F, ci, F, F]
         _lib.mo_helpers_batch.argtypes = [c64] + [F] * 13
         _lib.mo_tenant_obs_batch.argtypes = [c64, F, F, F, F, F, cf, F, F]
         _lib.mo_tenant_goals_batch.argtypes = [c64, F, F, F, F, F, F]

@@ -99,7 +99,12 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+ONLY = set(sys.argv[1:])        # fixture names given on the command line: write only those
+
+
 def _save(name, meta, **arrays):
+    if ONLY and name not in ONLY:
+        return
     out = {k: (_np(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
     out["meta"] = np.array(meta)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
@@ -448,6 +453,29 @@ def main():
           last_values=last_values, gamma=0.96, lam=0.95, returns=st.returns, advantages=st.advantages,
           stored_rewards=st.rewards, stored_dones=st.dones, stored_logp=st.actions_log_prob,
           logp=torch.stack(rec["logp"]), mean_traj_len=stats_len, mean_reward=stats_rew)
+
+    # ---------------- ppo_act ----------------
+    # ActorCritic.act / evaluate (algorithms/rl/ppo/module.py:73-109) on a small network: pins the scale_tril = diag(sigma^2)
+    # reading of the covariance (:76-77), the log-probability, the entropy and what is returned as "sigma" (:87).
+    module_mod = _load_by_path("ref_ppo_module", os.path.join(REF, "agents/algorithms/rl/ppo/module.py"))
+    torch.manual_seed(21)
+    with _quiet():
+        ac = module_mod.ActorCritic((48,), (0,), (8,), 0.8, {"pi_hid_sizes": [32, 32, 16], "vf_hid_sizes": [32, 32, 16],
+                                                           "activation": "elu"}, asymmetric=False)
+    with torch.no_grad():
+        ac.log_std.copy_(torch.linspace(-0.6, 0.1, 8))
+    g = torch.Generator().manual_seed(22)
+    o = torch.randn(N, 48, generator=g)
+    torch.manual_seed(23)
+    with torch.no_grad():
+        a_act, lp_act, v_act, mu_act, sg_act = ac.act(o, torch.zeros(N, 0))
+        lp_ev, ent_ev, v_ev, mu_ev, sg_ev = ac.evaluate(o, torch.zeros(N, 0), a_act)
+        a_inf = ac.act_inference(o)
+    sd = {k.replace(".", "_"): v for k, v in ac.state_dict().items()}
+    _save("ppo_act", meta_common + "; ActorCritic.act/evaluate/act_inference (algorithms/rl/ppo/module.py:73-109), "
+          "obs 48, actions 8, hidden [32,32,16] elu, initial_std 0.8 then log_std = linspace(-0.6, 0.1, 8)",
+          obs=o, actions=a_act, log_prob=lp_act, value=v_act, mu=mu_act, sigma=sg_act, eval_log_prob=lp_ev, eval_entropy=ent_ev,
+          eval_value=v_ev, inference=a_inf, **sd)
 
     # ---------------- marl_gae ----------------
     sb = __import__("agents.algorithms.marl.utils.separated_buffer", fromlist=["x"])

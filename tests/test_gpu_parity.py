@@ -600,3 +600,104 @@ def test_bound_obs_out_and_graph_replay(torch_cuda):
     assert torch.equal(e1.tensor("obs"), e2.tensor("obs"))
     e1.close()
     e2.close()
+
+
+def test_ppo_act_kernel_vs_oracle(torch_cuda):
+    """mms_ppo_act (sampling tail of ActorCritic.act + the add_transitions stores) against the oracle's restatement with
+    the same seed / counters: noise stream bit-compatible up to libm rounding, every destination written, counters
+    advanced, and a captured graph draws fresh noise on every replay."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    from oracle.oracle import fp, ip, lib as olib_
+    olib = olib_()
+    L = _lib.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(3)
+    for (N, A, ref) in ((1001, 80, 1), (1001, 80, 0), (130, 8, 1), (64, 128, 0)):
+        mean = rng.standard_normal((N, A)).astype(np.float32)
+        value = rng.standard_normal(N).astype(np.float32)
+        ls = np.linspace(-0.6, 0.15, A).astype(np.float32)
+        c0 = (np.arange(N) % 5).astype(np.int64)
+        d = {k: torch.zeros(N, A, device="cuda") for k in ("actions_out", "act", "mu", "sigma")}
+        logp, val = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        counters = torch.from_numpy(c0).cuda()
+        tm, tv, tl = torch.from_numpy(mean).cuda(), torch.from_numpy(value).cuda(), torch.from_numpy(ls).cuda()
+        _lib.check(L.mms_ppo_act(0, p(tm), p(tv), p(tl), 1234, p(counters), 7000, ref, p(d["actions_out"]), p(d["act"]), p(logp),
+                                 p(val), p(d["mu"]), p(d["sigma"]), N, A, stream), None, "mms_ppo_act")
+        torch.cuda.synchronize()
+        oc = c0.copy()
+        oact, ologp, osig = np.zeros((N, A), np.float32), np.zeros(N, np.float32), np.zeros((N, A), np.float32)
+        olib.mo_ppo_act(N, A, fp(mean), fp(ls), ctypes.c_uint64(1234), ip(oc), 7000, ref, fp(oact), fp(ologp), fp(osig))
+        np.testing.assert_array_equal(to_np(counters), oc)
+        assert np.max(np.abs(to_np(d["act"]) - oact)) < 2e-5, (N, A, ref)       # logf / cosf / expf: a few ulp of |noise| <= 6
+        assert torch.equal(d["act"], d["actions_out"])
+        assert np.max(np.abs(to_np(logp) - ologp)) < 2e-3 * (A / 80.0 + 1.0)
+        np.testing.assert_array_equal(to_np(d["mu"]), mean)
+        np.testing.assert_array_equal(to_np(d["sigma"]), osig)
+        np.testing.assert_array_equal(to_np(val), value)
+    # NULL destinations are skipped; graph replays advance the device-side counters -> fresh noise
+    N, A = 256, 80
+    tm, tl = torch.zeros(N, A, device="cuda"), torch.zeros(A, device="cuda")
+    counters = torch.zeros(N, dtype=torch.int64, device="cuda")
+    out = torch.zeros(N, A, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            _lib.check(L.mms_ppo_act(0, p(tm), None, p(tl), 5, p(counters), 0, 0, p(out), None, None, None, None, None, N, A,
+                                     ctypes.c_void_p(side.cuda_stream)), None, "mms_ppo_act")
+    torch.cuda.current_stream().wait_stream(side)
+    draws = []
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        draws.append(out.clone())
+    assert int(counters.min()) == 3 and int(counters.max()) == 3
+    assert float((draws[0] == draws[1]).float().mean()) < 0.01 and float((draws[1] == draws[2]).float().mean()) < 0.01
+    z = torch.cat(draws).flatten()
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+
+
+def test_fused_act_and_bound_rollout(torch_cuda):
+    """ActorCritic.act (fused tail) + RolloutStorage + engine, all zero-copy: slot t of the storage holds exactly what the
+    reference's act -> step -> add_transitions sequence would have copied there."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.storage import RolloutStorage
+    from massive_marl_benchmark_amd.engine import Engine
+    n, T = 192, 4
+    eng = Engine("TenAnt", num_envs=n, device=0, seed=3)
+    torch.manual_seed(0)
+    ac = ActorCritic((388,), (0,), (80,), 0.8, {"pi_hid_sizes": [64, 64], "vf_hid_sizes": [64, 64], "activation": "elu"},
+                     seed=11).cuda()
+    st = RolloutStorage(n, T, (388,), (0,), (80,), device="cuda:0")
+    ac.bind_rollout(st, eng.tensor("actions"))
+    states = torch.zeros(n, 0, device="cuda")
+    eng.tensor("actions").zero_()
+    eng.step()                                                     # first step = full reset
+    cur = eng.tensor("obs_clipped").clone()
+    for t in range(T):
+        st.observations[t].copy_(cur)
+        actions, logp, values, mu, sigma = ac.act(st.observations[t], states)
+        assert actions.data_ptr() == st.actions[t].data_ptr() and values.data_ptr() == st.values[t].data_ptr()
+        assert torch.equal(eng.tensor("actions"), actions)
+        with torch.no_grad():
+            lp2, _, v2, mu2, sg2 = ac.evaluate(st.observations[t], states, actions)
+        assert float((lp2 - logp).abs().max()) < 5e-3              # (a - mu) / sigma^2 in fp32 vs the noise itself
+        assert float((v2 - values).abs().max()) < 1e-5 and float((mu2 - mu).abs().max()) < 1e-5
+        assert torch.equal(sg2, sigma)
+        eng.bind_rollout_out(st.rewards[t].view(-1), st.dones[t].view(-1))
+        eng.step()
+        st.add_transitions(st.observations[t], states, actions, st.rewards[t], st.dones[t], values, logp, mu, sigma)
+        torch.cuda.synchronize()
+        assert torch.equal(st.rewards[t].view(-1), eng.tensor("rew"))
+        assert torch.equal(st.dones[t].view(-1).long(), eng.tensor("reset"))
+        assert torch.equal(st.actions[t], actions) and torch.equal(st.actions_log_prob[t].view(-1), logp)
+        cur = eng.tensor("obs_clipped").clone()
+    assert st.step == T
+    z = (st.actions - st.mu) / torch.exp(2.0 * ac.log_std.detach())
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+    eng.bind_rollout_out(None, None)
+    eng.close()

@@ -166,6 +166,46 @@ def test_ppo_gae_golden(olib):
     assert np.max(np.abs(adv - g["advantages"][..., 0])) < 1e-5
 
 
+def test_ppo_act_golden(olib):
+    """ActorCritic.act / evaluate (module.py:73-109): log-probability and entropy under scale_tril = diag(sigma^2), and the
+    log_std that is returned as "sigma"."""
+    import ctypes
+    g = load_golden("ppo_act")
+    n, A = g["actions"].shape
+    log_std = f32(g["log_std"])
+    np.testing.assert_array_equal(g["sigma"], np.tile(log_std, (n, 1)))
+    np.testing.assert_allclose(g["mu"], g["inference"], atol=1e-6)
+    lp, ent = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    olib.mo_ppo_log_prob(n, A, fp(f32(g["mu"])), fp(log_std), fp(f32(g["actions"])), 1, fp(lp), fp(ent))
+    assert np.max(np.abs(lp - g["log_prob"])) < TOL
+    assert np.max(np.abs(lp - g["eval_log_prob"])) < TOL
+    assert np.max(np.abs(ent - g["eval_entropy"])) < TOL
+    # the conventional reading (scale = sigma) gives a different number: the quirk is real and pinned
+    lp0 = np.zeros(n, np.float32)
+    olib.mo_ppo_log_prob(n, A, fp(f32(g["mu"])), fp(log_std), fp(f32(g["actions"])), 0, fp(lp0), None)
+    assert np.max(np.abs(lp0 - g["log_prob"])) > 0.1
+    # the oracle's own sampler: log-prob consistent with its actions, counters advance, noise is standard normal
+    N2, A2 = 512, 80
+    rng = np.random.default_rng(5)
+    mean = f32(rng.standard_normal((N2, A2)))
+    ls = f32(np.linspace(-0.5, 0.2, A2))
+    for ref in (1, 0):
+        counters = i64(np.arange(N2) % 3)
+        c0 = counters.copy()
+        act, logp, sig = np.zeros((N2, A2), np.float32), np.zeros(N2, np.float32), np.zeros((N2, A2), np.float32)
+        olib.mo_ppo_act(N2, A2, fp(mean), fp(ls), ctypes.c_uint64(99), ip(counters), 1000, ref, fp(act), fp(logp), fp(sig))
+        np.testing.assert_array_equal(counters, c0 + 1)
+        np.testing.assert_array_equal(sig, np.tile(ls, (N2, 1)))
+        chk = np.zeros(N2, np.float32)
+        olib.mo_ppo_log_prob(N2, A2, fp(mean), fp(ls), fp(act), ref, fp(chk), None)
+        assert np.max(np.abs(chk - logp)) < 2e-3          # (act - mean) / scale loses a few ulp of act
+        z = (act - mean) / np.exp((2.0 if ref else 1.0) * ls)
+        assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02 and abs((z ** 4).mean() - 3.0) < 0.15
+        act2 = np.zeros_like(act)
+        olib.mo_ppo_act(N2, A2, fp(mean), fp(ls), ctypes.c_uint64(99), ip(counters), 1000, ref, fp(act2), fp(logp), fp(sig))
+        assert np.mean(act2 == act) < 0.01                 # a new draw per call
+
+
 def test_marl_gae_golden(olib):
     g = load_golden("marl_gae")
     T, N = g["rewards"].shape[:2]
