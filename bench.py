@@ -67,6 +67,11 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--policy-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--fuse-head", action="store_true", help="A/B: the actor's last Linear layer inside the sampling kernel (mms_ppo_head_act)")
+    ap.add_argument("--one-stream", action="store_true", help="A/B: actor and critic MLPs on one stream")
+    ap.add_argument("--defer-critic", action="store_true",
+                    help="A/B: let the critic pass overlap the sampling kernel and the env step (joined before the GAE); faster, but "
+                         "the step kernel then shares the GPU with GEMMs and its rocprof average no longer is its stand-alone duration")
     ap.add_argument("--unfused", action="store_true", help="A/B: torch sampling + add_transitions copies instead of mms_ppo_act and bound rollout slots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for the CPU baseline (0 = sized for ~15 s)")
@@ -147,18 +152,25 @@ def main():
             sim_graph.replay()
     torch.cuda.synchronize()
     sim_wall = time.perf_counter() - t0
-    # step-kernel launch duration: back-to-back launches with nothing else on the stream, HIP events around them
-    ev0.record()
-    for i in range(256):
-        eng.step()
-    ev1.record()
-    torch.cuda.synchronize()
-    kernel_ms = ev0.elapsed_time(ev1) / 256.0
+    # step-kernel launch duration: back-to-back launches with nothing else on the stream, HIP events around them.
+    # Measured twice -- here, after the sim-only series, and again right after the GEMM-heavy rollout series -- because the
+    # kernel is VALU-issue bound and so follows the core clock, which the rollout's matrix-core bursts pull down.
+    def time_step_kernel(n=256):
+        ev0.record()
+        for _ in range(n):
+            eng.step()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / n
+    kernel_ms_pre = time_step_kernel()
 
     # ---- PPO rollout series -----------------------------------------------------------------------------------
     def measure_rollout(pdtype, K_req, W_req):
         ac_ = ac if pdtype == torch.float32 else ac_bf16
         ac_.bind_rollout(None if args.unfused else storage, None if args.unfused else actions_buf)
+        ac_.two_streams = not args.one_stream
+        ac_.fuse_head = args.fuse_head
+        ac_.defer_value = args.defer_critic and not args.one_stream
 
         def rollout_step_fused():
             # Zero-copy rollout: the engine writes observation t+1, reward t and done t into the storage slots, mms_ppo_act
@@ -174,6 +186,7 @@ def main():
             eng.step()
             storage.add_transitions(obs_t, states, act, storage.rewards[t], storage.dones[t], value, logp, mu, sigma)
             if storage.step == NSTEPS:
+                ac_.join()                                                   # deferred critic passes: values are read from here on
                 with torch.no_grad():
                     last_values = ac_.critic(obs_clipped.to(pdtype)).float()
                 storage.compute_returns(last_values, GAMMA, LAM)
@@ -237,7 +250,30 @@ def main():
         t0 = time.perf_counter()
         run_steps(K)
         barrier()
-        return time.perf_counter() - t0, K, W, graph is not None
+        elapsed_ = time.perf_counter() - t0
+        # the step kernel inside the rollout (caches cold after the policy GEMMs): HIP events around each of 4 x NSTEPS
+        # eager rollout steps, outside the timed region
+        pairs = []
+        plain_step = eng.step
+
+        def probed_step():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            plain_step()
+            b.record()
+            pairs.append((a, b))
+        eng.step = probed_step
+        try:
+            for _ in range(4 * NSTEPS):
+                rollout_step()
+        finally:
+            eng.step = plain_step
+        torch.cuda.synchronize()
+        in_rollout_ms.append(sum(a.elapsed_time(b) for a, b in pairs) / len(pairs))
+        rollout_counts.append((W, K))
+        return elapsed_, K, W, graph is not None
+
+    in_rollout_ms, rollout_counts = [], []
 
     ac_bf16 = None
     bf_elapsed, bf_K = 0.0, 0
@@ -249,10 +285,20 @@ def main():
         ac_bf16 = ac.to(torch.bfloat16)
     elapsed, K, W, graphed = measure_rollout(pdtype, args.steps, args.warmup)
     graph = graphed or None
-    tmax = torch.tensor([elapsed, sim_wall, kernel_ms, bf_elapsed], dtype=torch.float64, device=device)
+    eng.bind_obs_out(None)
+    eng.bind_rollout_out(None, None)
+    kernel_ms_post = time_step_kernel()
+    kernel_ms_b2b = 0.5 * (kernel_ms_pre + kernel_ms_post)
+    kernel_ms_roll = in_rollout_ms[-1]
+    # average over the step-kernel launches of this run (what a kernel trace of the same command averages): back-to-back
+    # launches (sim-only series, its warm-up, the timing loops) and launches inside rollout steps (all series)
+    n_b2b = 64 + 16 + sim_steps + 2 * 256
+    n_roll = sum(NSTEPS + w + k + 4 * NSTEPS for (w, k) in rollout_counts)
+    kernel_ms = (n_b2b * kernel_ms_b2b + n_roll * kernel_ms_roll) / (n_b2b + n_roll)
+    tmax = torch.tensor([elapsed, sim_wall, kernel_ms, bf_elapsed, kernel_ms_b2b, kernel_ms_roll], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed, sim_wall, kernel_ms, bf_elapsed = [float(x) for x in tmax.tolist()]
+    elapsed, sim_wall, kernel_ms, bf_elapsed, kernel_ms_b2b, kernel_ms_roll = [float(x) for x in tmax.tolist()]
     finite = bool(torch.isfinite(obs_clipped).all().item()) and bool(torch.isfinite(rew).all().item())
     resets_seen = int(eng.tensor("reset_count").sum().item())
 
@@ -274,13 +320,20 @@ def main():
             "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
                                    "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "finite": finite, "resets_total": resets_seen},
+                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "actor_head_in_kernel": bool(args.fuse_head),
+                       "critic_deferred": bool(args.defer_critic), "finite": finite, "resets_total": resets_seen},
             "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
                          "note": "engine step with pre-drawn actions (ring of 16)", "hipgraph": sim_graph is not None},
-            "roofline": {"bound": "hbm", "kernel": "mms::ant_step_kernel<TEN_ANT,64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "mms::ant_step_kernel<TEN_ANT, 192, 4, 10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (tr or {}).get("source"),
-                         "bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "launch_ms": kernel_ms},
+                         "bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "launch_ms": kernel_ms,
+                         "launch_ms_back_to_back": kernel_ms_b2b, "launch_ms_in_rollout": kernel_ms_roll,
+                         "launches": {"back_to_back": n_b2b, "in_rollout": n_roll},
+                         "frac_back_to_back": ALGO_BYTES_PER_ENV_STEP * N / (kernel_ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "launch_note": "HIP events on the launch stream: 2 x 256 back-to-back launches (state hot in L2 / MALL) and 32 launches "
+                                        "inside eager rollout steps (cold after the policy GEMMs); launch_ms = average over all step-kernel "
+                                        "launches of this run, the figure a kernel trace of the same command averages"},
             "cpu_baseline": cpu,
         }
         if bf_K:

@@ -192,6 +192,15 @@ int mms_ppo_act(int device, const float* mean, const float* value, const float* 
                 int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot, float* logp_slot,
                 float* value_slot, float* mu_slot, float* sigma_slot, int64_t N, int32_t A, void* hip_stream);
 
+/* mms_ppo_act with the actor's last Linear layer (module.py:29-30: nn.Linear(pi_hid_sizes[-1], actions)) folded in:
+ * mean = hidden @ weight^T + bias on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums), then the same
+ * sampling and stores.  hidden [N,H] f32 is the output of the last activation, weight [A,H] and bias [A] are torch's Linear
+ * parameters; H must be a multiple of 64, A <= 128.  Replaces a skinny GEMM that runs at < 20 TFLOP/s plus a launch. */
+int mms_ppo_head_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H, const float* value,
+                     const float* log_std, uint64_t seed, int64_t* counters, int64_t row_offset, int32_t reference_scale,
+                     float* actions_out, float* act_slot, float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot,
+                     int64_t N, int32_t A, void* hip_stream);
+
 const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
 int mms_abi_version(void);
 

@@ -56,11 +56,20 @@ class ActorCritic(nn.Module):
         self.seed, self.row_offset = int(seed), int(row_offset)     # noise stream key; row_offset = global index of env 0
         self._counters = None
         self._bound = None
+        self._side = None       # second HIP stream: the critic MLP runs beside the actor MLP (see act)
+        self._trunk = None
 
     @staticmethod
     def init_weights(sequential, scales):
         for idx, module in enumerate(m for m in sequential if isinstance(m, nn.Linear)):
             torch.nn.init.orthogonal_(module.weight, gain=scales[idx])
+
+    # last actor Linear inside the sampling kernel (mms_ppo_head_act) when its shape allows.  Opt-in: stand-alone it beats the
+    # library's skinny GEMM + mms_ppo_act (12.2 us against 14.6 us at N 4096, H 512, A 80) but inside the two-stream rollout,
+    # next to the critic's GEMMs, the rollout step measured 371.8 us with it and 365.5 us without (profiles/r01_v8_rollout_ab.txt)
+    fuse_head = False
+    two_streams = True      # critic beside the actor on a second stream
+    defer_value = False     # opt-in: `act` returns before the critic has finished; the owner calls join() before reading values
 
     def forward(self):
         raise NotImplementedError
@@ -72,9 +81,23 @@ class ActorCritic(nn.Module):
         not copy again) and `actions_out` (e.g. the engine's "actions" buffer)."""
         self._bound = (storage, actions_out)
 
-    def _sample(self, mean, value):
-        N, A = mean.shape
-        dev = mean.device
+    def _actor_pass(self, x):
+        """The actor MLP up to what the sampling kernel takes: (mean, None) or, when the last Linear layer can run inside
+        the kernel (fp32, in_features a multiple of 64, at most 128 actions), (None, hidden)."""
+        last = self.actor[-1]
+        if (self.fuse_head and x.is_cuda and isinstance(last, nn.Linear) and last.weight.dtype == torch.float32
+                and last.in_features % 64 == 0 and last.out_features <= 128 and last.bias is not None):
+            if self._trunk is None:
+                self._trunk = [self.actor[:-1]]          # in a list: not registered as a second copy of the parameters
+            return None, self._trunk[0](x)
+        return self.actor(x), None
+
+    def _sample(self, mean, value, hidden=None):
+        """mean [N, A] (or None with hidden [N, H]: the last actor layer runs in the kernel); value [N, 1] or None (the caller
+        stores the value itself).  Returns act, logp, val, mu, sigma."""
+        src = mean if mean is not None else hidden
+        N, A = src.shape[0], self.log_std.shape[0]
+        dev = src.device
         if dev.type != "cuda":
             raise _lib.MmsError("ActorCritic.act samples on the HIP device only (no CPU fallback)")
         if self._counters is None or self._counters.numel() != N or self._counters.device != dev:
@@ -85,23 +108,58 @@ class ActorCritic(nn.Module):
             act, logp, val = storage.actions[s], storage.actions_log_prob[s], storage.values[s]
             mu, sigma = storage.mu[s], storage.sigma[s]
         else:
-            act, mu, sigma = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+            act, mu, sigma = (torch.empty(N, A, device=dev) for _ in range(3))
             logp, val = torch.empty(N, 1, device=dev), torch.empty(N, 1, device=dev)
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-        mean, value = mean.contiguous().float(), value.contiguous().float()
+        value = None if value is None else value.contiguous().float()
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         log_std = self.log_std.detach().float().contiguous()
-        _lib.check(_lib.lib().mms_ppo_act(idx, p(mean), p(value), p(log_std), self.seed, p(self._counters),
-                                          self.row_offset, 1, p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A,
-                                          current_stream_ptr(dev)), None, "mms_ppo_act")
+        L = _lib.lib()
+        if mean is not None:
+            mean = mean.contiguous().float()
+            _lib.check(L.mms_ppo_act(idx, p(mean), p(value), p(log_std), self.seed, p(self._counters), self.row_offset, 1,
+                                     p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A, current_stream_ptr(dev)),
+                       None, "mms_ppo_act")
+        else:
+            last = self.actor[-1]
+            hidden = hidden.contiguous()
+            _lib.check(L.mms_ppo_head_act(idx, p(hidden), p(last.weight.detach()), p(last.bias.detach()), last.in_features, p(value),
+                                          p(log_std), self.seed, p(self._counters), self.row_offset, 1, p(actions_out), p(act), p(logp),
+                                          p(val), p(mu), p(sigma), N, A, current_stream_ptr(dev)), None, "mms_ppo_head_act")
         return act, logp.view(-1), val, mu, sigma
 
     def act(self, observations, states):
         with torch.no_grad():
             dtype = self.log_std.dtype                              # a bf16 copy of the module takes fp32 observations
-            mean = self.actor(observations.to(dtype))
-            value = self.critic((states if self.asymmetric else observations).to(dtype))
-            return self._sample(mean, value)
+            critic_in = (states if self.asymmetric else observations).to(dtype)
+            if not (observations.is_cuda and self.two_streams):
+                mean, hidden = self._actor_pass(observations.to(dtype))
+                return self._sample(mean, self.critic(critic_in), hidden)
+            # The two MLPs are independent: the critic's GEMMs / activations go to a second stream, so its memory-bound
+            # activation kernels overlap the actor's compute-bound GEMMs (fork / join edges when captured in a hipGraph).
+            if self._side is None:
+                self._side = torch.cuda.Stream(observations.device)
+            cur = torch.cuda.current_stream(observations.device)
+            self._side.wait_stream(cur)
+            if not self.defer_value:
+                with torch.cuda.stream(self._side):
+                    value = self.critic(critic_in)
+                mean, hidden = self._actor_pass(observations.to(dtype))
+                cur.wait_stream(self._side)
+                return self._sample(mean, value, hidden)
+            # defer_value: nothing downstream of the action needs the value -- not the env step, not the next actor pass --
+            # so the critic keeps running on its stream beside the sampling kernel and the env step; `join()` (called by the
+            # owner before the values are read: GAE) is the only point where the current stream waits for it.
+            mean, hidden = self._actor_pass(observations.to(dtype))
+            act, logp, val, mu, sigma = self._sample(mean, None, hidden)
+            with torch.cuda.stream(self._side):
+                val.copy_(self.critic(critic_in))
+            return act, logp, val, mu, sigma
+
+    def join(self):
+        """Make the current stream wait for deferred critic passes (see `defer_value`)."""
+        if self._side is not None:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
     def act_inference(self, observations):
         return self.actor(observations)

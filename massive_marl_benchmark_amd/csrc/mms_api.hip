@@ -21,6 +21,8 @@ hipError_t launch_gae_marl(const float*, const float*, const float*, float*, int
 hipError_t launch_marl_views(const float*, float*, int64_t, int, int, int, hipStream_t);
 hipError_t launch_gae_marl_agents(const float*, const float*, const float*, float*, int, int64_t, int, float, float, int, const float*, const float*, hipStream_t);
 hipError_t launch_ppo_act(const float*, const float*, const float*, uint64_t, int64_t*, int64_t, int, float*, float*, float*, float*, float*, float*, int64_t, int, hipStream_t);
+hipError_t launch_ppo_head_act(const float*, const float*, const float*, int, const float*, const float*, uint64_t, int64_t*, int64_t, int, float*, float*, float*,
+                               float*, float*, float*, int64_t, int, hipStream_t);
 }  // namespace mms
 
 struct mms_buffer {
@@ -336,6 +338,21 @@ __attribute__((visibility("default"))) int mms_ppo_act(int device, const float* 
     if (!mean || !log_std || !counters || N < 0 || A <= 0 || A > 128) { g_create_error = "mms_ppo_act: bad arguments (A must be in 1..128)"; return 1; }
     MMS_FREE(mms::launch_ppo_act(mean, value, log_std, seed, counters, row_offset, reference_scale, actions_out, act_slot, logp_slot, value_slot,
                                  mu_slot, sigma_slot, N, A, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_ppo_head_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H,
+                                                            const float* value, const float* log_std, uint64_t seed, int64_t* counters,
+                                                            int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
+                                                            float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N,
+                                                            int32_t A, void* s) {
+    if (dev_guard(device)) return 1;
+    if (!hidden || !weight || !bias || !log_std || !counters || N < 0 || A <= 0 || A > 128 || H <= 0 || (H % 64) != 0) {
+        g_create_error = "mms_ppo_head_act: bad arguments (A must be in 1..128, H a positive multiple of 64)";
+        return 1;
+    }
+    MMS_FREE(mms::launch_ppo_head_act(hidden, weight, bias, H, value, log_std, seed, counters, row_offset, reference_scale, actions_out, act_slot,
+                                      logp_slot, value_slot, mu_slot, sigma_slot, N, A, (hipStream_t)s));
     return 0;
 }
 

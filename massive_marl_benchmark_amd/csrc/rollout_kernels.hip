@@ -8,6 +8,7 @@
 //   marl_views_kernel    MultiVecTaskPython.step slicing  (agents/tasks/agent_base/multi_vec_task.py:105-142)
 //   ppo_act_kernel       the sampling tail of ActorCritic.act (agents/algorithms/rl/ppo/module.py:73-87) fused with the
 //                        stores of RolloutStorage.add_transitions (storage.py:33-47)
+//   ppo_head_act_kernel  the same with the actor's last Linear layer (module.py:29-30) on the matrix cores in front of it
 //
 // All are HBM-bound streaming kernels: thread = env column, T serial steps, every load of a [T,N] plane is a
 // coalesced 256 B wave transaction.
@@ -136,18 +137,15 @@ __global__ void __launch_bounds__(256) marl_views_kernel(const float* __restrict
     }
 }
 
-// One wave per row (env): lane j draws the noise of action j (and j + 64), the row's log-probability is a wave reduction.
-// The per-row draw counter lives in device memory so that a replayed hipGraph sees fresh noise; the store of c + 1 depends
-// on the load of c, which orders the two.
-__global__ void __launch_bounds__(256) ppo_act_kernel(const float* __restrict__ mean, const float* __restrict__ value,
-                                                      const float* __restrict__ log_std, uint64_t seed, int64_t* __restrict__ counters,
-                                                      int64_t row_offset, int ref_scale, float* __restrict__ actions_out,
-                                                      float* __restrict__ act_slot, float* __restrict__ logp_slot,
-                                                      float* __restrict__ value_slot, float* __restrict__ mu_slot,
-                                                      float* __restrict__ sigma_slot, int64_t N, int A) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;
+// Sampling of one row by one wave: lane j draws the noise of action j (and j + 64), the row's log-probability is a wave
+// reduction.  The per-row draw counter lives in device memory so that a replayed hipGraph sees fresh noise; the store of
+// c + 1 depends on the load of c, which orders the two.  `mean_row` may point to global memory or LDS.
+struct PpoActOut {
+    float* actions_out; float* act_slot; float* logp_slot; float* value_slot; float* mu_slot; float* sigma_slot;
+};
+__device__ __forceinline__ void ppo_sample_row(const float* mean_row, const float* __restrict__ value, const float* __restrict__ log_std,
+                                               uint64_t seed, int64_t* __restrict__ counters, int64_t row_offset, int ref_scale,
+                                               const PpoActOut& o, int64_t row, int A, int lane) {
     const int64_t c = counters[row];
     float lp = 0.f;
     for (int j = lane; j < A; j += 64) {
@@ -156,20 +154,105 @@ __global__ void __launch_bounds__(256) ppo_act_kernel(const float* __restrict__ 
         if (ref_scale) { float sd = expf(ls); scale = sd * sd; lscale = logf(scale); }   // module.py:76: diag(exp * exp) as scale_tril
         else { scale = expf(ls); lscale = ls; }
         const float z = rand_normal(seed, (uint64_t)(row_offset + row), (uint64_t)c, (uint32_t)j);
-        const float m = mean[row * A + j];
+        const float m = mean_row[j];
         const float act = m + scale * z;
         lp += -0.5f * z * z - lscale - 0.9189385332046727f;
-        if (actions_out) actions_out[row * A + j] = act;
-        if (act_slot) act_slot[row * A + j] = act;
-        if (mu_slot) mu_slot[row * A + j] = m;
-        if (sigma_slot) sigma_slot[row * A + j] = ls;
+        if (o.actions_out) o.actions_out[row * A + j] = act;
+        if (o.act_slot) o.act_slot[row * A + j] = act;
+        if (o.mu_slot) o.mu_slot[row * A + j] = m;
+        if (o.sigma_slot) o.sigma_slot[row * A + j] = ls;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) lp += __shfl_xor(lp, m, 64);
     if (lane == 0) {
-        if (logp_slot) logp_slot[row] = lp;
-        if (value_slot && value) value_slot[row] = value[row];
+        if (o.logp_slot) o.logp_slot[row] = lp;
+        if (o.value_slot && value) o.value_slot[row] = value[row];
         counters[row] = c + 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) ppo_act_kernel(const float* __restrict__ mean, const float* __restrict__ value,
+                                                      const float* __restrict__ log_std, uint64_t seed, int64_t* __restrict__ counters,
+                                                      int64_t row_offset, int ref_scale, PpoActOut o, int64_t N, int A) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    ppo_sample_row(mean + row * A, value, log_std, seed, counters, row_offset, ref_scale, o, row, A, threadIdx.x & 63);
+}
+
+// The same with the actor's last Linear layer folded in: mean = hidden @ W^T + b on the matrix cores, then the sampling.
+// A block owns 16 rows; its WAVES (8 when H is a multiple of 512, else 4 / 2 / 1) waves split K = H evenly and each accumulates the 16 x A tile of its share with
+// v_mfma_f32_16x16x4_f32 (exact fp32 products and sums).  Operand lane map: lane l supplies A[l & 15][k = l >> 4] and
+// B[k = l >> 4][l & 15]; a lane loads 4 consecutive k of its row as one float4 and feeds four MFMAs from it, which only
+// permutes the order in which k is summed.  The partial sums meet in LDS, in wave order.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// NCT = number of 16-column tiles (compile time: the accumulators must be plain registers), A <= 16 NCT.
+// Rows past N and columns past A are computed from clamped (valid) addresses and never read back.
+template <int NCT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* __restrict__ hidden, const float* __restrict__ weight,
+                                                           const float* __restrict__ bias, int H, const float* __restrict__ value,
+                                                           const float* __restrict__ log_std, uint64_t seed, int64_t* __restrict__ counters,
+                                                           int64_t row_offset, int ref_scale, PpoActOut o, int64_t N, int A) {
+    extern __shared__ __attribute__((aligned(16))) float s_part[];      // [WAVES][16 rows][AP], then [16][AP] means
+    constexpr int AP = NCT * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    const int64_t row_a = r0 + i < N ? r0 + i : N - 1;
+    const float* hrow = hidden + row_a * (int64_t)H + 4 * g;
+    const float* wrow[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {
+        const int j = ct * 16 + i;
+        wrow[ct] = weight + (int64_t)(j < A ? j : A - 1) * H + 4 * g;
+    }
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kq = H / WAVES;
+    const int kbeg = wave * kq;
+    // 64 k per trip (the launcher picks WAVES so that H / WAVES is a multiple of 64): the 4 x (1 + NCT) float4 loads of a
+    // trip are issued together, then its 16 NCT MFMAs
+    for (int kc = kbeg; kc < kbeg + kq; kc += 64) {
+        float4 a[4], b[4][NCT];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            a[u] = *reinterpret_cast<const float4*>(hrow + kc + 16 * u);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++) b[u][ct] = *reinterpret_cast<const float4*>(wrow[ct] + kc + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u][ct].x, acc[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u][ct].y, acc[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u][ct].z, acc[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u][ct].w, acc[ct], 0, 0, 0);
+        }
+    }
+    // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+    float* mine = s_part + (size_t)wave * 16 * AP;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) mine[(4 * g + r) * AP + ct * 16 + i] = acc[ct][r];
+    }
+    __syncthreads();
+    float* s_mean = s_part + (size_t)WAVES * 16 * AP;
+    for (int e = threadIdx.x; e < 16 * AP; e += 64 * WAVES) {
+        const int j = e % AP;
+        float sum = s_part[e];
+#pragma unroll
+        for (int w = 1; w < WAVES; w++) sum += s_part[w * 16 * AP + e];      // wave order
+        s_mean[e] = sum + bias[j < A ? j : 0];
+    }
+    __syncthreads();
+    constexpr int RPW = 16 / WAVES;                                          // rows sampled per wave (WAVES in 1, 2, 4, 8)
+    for (int r = wave * RPW; r < wave * RPW + RPW; r++) {
+        const int64_t row = r0 + r;
+        if (row < N) ppo_sample_row(s_mean + r * AP, value, log_std, seed, counters, row_offset, ref_scale, o, row, A, lane);
     }
 }
 
@@ -203,8 +286,35 @@ hipError_t launch_ppo_act(const float* mean, const float* value, const float* lo
                           int ref_scale, float* actions_out, float* act_slot, float* logp_slot, float* value_slot, float* mu_slot,
                           float* sigma_slot, int64_t N, int A, hipStream_t s) {
     if (N == 0) return hipSuccess;
-    hipLaunchKernelGGL(ppo_act_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, mean, value, log_std, seed, counters, row_offset, ref_scale,
-                       actions_out, act_slot, logp_slot, value_slot, mu_slot, sigma_slot, N, A);
+    PpoActOut o{actions_out, act_slot, logp_slot, value_slot, mu_slot, sigma_slot};
+    hipLaunchKernelGGL(ppo_act_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, mean, value, log_std, seed, counters, row_offset, ref_scale, o, N, A);
+    return hipGetLastError();
+}
+hipError_t launch_ppo_head_act(const float* hidden, const float* weight, const float* bias, int H, const float* value, const float* log_std,
+                               uint64_t seed, int64_t* counters, int64_t row_offset, int ref_scale, float* actions_out, float* act_slot,
+                               float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N, int A, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    PpoActOut o{actions_out, act_slot, logp_slot, value_slot, mu_slot, sigma_slot};
+    const int nct = (A + 15) / 16;
+    const int waves = (H % 512 == 0) ? 8 : (H % 256 == 0) ? 4 : (H % 128 == 0) ? 2 : 1;      // H / waves is a multiple of 64
+    const size_t lds = (size_t)(waves + 1) * 16 * (nct * 16) * sizeof(float);
+    const dim3 grid((unsigned)((N + 15) / 16));
+#define MMS_HEAD_W(NCT, W)                                                                                                                        \
+    hipLaunchKernelGGL((ppo_head_act_kernel<NCT, W>), grid, dim3(64 * W), lds, s, hidden, weight, bias, H, value, log_std, seed, counters, row_offset, \
+                       ref_scale, o, N, A)
+#define MMS_HEAD(NCT)                                                                                                                              \
+    case NCT:                                                                                                                                      \
+        if (waves == 8) MMS_HEAD_W(NCT, 8);                                                                                                        \
+        else if (waves == 4) MMS_HEAD_W(NCT, 4);                                                                                                   \
+        else if (waves == 2) MMS_HEAD_W(NCT, 2);                                                                                                   \
+        else MMS_HEAD_W(NCT, 1);                                                                                                                   \
+        break;
+    switch (nct) {
+        MMS_HEAD(1) MMS_HEAD(2) MMS_HEAD(3) MMS_HEAD(4) MMS_HEAD(5) MMS_HEAD(6) MMS_HEAD(7) MMS_HEAD(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef MMS_HEAD
+#undef MMS_HEAD_W
     return hipGetLastError();
 }
 hipError_t launch_marl_views(const float* obs, float* obs_all, int64_t n, int agents, int per, int shared, hipStream_t s) {

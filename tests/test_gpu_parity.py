@@ -660,6 +660,45 @@ def test_ppo_act_kernel_vs_oracle(torch_cuda):
     assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
 
 
+def test_ppo_head_act_kernel(torch_cuda):
+    """mms_ppo_head_act: the actor's last Linear layer on the matrix cores (fp32 MFMA) + the sampling.  The mean against a
+    float64 product of the same operands, everything downstream of it against the oracle fed with the kernel's own mean."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    from oracle.oracle import fp, ip, lib as olib_
+    olib = olib_()
+    L = _lib.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(8)
+    for (N, H, A) in ((4096, 512, 80), (1003, 64, 8), (37, 256, 128), (16, 128, 1)):
+        hid = rng.standard_normal((N, H)).astype(np.float32)
+        W = (rng.standard_normal((A, H)) / np.sqrt(H)).astype(np.float32)
+        b = rng.standard_normal(A).astype(np.float32)
+        ls = np.linspace(-0.5, 0.1, A).astype(np.float32)
+        value = rng.standard_normal(N).astype(np.float32)
+        th, tw, tb, tl, tv = (torch.from_numpy(x).cuda() for x in (hid, W, b, ls, value))
+        counters = torch.zeros(N, dtype=torch.int64, device="cuda")
+        act, mu, sigma = (torch.zeros(N, A, device="cuda") for _ in range(3))
+        logp, val = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        _lib.check(L.mms_ppo_head_act(0, p(th), p(tw), p(tb), H, p(tv), p(tl), 77, p(counters), 5, 1, None, p(act), p(logp), p(val),
+                                      p(mu), p(sigma), N, A, stream), None, "mms_ppo_head_act")
+        torch.cuda.synchronize()
+        ref = hid.astype(np.float64) @ W.astype(np.float64).T + b
+        scale = np.abs(hid).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b)
+        assert np.max(np.abs(to_np(mu) - ref) / scale) < 4e-7, (N, H, A)          # fp32 products and sums, K <= 512
+        oc = np.zeros(N, np.int64)
+        oact, ologp, osig = np.zeros((N, A), np.float32), np.zeros(N, np.float32), np.zeros((N, A), np.float32)
+        kmu = np.ascontiguousarray(to_np(mu))
+        olib.mo_ppo_act(N, A, fp(kmu), fp(ls), ctypes.c_uint64(77), ip(oc), 5, 1, fp(oact), fp(ologp), fp(osig))
+        assert np.max(np.abs(to_np(act) - oact)) < 2e-5
+        assert np.max(np.abs(to_np(logp) - ologp)) < 2e-3 * (A / 80.0 + 1.0)
+        np.testing.assert_array_equal(to_np(val), value)
+        np.testing.assert_array_equal(to_np(counters), oc)
+    rc = L.mms_ppo_head_act(0, p(th), p(tw), p(tb), 100, p(tv), p(tl), 77, p(counters), 5, 1, None, p(act), p(logp), p(val), p(mu), p(sigma), N, A, stream)
+    assert rc != 0 and "multiple of 64" in _lib.last_error(None)
+
+
 def test_fused_act_and_bound_rollout(torch_cuda):
     """ActorCritic.act (fused tail) + RolloutStorage + engine, all zero-copy: slot t of the storage holds exactly what the
     reference's act -> step -> add_transitions sequence would have copied there."""
@@ -672,6 +711,7 @@ def test_fused_act_and_bound_rollout(torch_cuda):
     torch.manual_seed(0)
     ac = ActorCritic((388,), (0,), (80,), 0.8, {"pi_hid_sizes": [64, 64], "vf_hid_sizes": [64, 64], "activation": "elu"},
                      seed=11).cuda()
+    ac.fuse_head = True                                            # exercise mms_ppo_head_act through the module (H = 64)
     st = RolloutStorage(n, T, (388,), (0,), (80,), device="cuda:0")
     ac.bind_rollout(st, eng.tensor("actions"))
     states = torch.zeros(n, 0, device="cuda")
@@ -697,6 +737,15 @@ def test_fused_act_and_bound_rollout(torch_cuda):
         assert torch.equal(st.actions[t], actions) and torch.equal(st.actions_log_prob[t].view(-1), logp)
         cur = eng.tensor("obs_clipped").clone()
     assert st.step == T
+    # deferred critic: act returns before the value is there; after join() the slot holds the critic's output
+    st.clear()
+    ac.defer_value = True
+    _, _, values, _, _ = ac.act(st.observations[0], states)
+    ac.join()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        assert float((ac.critic(st.observations[0]) - values).abs().max()) < 1e-5
+    ac.defer_value = False
     z = (st.actions - st.mu) / torch.exp(2.0 * ac.log_std.detach())
     assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
     eng.bind_rollout_out(None, None)
