@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--defer-critic", action="store_true",
                     help="A/B: let the critic pass overlap the sampling kernel and the env step (joined before the GAE); faster, but "
                          "the step kernel then shares the GPU with GEMMs and its rocprof average no longer is its stand-alone duration")
+    ap.add_argument("--all-obs-rows", action="store_true", help="A/B: the step kernel also writes the engine's raw and clamped observation buffers in the rollout")
     ap.add_argument("--unfused", action="store_true", help="A/B: torch sampling + add_transitions copies instead of mms_ppo_act and bound rollout slots")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle steps for the CPU baseline (0 = sized for ~15 s)")
@@ -181,7 +182,10 @@ def main():
             if t == 0:
                 obs_t.copy_(obs_clipped)                                     # the first slot of a rollout: the current observation
             act, logp, value, mu, sigma = ac_.act(obs_t, states)             # module.py:73-87
-            eng.bind_obs_out(storage.observations[t + 1] if t + 1 < NSTEPS else None)
+            last = t + 1 == NSTEPS
+            eng.bind_obs_out(None if last else storage.observations[t + 1])
+            if not args.all_obs_rows:
+                eng.set_obs_outputs(raw=False, clipped=last)                 # one observation row per env-step, not three
             eng.bind_rollout_out(storage.rewards[t].view(-1), storage.dones[t].view(-1))
             eng.step()
             storage.add_transitions(obs_t, states, act, storage.rewards[t], storage.dones[t], value, logp, mu, sigma)
@@ -217,6 +221,7 @@ def main():
         rollout_step = rollout_step_unfused if args.unfused else rollout_step_fused
         eng.bind_obs_out(None)
         eng.bind_rollout_out(None, None)
+        eng.set_obs_outputs(True, True)
         storage.clear()
 
         graph = None
@@ -287,6 +292,7 @@ def main():
     graph = graphed or None
     eng.bind_obs_out(None)
     eng.bind_rollout_out(None, None)
+    eng.set_obs_outputs(True, True)
     kernel_ms_post = time_step_kernel()
     kernel_ms_b2b = 0.5 * (kernel_ms_pre + kernel_ms_post)
     kernel_ms_roll = in_rollout_ms[-1]

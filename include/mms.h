@@ -146,6 +146,12 @@ int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_ho
  * [T,N,obs_dim]; NULL disables.  The pointer must stay valid until the next bind. */
 int mms_bind_obs_out(mms_handle h, void* dst);
 
+/* Which of the engine-owned observation rows mms_step writes: "obs" (raw, = task.obs_buf of the reference) and "obs_clipped"
+ * (what VecTaskPython.step returns, vec_task.py:131).  Both on by default.  A rollout that binds a slot with mms_bind_obs_out
+ * needs neither while the slot is bound: one 1552-B row per env-step instead of three.  A row that is switched off keeps its
+ * last contents. */
+int mms_set_obs_outputs(mms_handle h, int32_t raw, int32_t clipped);
+
 /* Optional extra destinations for the step's reward (f32 [N]) and done flag (u8 [N], = reset_buf after the step), e.g.
  * RolloutStorage.rewards[t] / dones[t] (storage.py:40-41): add_transitions then has nothing left to copy for them.
  * NULL disables either.  Pointers must stay valid until the next bind. */

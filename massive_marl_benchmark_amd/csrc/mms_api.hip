@@ -40,6 +40,7 @@ struct mms_engine {
     mms_config* d_cfg = nullptr;
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
     float* obs_out = nullptr;
+    int write_raw_obs = 1, write_clipped_obs = 1;
     float* rew_out = nullptr;
     uint8_t* done_out = nullptr;
     int packing = 1;
@@ -219,8 +220,8 @@ static int do_step(mms_handle h, void* stream, int physics) {
     mms::StepArgs a{};
     a.cfg = h->d_cfg;
     a.actions = (const float*)find(h, "actions")->ptr;
-    a.obs = (float*)find(h, "obs")->ptr;
-    a.obs_clipped = (float*)find(h, "obs_clipped")->ptr;
+    a.obs = h->write_raw_obs ? (float*)find(h, "obs")->ptr : nullptr;
+    a.obs_clipped = h->write_clipped_obs ? (float*)find(h, "obs_clipped")->ptr : nullptr;
     a.obs_out = h->obs_out;
     a.rew_out = h->rew_out;
     a.done_out = h->done_out;
@@ -277,6 +278,13 @@ __attribute__((visibility("default"))) int mms_set_state(mms_handle h, const cha
 __attribute__((visibility("default"))) int mms_bind_obs_out(mms_handle h, void* dst) {
     if (!h) return fail(nullptr, "mms_bind_obs_out: null handle");
     h->obs_out = (float*)dst;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_set_obs_outputs(mms_handle h, int32_t raw, int32_t clipped) {
+    if (!h) return fail(nullptr, "mms_set_obs_outputs: null handle");
+    h->write_raw_obs = raw != 0;
+    h->write_clipped_obs = clipped != 0;
     return 0;
 }
 

@@ -376,8 +376,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
         const int e0 = blockIdx.x * EPB;
         const int n_live = min(EPB, a.num_envs - e0);
         const float clip = C->clip_obs;
-        float* obs = a.obs + (size_t)e0 * obs_dim;
-        float* obs_clip = a.obs_clipped + (size_t)e0 * obs_dim;
+        // each of the three destinations is optional (mms_set_obs_outputs / mms_bind_obs_out)
+        float* obs = a.obs ? a.obs + (size_t)e0 * obs_dim : nullptr;
+        float* obs_clip = a.obs_clipped ? a.obs_clipped + (size_t)e0 * obs_dim : nullptr;
         float* obs_out = a.obs_out ? a.obs_out + (size_t)e0 * obs_dim : nullptr;
         const float* rows = lds_envs + (s_obs - env_lds);
         if ((obs_dim & 3) == 0) {
@@ -385,18 +386,18 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             for (int i = threadIdx.x; i < n_live * q; i += BLOCK) {
                 const int e = EPB == 1 ? 0 : i / q, k = i - e * q;
                 float4 v = reinterpret_cast<const float4*>(rows + (size_t)e * env_stride)[k];
-                reinterpret_cast<float4*>(obs)[i] = v;
+                if (obs) reinterpret_cast<float4*>(obs)[i] = v;
                 float4 c = make_float4(clampf(v.x, -clip, clip), clampf(v.y, -clip, clip), clampf(v.z, -clip, clip), clampf(v.w, -clip, clip));
-                reinterpret_cast<float4*>(obs_clip)[i] = c;
+                if (obs_clip) reinterpret_cast<float4*>(obs_clip)[i] = c;
                 if (obs_out) reinterpret_cast<float4*>(obs_out)[i] = c;
             }
         } else {
             for (int i = threadIdx.x; i < n_live * obs_dim; i += BLOCK) {
                 const int e = EPB == 1 ? 0 : i / obs_dim, k = i - e * obs_dim;
                 float v = rows[(size_t)e * env_stride + k];
-                obs[i] = v;
+                if (obs) obs[i] = v;
                 float c = clampf(v, -clip, clip);
-                obs_clip[i] = c;
+                if (obs_clip) obs_clip[i] = c;
                 if (obs_out) obs_out[i] = c;
             }
         }
@@ -456,17 +457,17 @@ __global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; j++) dof[j] = dq[j];
         // obs = raw root states in the global frame (multi_ingenuity.py:351-357)
-        float* o = a.obs + (size_t)env * 13 * A + 13 * k;
-        float* oc = a.obs_clipped + (size_t)env * 13 * A + 13 * k;
+        float* o = a.obs ? a.obs + (size_t)env * 13 * A + 13 * k : nullptr;
+        float* oc = a.obs_clipped ? a.obs_clipped + (size_t)env * 13 * A + 13 * k : nullptr;
         float* oo = a.obs_out ? a.obs_out + (size_t)env * 13 * A + 13 * k : nullptr;
         float row[13];
         store_rigid(row, B);
         row[0] += a.env_origin[3 * env]; row[1] += a.env_origin[3 * env + 1]; row[2] += a.env_origin[3 * env + 2];
 #pragma unroll
         for (int j = 0; j < 13; j++) {
-            o[j] = row[j];
+            if (o) o[j] = row[j];
             float c = clampf(row[j], -C->clip_obs, C->clip_obs);
-            oc[j] = c;
+            if (oc) oc[j] = c;
             if (oo) oo[j] = c;
         }
     }

@@ -79,6 +79,11 @@ class Engine:
         self._bound = tensor_or_none          # keep it alive
         _lib.check(_lib.lib().mms_bind_obs_out(self._h, ptr), self._h, "mms_bind_obs_out")
 
+    def set_obs_outputs(self, raw=True, clipped=True):
+        """Which engine-owned observation rows the step writes ("obs", "obs_clipped"); a rollout that binds a slot with
+        bind_obs_out needs neither while the slot is bound."""
+        _lib.check(_lib.lib().mms_set_obs_outputs(self._h, int(bool(raw)), int(bool(clipped))), self._h, "mms_set_obs_outputs")
+
     def bind_rollout_out(self, rewards=None, dones=None):
         """Extra destinations for the step's reward (f32 [N]) and done flag (u8 [N]), e.g. RolloutStorage.rewards[t] /
         dones[t]; None disables either."""

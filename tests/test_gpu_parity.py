@@ -750,3 +750,37 @@ def test_fused_act_and_bound_rollout(torch_cuda):
     assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
     eng.bind_rollout_out(None, None)
     eng.close()
+
+
+def test_optional_observation_rows(torch_cuda):
+    """mms_set_obs_outputs: a switched-off engine row keeps its last contents, the bound slot and everything else still follow
+    the state; switching back on resumes."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.engine import Engine
+    for task, width in (("TenAnt", 388), ("MultiIngenuity", 52)):
+        n = 96
+        e1 = Engine(task, num_envs=n, device=0, seed=4)
+        e2 = Engine(task, num_envs=n, device=0, seed=4)
+        acts = [(torch.rand(n, e1.num_actions) * 2 - 1).cuda() for _ in range(3)]
+        slot = torch.zeros(n, width, device="cuda")
+        e2.bind_obs_out(slot)
+        for e in (e1, e2):
+            e.tensor("actions").copy_(acts[0])
+            e.step()
+        torch.cuda.synchronize()
+        kept_raw, kept_clip = e2.tensor("obs").clone(), e2.tensor("obs_clipped").clone()
+        e2.set_obs_outputs(raw=False, clipped=False)
+        for e in (e1, e2):
+            e.tensor("actions").copy_(acts[1])
+            e.step()
+        torch.cuda.synchronize()
+        assert torch.equal(e2.tensor("obs"), kept_raw) and torch.equal(e2.tensor("obs_clipped"), kept_clip)
+        assert torch.equal(slot, e1.tensor("obs_clipped")) and torch.equal(e1.tensor("rew"), e2.tensor("rew"))
+        e2.set_obs_outputs(raw=True, clipped=True)
+        for e in (e1, e2):
+            e.tensor("actions").copy_(acts[2])
+            e.step()
+        torch.cuda.synchronize()
+        assert torch.equal(e2.tensor("obs"), e1.tensor("obs")) and torch.equal(e2.tensor("obs_clipped"), e1.tensor("obs_clipped"))
+        e1.close()
+        e2.close()
