@@ -543,19 +543,25 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         SP->J2 = K.J2;
     }
     // ---- the torso body itself (lane 0 of the quad adds it once) ------------------------------------------------
+    // Its COM is the frame origin: the spatial inertia is block diagonal, (it 1 + (ia - it) u u^T, m 1), and the bias force is
+    // (w x Ic w, m w x v + m g z) -- the general routines with c = 0, minus the terms that are zero by construction.
     if (leg == 0) {
-        Sym6 It;
+        const V3 u = Rt.c2;
+        const float m = M->torso_mass, it = M->torso_ixx, d = M->torso_izz - M->torso_ixx;
+        IA0.m[sidx(0, 0)] += it + d * u.x * u.x; IA0.m[sidx(0, 1)] += d * u.x * u.y; IA0.m[sidx(0, 2)] += d * u.x * u.z;
+        IA0.m[sidx(1, 1)] += it + d * u.y * u.y; IA0.m[sidx(1, 2)] += d * u.y * u.z; IA0.m[sidx(2, 2)] += it + d * u.z * u.z;
+        IA0.m[sidx(3, 3)] += m; IA0.m[sidx(4, 4)] += m; IA0.m[sidx(5, 5)] += m;
+        const V3 n = it * v0.a + (d * dot(u, v0.a)) * u;          // Ic w
+        const V3 f = m * v0.l;
+        pA0.a = pA0.a + cross(v0.a, n);
+        pA0.l = pA0.l + (cross(v0.a, f) - V3{0.f, 0.f, -m * M->gravity});
         V3 zero = V3{0, 0, 0};
-        spatial_inertia_axisym(M->torso_mass, zero, Rt.c2, M->torso_izz, M->torso_ixx, It);
-        S6 pt = bias_force_axisym(v0, M->torso_mass, zero, Rt.c2, M->torso_izz, M->torso_ixx, M->gravity);
         Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, zero, M->torso_radius, v0);
-        contact_fold_ground(g, h, It, pt);
+        contact_fold_ground(g, h, IA0, pA0);
         if (P.near_box) {
             Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, zero, M->torso_radius, v0, box);
-            contact_fold_box(b, h, It, pt);
+            contact_fold_box(b, h, IA0, pA0);
         }
-        sym_add(IA0, It);
-        pA0 = pA0 + pt;
     }
 }
 
@@ -745,11 +751,9 @@ MMS_HD V3 quat_rotate(float x, float y, float z, float w, V3 v, float sign) {
     return V3{v.x * a + sign * (c.x * w * 2.0f) + x * d * 2.0f, v.y * a + sign * (c.y * w * 2.0f) + y * d * 2.0f,
               v.z * a + sign * (c.z * w * 2.0f) + z * d * 2.0f};
 }
-MMS_HD float wrap_2pi(float a) {
-    float r = fmodf(a, kTwoPi);
-    if (r < 0.f) r += kTwoPi;
-    return r;
-}
+// a % (2 pi) with the sign of the divisor (torch's %), for |a| < 2 pi -- every caller passes an atan2f result, for which
+// fmodf(a, 2 pi) returns a itself: the generic fmodf costs ~60 instructions on the GPU for nothing
+MMS_HD float wrap_2pi(float a) { return (a < 0.f) ? a + kTwoPi : a; }
 struct AntObsCore { V3 vel_loc, angvel_loc; float yaw, roll, angle_to_target, up_proj, heading_proj; };
 // p: GLOBAL position (local + env origin)
 MMS_HD AntObsCore ant_obs_core(V3 p, float x, float y, float z, float w, V3 vel, V3 ang) {
@@ -783,6 +787,16 @@ MMS_HD float l2_dist2(float ax, float ay, float bx, float by) {
     return sqrtf(c1 * c1 + c2 * c2);
 }
 MMS_HD float box_angle(float qz, float qw) { return atanf((2.f * qw * qz) / (1.f - 2.f * qz * qz)); }
+// (sin, -cos) of that angle (ten_ant.py:1353-1393 offsets the goals along it) without the trigonometry: the angle is
+// atan(t) in (-pi/2, pi/2), so sin = t / sqrt(1 + t^2) and cos = 1 / sqrt(1 + t^2); written on (num, den) so that
+// den = 0 (a quarter turn) gives (+-1, 0) like sin / cos of atan(+-inf)
+MMS_HD void box_yaw_dir(float qz, float qw, float& sv, float& cv) {
+    float num = 2.f * qw * qz, den = 1.f - 2.f * qz * qz;
+    float inv = 1.f / sqrtf(num * num + den * den);
+    float sgn = (den < 0.f) ? -1.f : 1.f;                  // atan(num / den): the sign of den folds into the quotient
+    sv = sgn * num * inv;
+    cv = -(sgn * den * inv);
+}
 MMS_HD float box_quat_dist(float qx, float qy, float qz, float qw) {
     float x = 2.f * (qx * qy + qw * qz), y = 1.f - 2.f * (qx * qx + qz * qz), z = 2.f * (qy * qz - qw * qx);
     float x1 = x * 0.f, y1 = y * 1.f, z1 = z * 0.f;

@@ -293,8 +293,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
         const float bgx = B.pos.x + origin.x, bgy = B.pos.y + origin.y;      // global frame
         s_epi[0] = bgx; s_epi[1] = bgy;
         if (TASK == MMS_TASK_TEN_ANT) {
-            const float ang = box_angle(B.qz, B.qw);
-            s_epi[2] = sinf(ang); s_epi[3] = -cosf(ang);
+            box_yaw_dir(B.qz, B.qw, s_epi[2], s_epi[3]);
             float* t = s_obs + 38 * A;
             t[0] = bgx; t[1] = bgy; t[2] = B.qx; t[3] = B.qy; t[4] = B.qz; t[5] = B.qw; t[6] = 0.f; t[7] = 0.f;
         }

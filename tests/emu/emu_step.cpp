@@ -118,7 +118,8 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
     float rew;
     int64_t rs;
     if (task == MMS_TASK_TEN_ANT) {
-        float ang = box_angle(B.qz, B.qw), sv = sinf(ang), cv = -cosf(ang);
+        float sv, cv;
+        box_yaw_dir(B.qz, B.qw, sv, cv);
         std::vector<TenAntLaneOut> o(nl);
         std::vector<float> newprev(prev_dim);
         for (int t = 0; t < nl; t++) {
