@@ -28,3 +28,16 @@ def angle_close(a, b, tol):
     """compare angles modulo 2*pi"""
     d = np.abs(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) + np.pi) % (2 * np.pi) - np.pi)
     return np.max(d) if d.size else 0.0
+
+
+def shove_ants_into_box(o, rng):
+    """Puts every ant of the oracle engine `o` against the +x face of its box, moving towards it: the ant-box contact
+    paths (narrow phase, rank-1 fold, reaction wrench on the box) are exercised from the next step on."""
+    A = o.num_agents
+    roots = o.tensor("root_states").reshape(o.num_envs, A + 1, 13)
+    box = roots[:, A, :]
+    half_x = 0.5
+    for k in range(A):
+        roots[:, k, 0] = box[:, 0] + half_x + rng.uniform(0.20, 0.45, o.num_envs).astype(np.float32)   # torso sphere r = 0.25: touching / overlapping
+        roots[:, k, 2] = rng.uniform(0.45, 0.75, o.num_envs).astype(np.float32)
+        roots[:, k, 7] = rng.uniform(-2.5, -0.5, o.num_envs).astype(np.float32)                         # vx towards the box

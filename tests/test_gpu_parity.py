@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import angle_close, load_golden
+from conftest import angle_close, load_golden, shove_ants_into_box
 
 pytestmark = pytest.mark.gpu
 
@@ -122,6 +122,69 @@ def test_teacher_forced_parity_vs_oracle(torch_cuda, task, n, steps):
     check_distribution(verr, perr)
     check_reward_flips(flips, n * steps)
     assert resets > 0 or n < 16
+    eng.close()
+
+
+@pytest.mark.parametrize("task,n", [("TenAnt", 10), ("OneAnt", 9)])
+def test_ant_box_contact_parity(torch_cuda, task, n):
+    """Teacher-forced parity while the ants are pressed against the box: narrow phase, rank-1 contact fold, per-ant reaction
+    sums through LDS and the box solve with a non-zero wrench.  The box must feel the ants (its x velocity goes negative)."""
+    torch = torch_cuda
+    kw = dict(num_envs=n, seed=11, total_envs=64, env_offset=7)
+    eng, ora = make_pair(task, **kw)
+    rng = np.random.default_rng(4)
+    zero = np.zeros((n, ora.num_actions), np.float32)
+    for _ in range(12):
+        ora.step(zero)
+    shove_ants_into_box(ora, rng)
+    verr, perr, flips, pushed = [], [], [], 0.0
+    A = ora.num_agents
+    for t in range(40):
+        push_state(torch, eng, ora)
+        act = rng.uniform(-1, 1, (n, ora.num_actions)).astype(np.float32)
+        eng.tensor("actions").copy_(torch.from_numpy(act).to(eng.device))
+        eng.step()
+        ora.step(act)
+        torch.cuda.synchronize()
+        compare_step(task, eng, ora, "%s contact step %d" % (task, t), verr, perr, flips)
+        pushed = min(pushed, float(ora.tensor("root_states").reshape(n, A + 1, 13)[:, A, 7].min()))
+        if t == 20:
+            shove_ants_into_box(ora, rng)
+    check_distribution(verr, perr)
+    assert pushed < -1e-3, pushed
+    eng.close()
+
+
+@pytest.mark.parametrize("task,n,agents", [("TenAnt", 1, 10), ("OneAnt", 1, 1), ("MultiIngenuity", 1, 4), ("TenAnt", 9, 2),
+                                            ("TenAnt", 5, 14), ("TenAnt", 3, 15), ("TenAnt", 2, 33)])
+def test_edge_shapes_and_timeouts(torch_cuda, task, n, agents):
+    """Single env, odd env counts, ant counts at the boundaries of the launch shapes (14 = the most one wave holds, 15 = the
+    first 512-thread shape), and the episode time-out: progress >= episodeLength - 1 raises the reset flag (ten_ant.py:1298)."""
+    torch = torch_cuda
+    kw = dict(num_envs=n, seed=2)
+    if task == "TenAnt":
+        kw["num_agents"] = agents
+    eng, ora = make_pair(task, **kw)
+    rng = np.random.default_rng(6)
+    verr, perr, flips = [], [], []
+    limit = int(ora.config.max_episode_length)
+    for t in range(24):
+        if t == 10:                                           # jump to the end of the episode
+            ora.tensor("progress")[...] = limit - 3
+        push_state(torch, eng, ora)
+        act = rng.uniform(-1, 1, (n, ora.num_actions)).astype(np.float32)
+        if task == "MultiIngenuity":
+            act[:, 2::3] = np.abs(act[:, 2::3]) * 0.12
+        eng.tensor("actions").copy_(torch.from_numpy(act).to(eng.device))
+        eng.step()
+        ora.step(act)
+        torch.cuda.synchronize()
+        compare_step(task, eng, ora, "%s A=%d step %d" % (task, agents, t), verr, perr, flips)
+        if t == 11:
+            assert int(ora.tensor("reset").min()) == 1        # progress reached limit - 1: every env times out
+        if t == 12:
+            assert int(ora.tensor("progress").max()) == 0     # ... and is reset on the following step
+    check_distribution(verr, perr)
     eng.close()
 
 

@@ -9,6 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from conftest import shove_ants_into_box
 from massive_marl_benchmark_amd.model import MmsConfig, make_config, task_dims
 from oracle.oracle import F, I64, OracleEngine, f32, fp, ip
 
@@ -136,6 +137,34 @@ def test_teacher_forced_parity(emu, task, n, steps):
     assert resets > 0 or task != "TenAnt"
 
 
+@pytest.mark.parametrize("task,n", [("TenAnt", 5), ("OneAnt", 6)])
+def test_ant_box_contact_parity(emu, task, n):
+    """Teacher-forced parity while ants are pressed against the box; the box must feel them (its x velocity goes negative)."""
+    kw = dict(num_envs=n, seed=11, total_envs=64, env_offset=7)
+    o = OracleEngine(task, **kw)
+    e = EmuEngine(emu, task, **kw)
+    rng = np.random.default_rng(4)
+    zero = f32(np.zeros((n, o.num_actions)))
+    for _ in range(12):                                    # reset, then let the box settle on the ground
+        o.step(zero)
+    shove_ants_into_box(o, rng)
+    verr, perr, flips, pushed = [], [], [], 0.0
+    A = o.num_agents
+    for t in range(40):
+        for name in STATE:
+            e.buf[name][...] = o.tensor(name)
+        act = f32(rng.uniform(-1, 1, (n, o.num_actions)))
+        o.step(act)
+        e.step(act)
+        compare(o, e, "%s contact step %d" % (task, t), verr, perr, flips)
+        box_vx = o.tensor("root_states").reshape(n, A + 1, 13)[:, A, 7]
+        pushed = min(pushed, float(box_vx.min()))
+        if t == 20:
+            shove_ants_into_box(o, rng)                    # again, from a different configuration
+    check_distribution(verr, perr)
+    assert pushed < -1e-3, pushed
+
+
 @pytest.mark.parametrize("task,n,steps", [("TenAnt", 4, 25), ("OneAnt", 4, 25), ("MultiIngenuity", 4, 60)])
 def test_free_running_parity(emu, task, n, steps):
     kw = dict(num_envs=n, seed=9)
@@ -157,7 +186,7 @@ def test_free_running_parity(emu, task, n, steps):
 
 def test_glue_fixture_through_lanes(emu):
     """The reference step-glue fixture through the lane code path (physics off)."""
-    from conftest import angle_close, load_golden
+    from conftest import shove_ants_into_box, angle_close, load_golden
     g = load_golden("tenant_step_glue")
     S, n = g["actions"].shape[0], g["actions"].shape[1]
     e = EmuEngine(emu, "TenAnt", num_envs=n, clip_obs=5.0, external_noise=True)
