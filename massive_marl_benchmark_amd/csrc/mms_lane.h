@@ -445,6 +445,18 @@ struct LegPass {
 };
 // extra state for the foot force sensors (OneAnt only)
 struct SensorPass { Contact tip_g, tip_b; M3 Rf; V3 J2; };
+// Where a lane parks the joint axes and velocity-product terms (s1, s2, c1, c2: 24 floats) between its two passes instead
+// of evaluating the kinematics again: six 16-B words at `base[k * stride]` (LDS in the step kernel, lane-interleaved so that
+// the accesses are conflict free).  base == nullptr: evaluate again (the host emulation, which has no such scratch).
+struct KinPark { float* base; int stride; };
+MMS_HD void park_store(const KinPark& pk, int k, float a, float b, float c, float d) {
+    float* p = pk.base + (size_t)k * pk.stride;
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+}
+MMS_HD void park_load(const KinPark& pk, int k, float& a, float& b, float& c, float& d) {
+    const float* p = pk.base + (size_t)k * pk.stride;
+    a = p[0]; b = p[1]; c = p[2]; d = p[3];
+}
 
 // joint torque with linearly-implicit damping and limits: returns tau, adds to De
 MMS_HD float joint_tau(const mms_model* M, float h, float q, float qd, float lo, float hi, float motor, float& De) {
@@ -472,13 +484,21 @@ MMS_HD float ant_reach(const mms_model* M, const LegConst& L) {
 // articulated inertia; lane l == 0 also adds the torso body itself and the torso sphere contacts.
 template <bool SENSORS>
 MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const AntLane& S, int leg, float tau1, float tau2,
-                       bool has_box, const BoxPose& box, LegPass& P, SensorPass* SP, Sym6& IA0, S6& pA0) {
+                       bool has_box, const BoxPose& box, LegPass& P, SensorPass* SP, Sym6& IA0, S6& pA0, const KinPark& park = KinPark{nullptr, 0}) {
     M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
     V3 Ow = S.pos;
     S6 v0 = S6{S.ang, S.vel};
     sincos_joint(S.q[0], P.sc[0], P.sc[1]);
     sincos_joint(S.q[1], P.sc[2], P.sc[3]);
     LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
+    if (park.base) {
+        park_store(park, 0, K.s1.a.x, K.s1.a.y, K.s1.a.z, K.s1.l.x);
+        park_store(park, 1, K.s1.l.y, K.s1.l.z, K.s2.a.x, K.s2.a.y);
+        park_store(park, 2, K.s2.a.z, K.s2.l.x, K.s2.l.y, K.s2.l.z);
+        park_store(park, 3, K.c1.a.x, K.c1.a.y, K.c1.a.z, K.c1.l.x);
+        park_store(park, 4, K.c1.l.y, K.c1.l.z, K.c2.a.x, K.c2.a.y);
+        park_store(park, 5, K.c2.a.z, K.c2.l.x, K.c2.l.y, K.c2.l.z);
+    }
     P.near_box = has_box && ant_near_box(Ow, box, ant_reach(M, L));
     // ---- foot body: inertia, bias force, tip contacts, joint 2 -------------------------------------------------
     Sym6 IAf;
@@ -567,12 +587,12 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
 
 // Phase B (after the quad reduction): root solve, outward pass, contact forces, integration.
 // `wrench` returns this lane's reaction on the box; `sens` the foot sensor (force, torque) in the foot frame.
-// The kinematics and the (rare) box contacts are evaluated again from the unchanged state: bit-identical to the
-// inward pass, and it keeps only 16 values per lane alive across the reduction and the solve (the register count
-// decides whether the whole 4096-env grid is resident at once).
+// The joint axes and velocity products come back from the lane's parking space (or are evaluated again from the unchanged
+// state: bit-identical), the (rare) box contacts are evaluated again: only 20 values per lane stay in registers across the
+// reduction and the solve (the register count decides whether the whole 4096-env grid is resident at once).
 template <bool SENSORS>
 MMS_HD void leg_outward(const mms_model* M, const LegConst& L, float h, AntLane& S, int leg, const BoxPose& box, const LegPass& P,
-                        const SensorPass* SP, const Sym6& IA0, S6 pA0, S6& wrench, float* sens) {
+                        const SensorPass* SP, const Sym6& IA0, S6 pA0, S6& wrench, float* sens, const KinPark& park = KinPark{nullptr, 0}) {
     S6 rhs = S6{V3{-pA0.a.x, -pA0.a.y, -pA0.a.z}, V3{-pA0.l.x, -pA0.l.y, -pA0.l.z}};
     S6 a0 = solve6(IA0, rhs);
     MMS_REG_FENCE(S.pos.x); MMS_REG_FENCE(S.pos.y); MMS_REG_FENCE(S.pos.z);
@@ -581,17 +601,30 @@ MMS_HD void leg_outward(const mms_model* M, const LegConst& L, float h, AntLane&
     MMS_REG_FENCE(S.ang.x); MMS_REG_FENCE(S.ang.y); MMS_REG_FENCE(S.ang.z);
     MMS_REG_FENCE(S.q[0]); MMS_REG_FENCE(S.q[1]); MMS_REG_FENCE(S.qd[0]); MMS_REG_FENCE(S.qd[1]);
     MMS_MEM_FENCE();
-    M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
-    LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
+    S6 s1, s2, c1, c2;
+    if (park.base) {
+        park_load(park, 0, s1.a.x, s1.a.y, s1.a.z, s1.l.x);
+        park_load(park, 1, s1.l.y, s1.l.z, s2.a.x, s2.a.y);
+        park_load(park, 2, s2.a.z, s2.l.x, s2.l.y, s2.l.z);
+        park_load(park, 3, c1.a.x, c1.a.y, c1.a.z, c1.l.x);
+        park_load(park, 4, c1.l.y, c1.l.z, c2.a.x, c2.a.y);
+        park_load(park, 5, c2.a.z, c2.l.x, c2.l.y, c2.l.z);
+    } else {
+        M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
+        LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
+        s1 = K.s1; s2 = K.s2; c1 = K.c1; c2 = K.c2;
+    }
     V3 Ow = S.pos;
-    S6 al = a0 + K.c1;
+    S6 al = a0 + c1;
     float qdd1 = (P.u1 - dot(P.U1, al)) / P.D1;
-    al = al + qdd1 * K.s1;
-    S6 af = al + K.c2;
+    al = al + qdd1 * s1;
+    S6 af = al + c2;
     float qdd2 = (P.u2 - dot(P.U2, af)) / P.D2;
-    af = af + qdd2 * K.s2;
+    af = af + qdd2 * s2;
     wrench = S6{V3{0, 0, 0}, V3{0, 0, 0}};
     if (P.near_box) {
+        M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);          // rare: the full kinematics again for the contact points
+        LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
         S6 v0 = S6{S.ang, S.vel};
         Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box);
         box_reaction(b, h, Ow, box, al, wrench);

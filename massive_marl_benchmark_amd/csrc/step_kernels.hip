@@ -129,6 +129,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     constexpr int kBoxOff = 0, kBpOff = 16, kWtotOff = kBpOff + (int)((sizeof(BoxPose) + 15) / 16 * 4), kEpiOff = kWtotOff + 8, kRedOff = kEpiOff + 8;
     const size_t env_stride = (ant_env_lds_floats(obs_dim, A) + 3) & ~(size_t)3;
     float* lds_envs = lds + (4 * sizeof(LegConst) + 15) / 16 * 4;
+    // behind the env blocks: six 16-B words per lane where a leg lane parks its joint axes between the two passes of a substep
+    const KinPark park{lds_envs + (size_t)EPB * ((ant_env_lds_floats(AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim, A) + 3) & ~(size_t)3) + 4 * threadIdx.x,
+                       4 * BLOCK};
     float* env_lds = lds_envs + (size_t)e_loc * env_stride;
     float* s_box = env_lds + kBoxOff;              // [16] box rigid state (home of the box between phases)
     BoxPose* s_bp = reinterpret_cast<BoxPose*>(env_lds + kBpOff);
@@ -206,10 +209,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             if (is_ant && simulate) {
                 const float tau1 = s_act[0] * L.gear[0] * C->power_scale;    // ten_ant.py:889
                 const float tau2 = s_act[1] * L.gear[1] * C->power_scale;
-                leg_inward<kSensors>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0);
+                leg_inward<kSensors>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0, park);
             } else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
             quad_sum(IA0, pA0);
-            if (is_ant && simulate) leg_outward<kSensors>(M, L, h, S, leg, *s_bp, P, &SP, IA0, pA0, wr, sens);
+            if (is_ant && simulate) leg_outward<kSensors>(M, L, h, S, leg, *s_bp, P, &SP, IA0, pA0, wr, sens, park);
             return wr;
         };
         // envs straddle waves: per-ant sums of the reactions (DPP) into LDS
@@ -501,7 +504,8 @@ __global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
 // ---- launchers ---------------------------------------------------------------------------------
 template <int TASK, int BLOCK, int EPB, int AT>
 static hipError_t launch_ant(const StepArgs& a, hipStream_t stream) {
-    size_t lds = (4 * sizeof(LegConst) + 15) / 16 * 16 + (size_t)EPB * ((ant_env_lds_floats(a.obs_dim, a.num_agents) + 3) & ~(size_t)3) * sizeof(float);
+    size_t lds = (4 * sizeof(LegConst) + 15) / 16 * 16 + (size_t)EPB * ((ant_env_lds_floats(a.obs_dim, a.num_agents) + 3) & ~(size_t)3) * sizeof(float) +
+                 (size_t)6 * 4 * BLOCK * sizeof(float);          // + the kinematics parking space
     int grid = (a.num_envs + EPB - 1) / EPB;
     hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT>), dim3(grid), dim3(BLOCK), lds, stream, a);
     return hipGetLastError();
