@@ -215,8 +215,7 @@ __attribute__((visibility("default"))) int mms_get_tensor(mms_handle h, const ch
     return 0;
 }
 
-static int do_step(mms_handle h, void* stream, int physics) {
-    if (!h) return fail(nullptr, "mms_step: null handle");
+static mms::StepArgs step_args(mms_handle h, int physics) {
     mms::StepArgs a{};
     a.cfg = h->d_cfg;
     a.actions = (const float*)find(h, "actions")->ptr;
@@ -242,6 +241,12 @@ static int do_step(mms_handle h, void* stream, int physics) {
     a.obs_dim = h->obs_dim;
     a.prev_dim = h->prev_dim;
     a.packing = h->packing;
+    return a;
+}
+
+static int do_step(mms_handle h, void* stream, int physics) {
+    if (!h) return fail(nullptr, "mms_step: null handle");
+    mms::StepArgs a = step_args(h, physics);
     MMS_HIP(h, mms::launch_step(a, h->cfg.task, (hipStream_t)stream));
     return 0;
 }
