@@ -26,6 +26,8 @@
  *     (algorithms/marl/utils/separated_buffer.py:153-164)
  *   MultiVecTaskPython.step slicing (agent_base/multi_vec_task.py:       mms_marl_views
  *     105-142)
+ *   apply_randomizations actor_params: set_actor_rigid_body_properties   mms_set_dr + "dr_params"
+ *     / set_actor_dof_properties (base_task.py:343-395)
  *   ActorCritic.act sampling tail + RolloutStorage.add_transitions       mms_ppo_act,
  *     (algorithms/rl/ppo/module.py:73-87; storage.py:33-47)              mms_bind_rollout_out
  *
@@ -46,6 +48,7 @@ extern "C" {
 #endif
 
 #define MMS_ABI_VERSION 1
+#define MMS_DR_FLOATS 33       /* per-ant physical domain-randomisation block, see mms_set_dr */
 
 enum mms_task { MMS_TASK_TEN_ANT = 0, MMS_TASK_ONE_ANT = 1, MMS_TASK_MULTI_INGENUITY = 2 };
 enum mms_dtype { MMS_F32 = 0, MMS_I64 = 1, MMS_I32 = 2, MMS_U8 = 3 };
@@ -120,6 +123,7 @@ int mms_destroy(mms_handle h);
  * "progress" [N] i64, "root_states" [N*actors,13] f32 (env-local frame), "dof_state" [N*dofs,2] f32,
  * "env_origin" [N,3] f32, "prev" [N,prev_dim] f32 (pos_before / goal_before / box_before caches),
  * "reset_noise" [N,16] f32, "foot_sensors" [N*A,24] f32, "initial_root_states" [N*actors,13] f32,
+ * "dr_params" [N*A,MMS_DR_FLOATS] f32 (see mms_set_dr),
  * "reset_count" [N] i64 (number of resets of each env so far: the counter of the reset-noise RNG, keyed with
  * the seed and the GLOBAL env index, so results do not depend on how envs are sharded over GPUs). */
 int mms_get_tensor(mms_handle h, const char* name, mms_tensor* out);
@@ -145,6 +149,15 @@ int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_ho
 /* Optional extra destination for the clamped observation row, e.g. slot t of a rollout buffer
  * [T,N,obs_dim]; NULL disables.  The pointer must stay valid until the next bind. */
 int mms_bind_obs_out(mms_handle h, void* dst);
+
+/* Physical domain randomisation of the ants (cfg/TenAnt.yaml:97-122 actor_params, applied by base_task.py:343-395 through
+ * set_actor_rigid_body_properties / set_actor_dof_properties).  The caller fills "dr_params" [N*A, MMS_DR_FLOATS] per ant:
+ *   [0] torso, [1..4] leg, [5..8] foot mass scale (the inertia scales with the mass: recomputeInertia is the setter's default),
+ *   [9..16] joint damping scale, [17..24] lower-limit offset, [25..32] upper-limit offset (rad), joints in DOF order;
+ * mms_set_dr(h, 1) makes mms_step use it (a separate kernel instantiation: the nominal path carries none of it).  The
+ * observations keep the nominal limits, as the reference's do (ten_ant.py:588-599 reads them once at construction).
+ * DOF stiffness is not a parameter of this path: the tasks drive the joints in effort mode (ten_ant.py:274). */
+int mms_set_dr(mms_handle h, int32_t enable);
 
 /* Which of the engine-owned observation rows mms_step writes: "obs" (raw, = task.obs_buf of the reference) and "obs_clipped"
  * (what VecTaskPython.step returns, vec_task.py:131).  Both on by default.  A rollout that binds a slot with mms_bind_obs_out

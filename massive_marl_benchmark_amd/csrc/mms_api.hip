@@ -41,6 +41,7 @@ struct mms_engine {
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
     float* obs_out = nullptr;
     int write_raw_obs = 1, write_clipped_obs = 1;
+    int dr_enabled = 0;
     float* rew_out = nullptr;
     uint8_t* done_out = nullptr;
     int packing = 1;
@@ -127,6 +128,7 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
     rc |= add_buffer(e, "prev", MMS_F32, {N, e->prev_dim}, 1);
     rc |= add_buffer(e, "reset_noise", MMS_F32, {N, 16}, 1);
     rc |= add_buffer(e, "foot_sensors", MMS_F32, {(int64_t)N * A, 24}, 1);
+    rc |= add_buffer(e, "dr_params", MMS_F32, {(int64_t)N * A, MMS_DR_FLOATS}, 1);
     if (rc) { g_create_error = e->err; mms_destroy(e); return 1; }
 
     // construction-time scene (host), uploaded once
@@ -183,6 +185,12 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
     up("env_origin", origin.data(), origin.size() * 4);
     up("prev", prev.data(), prev.size() * 4);
     up("reset", ones.data(), ones.size() * 8);                                   // base_task.py:62-63
+    {
+        std::vector<float> dr((size_t)N * A * MMS_DR_FLOATS, 0.f);               // nominal: scales 1, limit offsets 0
+        for (size_t k = 0; k < (size_t)N * A; k++)
+            for (int j = 0; j < 17; j++) dr[k * MMS_DR_FLOATS + j] = 1.f;
+        up("dr_params", dr.data(), dr.size() * 4);
+    }
     if (he == hipSuccess) he = hipMalloc((void**)&e->d_cfg, sizeof(mms_config));
     if (he == hipSuccess) he = hipMemcpy(e->d_cfg, &e->cfg, sizeof(mms_config), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipDeviceSynchronize();
@@ -235,6 +243,7 @@ static mms::StepArgs step_args(mms_handle h, int physics) {
     a.reset_noise = (const float*)find(h, "reset_noise")->ptr;
     a.foot_sensors = (float*)find(h, "foot_sensors")->ptr;
     a.reset_count = (int64_t*)find(h, "reset_count")->ptr;
+    a.dr = h->dr_enabled ? (const float*)find(h, "dr_params")->ptr : nullptr;
     a.do_physics = physics;
     a.num_envs = h->cfg.num_envs;
     a.num_agents = h->cfg.num_agents;
@@ -283,6 +292,13 @@ __attribute__((visibility("default"))) int mms_set_state(mms_handle h, const cha
 __attribute__((visibility("default"))) int mms_bind_obs_out(mms_handle h, void* dst) {
     if (!h) return fail(nullptr, "mms_bind_obs_out: null handle");
     h->obs_out = (float*)dst;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_set_dr(mms_handle h, int32_t enable) {
+    if (!h) return fail(nullptr, "mms_set_dr: null handle");
+    if (enable && h->cfg.task == MMS_TASK_MULTI_INGENUITY) return fail(h, "mms_set_dr: the helicopter task has no randomised physical parameters");
+    h->dr_enabled = enable != 0;
     return 0;
 }
 

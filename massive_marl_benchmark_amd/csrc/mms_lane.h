@@ -449,6 +449,18 @@ struct SensorPass { Contact tip_g, tip_b; M3 Rf; V3 J2; };
 // of evaluating the kinematics again: six 16-B words at `base[k * stride]` (LDS in the step kernel, lane-interleaved so that
 // the accesses are conflict free).  base == nullptr: evaluate again (the host emulation, which has no such scratch).
 struct KinPark { float* base; int stride; };
+// Per-lane slice of an ant's physical domain-randomisation block (mms.h: MMS_DR_FLOATS; oracle ant_substep): mass scales of
+// the torso and of this lane's leg / foot (inertia scales with the mass), damping scale and limit offsets of its two joints.
+// Lives in LDS in the step kernel and is read at the point of use.
+struct LegDR { float m_torso, m_leg, m_foot, damp[2], lo[2], hi[2]; };
+MMS_HD LegDR load_leg_dr(const float* ant_block, int leg) {
+    LegDR d;
+    d.m_torso = ant_block[0]; d.m_leg = ant_block[1 + leg]; d.m_foot = ant_block[5 + leg];
+    for (int j = 0; j < 2; j++) {
+        d.damp[j] = ant_block[9 + 2 * leg + j]; d.lo[j] = ant_block[17 + 2 * leg + j]; d.hi[j] = ant_block[25 + 2 * leg + j];
+    }
+    return d;
+}
 MMS_HD void park_store(const KinPark& pk, int k, float a, float b, float c, float d) {
     float* p = pk.base + (size_t)k * pk.stride;
     p[0] = a; p[1] = b; p[2] = c; p[3] = d;
@@ -459,9 +471,9 @@ MMS_HD void park_load(const KinPark& pk, int k, float& a, float& b, float& c, fl
 }
 
 // joint torque with linearly-implicit damping and limits: returns tau, adds to De
-MMS_HD float joint_tau(const mms_model* M, float h, float q, float qd, float lo, float hi, float motor, float& De) {
-    float t = motor - M->joint_damping * qd;
-    De = M->armature + h * M->joint_damping;
+MMS_HD float joint_tau(const mms_model* M, float h, float q, float qd, float lo, float hi, float motor, float& De, float damping) {
+    float t = motor - damping * qd;
+    De = M->armature + h * damping;
     float ehi = q - hi, elo = lo - q;
     float whi = ramp01(fmaxf(ehi, ehi + h * qd), M->limit_ramp), wlo = ramp01(fmaxf(elo, elo - h * qd), M->limit_ramp);
     if (whi > 0.f) {
@@ -482,9 +494,10 @@ MMS_HD float ant_reach(const mms_model* M, const LegConst& L) {
 
 // Phase A (inward pass of one leg chain).  Returns this lane's contribution (Ia, pa) to the torso's
 // articulated inertia; lane l == 0 also adds the torso body itself and the torso sphere contacts.
-template <bool SENSORS>
+template <bool SENSORS, bool DR = false>
 MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const AntLane& S, int leg, float tau1, float tau2,
-                       bool has_box, const BoxPose& box, LegPass& P, SensorPass* SP, Sym6& IA0, S6& pA0, const KinPark& park = KinPark{nullptr, 0}) {
+                       bool has_box, const BoxPose& box, LegPass& P, SensorPass* SP, Sym6& IA0, S6& pA0, const KinPark& park = KinPark{nullptr, 0},
+                       const LegDR* dr = nullptr) {
     M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
     V3 Ow = S.pos;
     S6 v0 = S6{S.ang, S.vel};
@@ -503,8 +516,9 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
     // ---- foot body: inertia, bias force, tip contacts, joint 2 -------------------------------------------------
     Sym6 IAf;
     V3 cf = K.J2 + (0.5f * M->foot_len) * K.uf;
-    spatial_inertia_axisym(M->foot_mass, cf, K.uf, M->foot_ia, M->foot_it, IAf);
-    S6 pAf = bias_force_axisym(K.vf, M->foot_mass, cf, K.uf, M->foot_ia, M->foot_it, M->gravity);
+    const float mf = DR ? dr->m_foot : 1.f;
+    spatial_inertia_axisym(M->foot_mass * mf, cf, K.uf, M->foot_ia * mf, M->foot_it * mf, IAf);
+    S6 pAf = bias_force_axisym(K.vf, M->foot_mass * mf, cf, K.uf, M->foot_ia * mf, M->foot_it * mf, M->gravity);
     {
         Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf);
         contact_fold_ground(g, h, IAf, pAf);
@@ -516,7 +530,8 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         }
     }
     float De1, De2;
-    float t2 = joint_tau(M, h, S.q[1], S.qd[1], L.lower[1], L.upper[1], tau2, De2);
+    float t2 = DR ? joint_tau(M, h, S.q[1], S.qd[1], L.lower[1] + dr->lo[1], L.upper[1] + dr->hi[1], tau2, De2, M->joint_damping * dr->damp[1])
+                  : joint_tau(M, h, S.q[1], S.qd[1], L.lower[1], L.upper[1], tau2, De2, M->joint_damping);
     P.U2 = sym_mul(IAf, K.s2);
     P.D2 = De2 + dot(K.s2, P.U2);
     P.u2 = t2 - dot(K.s2, pAf);
@@ -530,8 +545,9 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
     // ---- leg body: inertia, bias force, hip / knee contacts, joint 1 -------------------------------------------
     Sym6 IAl;
     V3 cl = K.J1 + (0.5f * M->leg_len) * K.ul;
-    spatial_inertia_axisym(M->leg_mass, cl, K.ul, M->leg_ia, M->leg_it, IAl);
-    S6 pAl = bias_force_axisym(K.vl, M->leg_mass, cl, K.ul, M->leg_ia, M->leg_it, M->gravity);
+    const float ml = DR ? dr->m_leg : 1.f;
+    spatial_inertia_axisym(M->leg_mass * ml, cl, K.ul, M->leg_ia * ml, M->leg_it * ml, IAl);
+    S6 pAl = bias_force_axisym(K.vl, M->leg_mass * ml, cl, K.ul, M->leg_ia * ml, M->leg_it * ml, M->gravity);
     sym_add(IAl, IAf);                                     // the foot's articulated inertia joins before the leg's contacts are
     pAl = pAl + pa_f;                                      // folded in: 27 fewer live values at the register-pressure peak
     {
@@ -546,7 +562,8 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
             contact_fold_box(b, h, IAl, pAl);
         }
     }
-    float t1 = joint_tau(M, h, S.q[0], S.qd[0], L.lower[0], L.upper[0], tau1, De1);
+    float t1 = DR ? joint_tau(M, h, S.q[0], S.qd[0], L.lower[0] + dr->lo[0], L.upper[0] + dr->hi[0], tau1, De1, M->joint_damping * dr->damp[0])
+                  : joint_tau(M, h, S.q[0], S.qd[0], L.lower[0], L.upper[0], tau1, De1, M->joint_damping);
     P.U1 = sym_mul(IAl, K.s1);
     P.D1 = De1 + dot(K.s1, P.U1);
     P.u1 = t1 - dot(K.s1, pAl);
@@ -567,7 +584,8 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
     // (w x Ic w, m w x v + m g z) -- the general routines with c = 0, minus the terms that are zero by construction.
     if (leg == 0) {
         const V3 u = Rt.c2;
-        const float m = M->torso_mass, it = M->torso_ixx, d = M->torso_izz - M->torso_ixx;
+        const float mt = DR ? dr->m_torso : 1.f;
+        const float m = M->torso_mass * mt, it = M->torso_ixx * mt, d = (M->torso_izz - M->torso_ixx) * mt;
         IA0.m[sidx(0, 0)] += it + d * u.x * u.x; IA0.m[sidx(0, 1)] += d * u.x * u.y; IA0.m[sidx(0, 2)] += d * u.x * u.z;
         IA0.m[sidx(1, 1)] += it + d * u.y * u.y; IA0.m[sidx(1, 2)] += d * u.y * u.z; IA0.m[sidx(2, 2)] += it + d * u.z * u.z;
         IA0.m[sidx(3, 3)] += m; IA0.m[sidx(4, 4)] += m; IA0.m[sidx(5, 5)] += m;

@@ -25,6 +25,7 @@ struct StepArgs {
     const float* reset_noise;         // [N, 16]
     float* foot_sensors;              // [N * A, 24]
     int64_t* reset_count;             // [N] resets so far (RNG counter)
+    const float* dr;                  // [N * A, MMS_DR_FLOATS] physical domain randomisation, or null (nominal model)
     int32_t do_physics;
     int32_t num_envs, num_agents, obs_dim, prev_dim;
     int32_t packing;                  // 1: several envs per workgroup where the lane counts allow (default), 0: one env per workgroup

@@ -103,7 +103,9 @@ __host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
 #define MMS_WAVES_PER_EU_PACKED 3
 #endif
 // AT > 0 fixes the number of ants at compile time (LDS offsets become immediates, the per-ant loops unroll); 0 = runtime.
-template <int TASK, int BLOCK, int EPB, int AT>
+// DR: per-env physical domain randomisation (mass / damping scales, limit offsets) read from a.dr; a separate instantiation so
+// that the nominal kernel carries none of it.
+template <int TASK, int BLOCK, int EPB, int AT, bool DR>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK == 192 ? MMS_WAVES_PER_EU_PACKED : 1)) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const mms_config* __restrict__ C = a.cfg;
@@ -135,8 +137,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
     const size_t env_stride = (ant_env_lds_floats(obs_dim, A) + 3) & ~(size_t)3;
     float* lds_envs = lds + (4 * sizeof(LegConst) + 15) / 16 * 4;
     // behind the env blocks: six 16-B words per lane where a leg lane parks its joint axes between the two passes of a substep
-    const KinPark park{lds_envs + (size_t)EPB * ((ant_env_lds_floats(AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim, A) + 3) & ~(size_t)3) + 4 * threadIdx.x,
-                       4 * BLOCK};
+    float* lds_lanes = lds_envs + (size_t)EPB * ((ant_env_lds_floats(AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim, A) + 3) & ~(size_t)3);
+    const KinPark park{lds_lanes + 4 * threadIdx.x, 4 * BLOCK};
+    LegDR* s_dr = reinterpret_cast<LegDR*>(lds_lanes + 6 * 4 * BLOCK) + threadIdx.x;     // (DR kernels only) this lane's slice
     float* env_lds = lds_envs + (size_t)e_loc * env_stride;
     float* s_box = env_lds + kBoxOff;              // [16] box rigid state (home of the box between phases)
     BoxPose* s_bp = reinterpret_cast<BoxPose*>(env_lds + kBpOff);
@@ -170,6 +173,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
         float4 d = reinterpret_cast<const float4*>(a.dof_state + (size_t)env * A * 16)[tid];   // (q1, qd1, q2, qd2): coalesced 16 B / lane
         S.q[0] = d.x; S.qd[0] = d.y; S.q[1] = d.z; S.qd[1] = d.w;
         ac = reinterpret_cast<const float2*>(a.actions + (size_t)env * A * 8)[tid];             // this lane's two actions
+        if (DR) *s_dr = load_leg_dr(a.dr + ((size_t)env * A + ant) * MMS_DR_FLOATS, leg);       // read back by this lane only
     }
     // the config block (~0.5 KB, read through the scalar cache all over the kernel): one lane per 64-B line touches it now, so
     // that the later scalar loads find it in L2
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             if (is_ant && simulate) {
                 const float tau1 = s_act[0] * L.gear[0] * C->power_scale;    // ten_ant.py:889
                 const float tau2 = s_act[1] * L.gear[1] * C->power_scale;
-                leg_inward<kSensors>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0, park);
+                leg_inward<kSensors, DR>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0, park, s_dr);
             } else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
             quad_sum(IA0, pA0);
             if (is_ant && simulate) leg_outward<kSensors>(M, L, h, S, leg, *s_bp, P, &SP, IA0, pA0, wr, sens, park);
@@ -525,7 +529,12 @@ static hipError_t launch_ant(const StepArgs& a, hipStream_t stream) {
     size_t lds = (4 * sizeof(LegConst) + 15) / 16 * 16 + (size_t)EPB * ((ant_env_lds_floats(a.obs_dim, a.num_agents) + 3) & ~(size_t)3) * sizeof(float) +
                  (size_t)6 * 4 * BLOCK * sizeof(float);          // + the kinematics parking space
     int grid = (a.num_envs + EPB - 1) / EPB;
-    hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    if (a.dr) {
+        lds += (size_t)BLOCK * sizeof(LegDR);
+        hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, true>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, false>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    }
     return hipGetLastError();
 }
 

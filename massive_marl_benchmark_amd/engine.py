@@ -84,6 +84,10 @@ class Engine:
         bind_obs_out needs neither while the slot is bound."""
         _lib.check(_lib.lib().mms_set_obs_outputs(self._h, int(bool(raw)), int(bool(clipped))), self._h, "mms_set_obs_outputs")
 
+    def set_dr(self, enable=True):
+        """Use the per-ant physical parameters in tensor("dr_params") (mass / damping scales, joint-limit offsets)."""
+        _lib.check(_lib.lib().mms_set_dr(self._h, int(bool(enable))), self._h, "mms_set_dr")
+
     def bind_rollout_out(self, rewards=None, dones=None):
         """Extra destinations for the step's reward (f32 [N]) and done flag (u8 [N]), e.g. RolloutStorage.rewards[t] /
         dones[t]; None disables either."""

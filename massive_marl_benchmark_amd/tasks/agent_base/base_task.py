@@ -8,6 +8,7 @@ gaussian / uniform, additive / scaling, with the linear / constant schedules and
 (mass, damping, limits) and the viewer are out of scope this round."""
 import operator
 
+import numpy as np
 import torch
 
 from ...engine import Engine
@@ -87,14 +88,17 @@ class BaseTask:
             self.obs_buf, self.obs_buf_clipped = self._engine_obs, self._engine_obs_clipped
 
     def apply_randomizations(self, dr_params):
-        """The 'observations' / 'actions' branch of base_task.py:216-316 (same parameters, schedules and lambdas)."""
+        """base_task.py:216-410: the 'observations' / 'actions' noise lambdas (same parameters and schedules) and the
+        'actor_params' physical parameters (see _randomize_actor_params); 'sim_params' (gravity) is not supported."""
         rand_freq = dr_params.get("frequency", 1)
         self.last_step = self.frame_count                                  # gym.get_frame_count
         if self.first_randomization:
             do_nonenv_randomize = True
+            env_ids = torch.arange(self.num_envs, device=self.device)
         else:
             do_nonenv_randomize = (self.last_step - self.last_rand_step) >= rand_freq
             rand_envs = torch.logical_and(self.randomize_buf >= rand_freq, self.reset_buf.bool())
+            env_ids = torch.nonzero(rand_envs, as_tuple=False).squeeze(-1)
             self.randomize_buf[rand_envs] = 0
         if do_nonenv_randomize:
             self.last_rand_step = self.last_step
@@ -152,7 +156,81 @@ class BaseTask:
 
                     self.dr_randomizations[name] = {'lo': lo, 'hi': hi, 'lo_corr': lo_corr, 'hi_corr': hi_corr,
                                                     'noise_lambda': noise_lambda}
+        if dr_params.get("actor_params") and env_ids.numel() > 0:
+            self._randomize_actor_params(dr_params["actor_params"], env_ids)
         self.first_randomization = False
+
+    # -- physical parameters (base_task.py:343-395) ------------------------------------------------------------------
+    def _dr_sample(self, prm, shape):
+        """One draw of isaacgym.gymutil.generate_random_samples / apply_random_samples (not in the reference tree; restated
+        from its documented behaviour: 'uniform' / 'loguniform' over range = [lo, hi], 'gaussian' with range = [mean, std];
+        a linear / constant schedule blends additive samples towards 0 and scaling samples towards 1)."""
+        lo, hi = prm["range"]
+        dist = prm.get("distribution", "uniform")
+        if dist == "gaussian":
+            x = np.random.normal(lo, hi, shape)
+        elif dist == "loguniform":
+            x = np.exp(np.random.uniform(np.log(lo), np.log(hi), shape))
+        elif dist == "uniform":
+            x = np.random.uniform(lo, hi, shape)
+        else:
+            raise ValueError("unknown randomisation distribution %r" % dist)
+        sched, steps = prm.get("schedule", None), prm.get("schedule_steps", None)
+        k = 1.0
+        if sched == "linear":
+            k = min(self.last_step, steps) / float(steps)
+        elif sched == "constant":
+            k = 0.0 if self.last_step < steps else 1.0
+        if prm["operation"] == "scaling":
+            return x * k + 1.0 * (1.0 - k)
+        if prm["operation"] == "additive":
+            return x * k
+        raise ValueError("unknown randomisation operation %r" % prm["operation"])
+
+    def _randomize_actor_params(self, actor_params, env_ids):
+        """Fills the engine's per-ant parameter blocks for `env_ids` (include/mms.h: mms_set_dr).  Supported, as in
+        cfg/TenAnt.yaml:97-122: rigid_body_properties.mass (scaling), dof_properties.damping (scaling) / lower / upper
+        (additive); dof stiffness has no effect in effort mode (ten_ant.py:274) and colour is visual.  Actor key `ant` addresses
+        every ant of the env (the reference looks the actor up by that name -- base_task.py:346 -- which exists in OneAnt only;
+        TenAnt names its actors ant_1 .. ant_10, also accepted here as keys)."""
+        if self.TASK_NAME == "MultiIngenuity":
+            raise NotImplementedError("actor_params randomisation: the helicopter task has no randomised physical parameters")
+        A = self.engine.num_agents
+        dr = self.engine.tensor("dr_params").view(self.num_envs, A, -1)
+        ids = env_ids.to(self.device)
+        block = dr[ids].cpu().numpy()                                     # [n, A, 33]
+        n = block.shape[0]
+        for actor, props in actor_params.items():
+            if actor == "ant":
+                ants = list(range(A))
+            elif actor.startswith("ant_") and actor[4:].isdigit() and 1 <= int(actor[4:]) <= A:
+                ants = [int(actor[4:]) - 1]
+            else:
+                raise KeyError("actor_params: no actor named %r in this task" % actor)
+            for prop_name, attrs in props.items():
+                if prop_name == "color":
+                    continue
+                if prop_name not in ("rigid_body_properties", "dof_properties"):
+                    raise NotImplementedError("actor_params.%s.%s is not a parameter of this engine" % (actor, prop_name))
+                for attr, prm in attrs.items():
+                    if prm.get("setup_only", False) and not self.first_randomization:
+                        continue                                          # randomised once, before the simulation starts
+                    if prop_name == "rigid_body_properties" and attr == "mass" and prm["operation"] == "scaling":
+                        cols, count = slice(0, 9), 9
+                    elif prop_name == "dof_properties" and attr == "damping" and prm["operation"] == "scaling":
+                        cols, count = slice(9, 17), 8
+                    elif prop_name == "dof_properties" and attr == "lower" and prm["operation"] == "additive":
+                        cols, count = slice(17, 25), 8
+                    elif prop_name == "dof_properties" and attr == "upper" and prm["operation"] == "additive":
+                        cols, count = slice(25, 33), 8
+                    elif prop_name == "dof_properties" and attr == "stiffness":
+                        continue
+                    else:
+                        raise NotImplementedError("actor_params.%s.%s.%s (%s) is not supported" % (actor, prop_name, attr, prm["operation"]))
+                    for a in ants:
+                        block[:, a, cols] = self._dr_sample(prm, (n, count))
+        dr[ids] = torch.from_numpy(block).to(self.device)
+        self.engine.set_dr(True)
 
     def get_states(self):
         return self.states_buf

@@ -797,8 +797,12 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
 /* One substep of one ant.  root[13]: env-local pos, quat, linvel, angvel (world frame).
  * dof[8][2]: (pos, vel).  tau_motor[8].  box may be NULL.  box_wrench[6] (torque about the box COM,
  * force) is ACCUMULATED.  sensors[4][6]: net contact (force, torque about the foot origin) in the foot frame. */
+/* dr: per-ant physical domain randomisation (cfg/TenAnt.yaml:97-122, applied by base_task.py:343-395 through
+ * set_actor_rigid_body_properties / set_actor_dof_properties), MMS_DR_FLOATS values or NULL for the nominal ant:
+ *   [0] torso, [1..4] leg, [5..8] foot mass scale (inertia scales with the mass: recomputeInertia = True is the setter's
+ *   default argument), [9..16] joint damping scale, [17..24] lower-limit offset, [25..32] upper-limit offset (rad). */
 static void ant_substep(const mms_model* M, float h, float root[13], float dof[8][2], const float tau_motor[8],
-                        const box_pose* box, float box_wrench[6], float sensors[4][6]) {
+                        const box_pose* box, float box_wrench[6], float sensors[4][6], const float* dr) {
     float Rt[3][3];
     quat_to_mat(root + 3, Rt);
     const float* Ow = root;
@@ -811,9 +815,10 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
     {
         float ez[3] = {Rt[0][2], Rt[1][2], Rt[2][2]};
         float Ic[3][3];
-        axisym_inertia(M->torso_izz, M->torso_ixx, ez, Ic);
-        spatial_inertia(M->torso_mass, zero3, Ic, IA0);
-        bias_force(IA0, v0, M->torso_mass, zero3, M->gravity, pA0);
+        const float mt = dr ? dr[0] : 1.f;
+        axisym_inertia(M->torso_izz * mt, M->torso_ixx * mt, ez, Ic);
+        spatial_inertia(M->torso_mass * mt, zero3, Ic, IA0);
+        bias_force(IA0, v0, M->torso_mass * mt, zero3, M->gravity, pA0);
     }
     contact_t ct_g, ct_b;
     sphere_contacts(M, h, Ow, zero3, M->torso_radius, v0, box, &ct_g, &ct_b);
@@ -861,12 +866,13 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
         /* inertias and bias forces */
         m66 IAl, IAf;
         float pAl[6], pAf[6], Ic[3][3];
-        axisym_inertia(M->leg_ia, M->leg_it, ul, Ic);
-        spatial_inertia(M->leg_mass, cl, Ic, IAl);
-        bias_force(IAl, vl, M->leg_mass, cl, M->gravity, pAl);
-        axisym_inertia(M->foot_ia, M->foot_it, uf, Ic);
-        spatial_inertia(M->foot_mass, cf, Ic, IAf);
-        bias_force(IAf, vf, M->foot_mass, cf, M->gravity, pAf);
+        const float ml = dr ? dr[1 + l] : 1.f, mf = dr ? dr[5 + l] : 1.f;
+        axisym_inertia(M->leg_ia * ml, M->leg_it * ml, ul, Ic);
+        spatial_inertia(M->leg_mass * ml, cl, Ic, IAl);
+        bias_force(IAl, vl, M->leg_mass * ml, cl, M->gravity, pAl);
+        axisym_inertia(M->foot_ia * mf, M->foot_it * mf, uf, Ic);
+        spatial_inertia(M->foot_mass * mf, cf, Ic, IAf);
+        bias_force(IAf, vf, M->foot_mass * mf, cf, M->gravity, pAf);
         /* contacts: hip and knee spheres on the leg body, tip sphere on the foot body */
         sphere_contacts(M, h, Ow, J1, M->limb_radius, vl, box, &chip_g[l], &chip_b[l]);
         sphere_contacts(M, h, Ow, J2[l], M->limb_radius, vl, box, &cknee_g[l], &cknee_b[l]);
@@ -880,9 +886,12 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
         for (int j = 0; j < 2; j++) {
             int d = 2 * l + j;
             float q = dof[d][0], qd = dof[d][1];
-            float t = tau_motor[d] - M->joint_damping * qd;
-            float De = M->armature + h * M->joint_damping;
-            float ehi = q - M->dof_upper[d], elo = M->dof_lower[d] - q;
+            const float damping = dr ? M->joint_damping * dr[9 + d] : M->joint_damping;
+            const float upper = dr ? M->dof_upper[d] + dr[25 + d] : M->dof_upper[d];
+            const float lower = dr ? M->dof_lower[d] + dr[17 + d] : M->dof_lower[d];
+            float t = tau_motor[d] - damping * qd;
+            float De = M->armature + h * damping;
+            float ehi = q - upper, elo = lower - q;
             float whi = ramp01(fmaxf(ehi, ehi + h * qd), M->limit_ramp), wlo = ramp01(fmaxf(elo, elo - h * qd), M->limit_ramp);
             if (whi > 0.f) {
                 float gl = whi * (h * M->limit_k + M->limit_c);
@@ -1111,6 +1120,8 @@ typedef struct mo_engine {
     float *actions, *obs, *obs_clipped, *rew, *root_states, *initial_root_states, *dof_state, *env_origin, *prev,
         *reset_noise, *foot_sensors;
     int64_t *reset, *progress, *reset_count;
+    float* dr_params;          /* [N][A][MMS_DR_FLOATS] */
+    int dr_enabled;
 } mo_engine;
 
 static int is_ant_task(int task) { return task == MMS_TASK_TEN_ANT || task == MMS_TASK_ONE_ANT; }
@@ -1169,6 +1180,9 @@ MO_EXPORT mo_engine* mo_create(const mms_config* cfg) {
     e->reset = (int64_t*)calloc(N, 8);
     e->progress = (int64_t*)calloc(N, 8);
     e->reset_count = (int64_t*)calloc(N, 8);
+    e->dr_params = (float*)calloc((size_t)N * A * MMS_DR_FLOATS, 4);
+    for (size_t k = 0; k < (size_t)N * A; k++)
+        for (int j = 0; j < 17; j++) e->dr_params[k * MMS_DR_FLOATS + j] = 1.f;      /* scales 1, offsets 0 */
     int64_t npr = (int64_t)sqrt((double)cfg->total_envs);
     if (npr < 1) npr = 1;
     for (int i = 0; i < N; i++) {
@@ -1199,7 +1213,7 @@ MO_EXPORT void mo_destroy(mo_engine* e) {
     if (!e) return;
     free(e->actions); free(e->obs); free(e->obs_clipped); free(e->rew); free(e->root_states);
     free(e->initial_root_states); free(e->dof_state); free(e->env_origin); free(e->prev); free(e->reset_noise);
-    free(e->foot_sensors); free(e->reset); free(e->progress); free(e->reset_count); free(e);
+    free(e->foot_sensors); free(e->reset); free(e->progress); free(e->reset_count); free(e->dr_params); free(e);
 }
 MO_EXPORT void* mo_tensor(mo_engine* e, const char* name, int64_t* numel) {
 #define T(nm, p, cnt) if (!strcmp(name, nm)) { *numel = (int64_t)(cnt); return (void*)(p); }
@@ -1217,10 +1231,12 @@ MO_EXPORT void* mo_tensor(mo_engine* e, const char* name, int64_t* numel) {
     T("prev", e->prev, (size_t)e->N * e->prev_dim)
     T("reset_noise", e->reset_noise, (size_t)e->N * 16)
     T("foot_sensors", e->foot_sensors, (size_t)e->N * e->A * 24)
+    T("dr_params", e->dr_params, (size_t)e->N * e->A * MMS_DR_FLOATS)
 #undef T
     *numel = 0;
     return NULL;
 }
+MO_EXPORT void mo_set_dr(mo_engine* e, int enable) { e->dr_enabled = enable != 0; }
 MO_EXPORT void mo_dims(mo_engine* e, int32_t out[6]) {
     out[0] = e->actors; out[1] = e->dofs_per_env; out[2] = e->num_actions; out[3] = e->obs_dim; out[4] = e->prev_dim; out[5] = e->A;
 }
@@ -1335,7 +1351,8 @@ static void physics_env(mo_engine* e, int i) {
                     tau[j] = clampf(e->actions[(size_t)i * e->num_actions + 8 * k + j], -c->clip_actions, c->clip_actions) *
                              M->gear[j] * c->power_scale;            /* ten_ant.py:889 */
                 ant_substep(M, h, roots + 13 * k, (float(*)[2])(dofs + 16 * k), tau, &box, wrench,
-                            (float(*)[6])(e->foot_sensors + ((size_t)i * A + k) * 24));
+                            (float(*)[6])(e->foot_sensors + ((size_t)i * A + k) * 24),
+                            e->dr_enabled ? e->dr_params + ((size_t)i * A + k) * MMS_DR_FLOATS : NULL);
             }
             box_substep(M, h, br, wrench);
         }
@@ -1363,8 +1380,14 @@ MO_EXPORT void mo_step(mo_engine* e, int do_physics) {
 }
 
 /* unit-level entry points for the physics KATs */
+MO_EXPORT void mo_ant_substep_dr(const mms_model* M, float h, float* root, float* dof, const float* tau,
+                                 const float* box_root /*may be NULL*/, float* box_wrench, float* sensors, const float* dr);
 MO_EXPORT void mo_ant_substep(const mms_model* M, float h, float* root, float* dof, const float* tau,
                               const float* box_root /*may be NULL*/, float* box_wrench, float* sensors) {
+    mo_ant_substep_dr(M, h, root, dof, tau, box_root, box_wrench, sensors, NULL);
+}
+MO_EXPORT void mo_ant_substep_dr(const mms_model* M, float h, float* root, float* dof, const float* tau,
+                                 const float* box_root /*may be NULL*/, float* box_wrench, float* sensors, const float* dr) {
     box_pose box;
     if (box_root) {
         memcpy(box.pos, box_root, 12);
@@ -1373,7 +1396,7 @@ MO_EXPORT void mo_ant_substep(const mms_model* M, float h, float* root, float* d
         memcpy(box.w, box_root + 10, 12);
         memcpy(box.half, M->box_half, 12);
     }
-    ant_substep(M, h, root, (float(*)[2])dof, tau, box_root ? &box : NULL, box_wrench, (float(*)[6])sensors);
+    ant_substep(M, h, root, (float(*)[2])dof, tau, box_root ? &box : NULL, box_wrench, (float(*)[6])sensors, dr);
 }
 MO_EXPORT void mo_box_substep(const mms_model* M, float h, float* root, const float* wrench) { box_substep(M, h, root, wrench); }
 MO_EXPORT void mo_heli_substep(const mms_model* M, float h, float* root, const float* thrust) {

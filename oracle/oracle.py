@@ -55,6 +55,8 @@ def lib():
         _lib.mo_gae_ppo.argtypes = [ci, c64, F, U8, F, F, cf, cf, F, F, ci]
         _lib.mo_gae_marl.argtypes = [ci, c64, F, F, F, cf, cf, ci, cf, cf, F]
         _lib.mo_ant_substep.argtypes = [ctypes.POINTER(MmsModel), cf, F, F, F, F, F, F]
+        _lib.mo_ant_substep_dr.argtypes = [ctypes.POINTER(MmsModel), cf, F, F, F, F, F, F, F]
+        _lib.mo_set_dr.argtypes = [ctypes.c_void_p, ci]
         _lib.mo_box_substep.argtypes = [ctypes.POINTER(MmsModel), cf, F, F]
         _lib.mo_heli_substep.argtypes = [ctypes.POINTER(MmsModel), cf, F, F]
         _lib.mo_ant_momentum.argtypes = [ctypes.POINTER(MmsModel), F, F, F]
@@ -108,8 +110,11 @@ class OracleEngine:
         shapes = {"actions": (N, self.num_actions), "obs": (N, self.obs_dim), "obs_clipped": (N, self.obs_dim),
                   "root_states": (N * self.actors, 13), "initial_root_states": (N * self.actors, 13),
                   "dof_state": (N * self.dofs, 2), "env_origin": (N, 3), "prev": (N, self.prev_dim),
-                  "reset_noise": (N, 16), "foot_sensors": (N * self.num_agents, 24)}
+                  "reset_noise": (N, 16), "foot_sensors": (N * self.num_agents, 24), "dr_params": (N * self.num_agents, 33)}
         return arr.reshape(shapes.get(name, (n.value,)))
+
+    def set_dr(self, enable=True):
+        lib().mo_set_dr(self._h, 1 if enable else 0)
 
     def step(self, actions=None, physics=True):
         if actions is not None:

@@ -41,3 +41,13 @@ def shove_ants_into_box(o, rng):
         roots[:, k, 0] = box[:, 0] + half_x + rng.uniform(0.20, 0.45, o.num_envs).astype(np.float32)   # torso sphere r = 0.25: touching / overlapping
         roots[:, k, 2] = rng.uniform(0.45, 0.75, o.num_envs).astype(np.float32)
         roots[:, k, 7] = rng.uniform(-2.5, -0.5, o.num_envs).astype(np.float32)                         # vx towards the box
+
+
+def random_dr_params(rng, num_ants):
+    """[num_ants, 33] physical domain-randomisation blocks drawn from the ranges of cfg/TenAnt.yaml:97-122: mass and damping
+    scales U(0.5, 1.5), joint-limit offsets N(0, 0.01) (include/mms.h: mms_set_dr)."""
+    dr = np.ones((num_ants, 33), np.float32)
+    dr[:, 0:9] = rng.uniform(0.5, 1.5, (num_ants, 9))
+    dr[:, 9:17] = rng.uniform(0.5, 1.5, (num_ants, 8))
+    dr[:, 17:33] = rng.normal(0.0, 0.01, (num_ants, 16))
+    return dr

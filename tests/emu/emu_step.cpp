@@ -28,7 +28,7 @@ static float quad4(const float x[4]) { return (x[0] + x[1]) + (x[2] + x[3]); }
 struct Bufs {
     const float* actions; float* obs; float* obs_clipped; float* rew; int64_t* reset; int64_t* progress;
     float* root_states; const float* initial_root_states; float* dof_state; const float* env_origin; float* prev;
-    const float* reset_noise; float* foot_sensors; int64_t* reset_count;
+    const float* reset_noise; float* foot_sensors; int64_t* reset_count; const float* dr;
 };
 
 static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_physics, int obs_dim, int prev_dim) {
@@ -69,9 +69,14 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
             std::vector<S6> pA(nl), wr(nl);
             std::vector<LegPass> P(nl);
             std::vector<SensorPass> SP(nl);
+            const KinPark no_park{nullptr, 0};
             for (int t = 0; t < nl; t++) {
                 float t1 = act0[t] * L[t].gear[0] * C->power_scale, t2 = act1[t] * L[t].gear[1] * C->power_scale;
-                if (task == MMS_TASK_ONE_ANT) leg_inward<true>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t]);
+                if (b.dr) {
+                    LegDR d = load_leg_dr(b.dr + ((size_t)env * A + (t >> 2)) * MMS_DR_FLOATS, t & 3);
+                    if (task == MMS_TASK_ONE_ANT) leg_inward<true, true>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t], no_park, &d);
+                    else leg_inward<false, true>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t], no_park, &d);
+                } else if (task == MMS_TASK_ONE_ANT) leg_inward<true>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t]);
                 else leg_inward<false>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t]);
             }
             for (int q = 0; q < nl; q += 4) {                      // quad all-reduce
@@ -211,8 +216,8 @@ extern "C" __attribute__((visibility("default"))) void emu_step(const mms_config
                                                                  float* rew, int64_t* reset, int64_t* progress, float* root_states,
                                                                  const float* initial_root_states, float* dof_state, const float* env_origin,
                                                                  float* prev, const float* reset_noise, float* foot_sensors, int64_t* reset_count,
-                                                                 int do_physics, int obs_dim, int prev_dim) {
-    Bufs b{actions, obs, obs_clipped, rew, reset, progress, root_states, initial_root_states, dof_state, env_origin, prev, reset_noise, foot_sensors, reset_count};
+                                                                 int do_physics, int obs_dim, int prev_dim, const float* dr /* may be NULL */) {
+    Bufs b{actions, obs, obs_clipped, rew, reset, progress, root_states, initial_root_states, dof_state, env_origin, prev, reset_noise, foot_sensors, reset_count, dr};
     for (int env = 0; env < C->num_envs; env++) {
         if (C->task == MMS_TASK_MULTI_INGENUITY) emu_heli_env(C, b, env, do_physics);
         else emu_ant_env(C, b, env, do_physics, obs_dim, prev_dim);

@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import angle_close, load_golden, shove_ants_into_box
+from conftest import angle_close, load_golden, random_dr_params, shove_ants_into_box
 
 pytestmark = pytest.mark.gpu
 
@@ -152,6 +152,40 @@ def test_ant_box_contact_parity(torch_cuda, task, n):
             shove_ants_into_box(ora, rng)
     check_distribution(verr, perr)
     assert pushed < -1e-3, pushed
+    eng.close()
+
+
+@pytest.mark.parametrize("task,n", [("TenAnt", 9), ("OneAnt", 10)])
+def test_domain_randomised_physics_parity(torch_cuda, task, n):
+    """mms_set_dr: per-ant mass / damping scales and joint-limit offsets through the DR instantiation of the step kernel,
+    teacher forced against the oracle; and the switch really switches."""
+    torch = torch_cuda
+    kw = dict(num_envs=n, seed=13, total_envs=64, env_offset=2)
+    eng, ora = make_pair(task, **kw)
+    rng = np.random.default_rng(9)
+    dr = random_dr_params(rng, n * ora.num_agents)
+    ora.tensor("dr_params")[...] = dr
+    ora.set_dr(True)
+    assert float(eng.tensor("dr_params")[:, :17].min()) == 1.0 and float(eng.tensor("dr_params")[:, 17:].abs().max()) == 0.0
+    eng.tensor("dr_params").copy_(torch.from_numpy(dr).to(eng.device))
+    eng.set_dr(True)
+    verr, perr, flips = [], [], []
+    for t in range(80):
+        push_state(torch, eng, ora)
+        act = rng.uniform(-1.2, 1.2, (n, ora.num_actions)).astype(np.float32)
+        eng.tensor("actions").copy_(torch.from_numpy(act).to(eng.device))
+        eng.step()
+        ora.step(act)
+        torch.cuda.synchronize()
+        compare_step(task, eng, ora, "%s DR step %d" % (task, t), verr, perr, flips)
+    check_distribution(verr, perr)
+    eng.set_dr(False)                                          # nominal kernel again: now it must differ from the DR oracle
+    push_state(torch, eng, ora)
+    eng.tensor("actions").copy_(torch.from_numpy(act).to(eng.device))
+    eng.step()
+    ora.step(act)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(to_np(eng.tensor("dof_state")) - ora.tensor("dof_state"))) > 1e-3
     eng.close()
 
 
@@ -625,6 +659,47 @@ def test_domain_randomisation_noise(torch_cuda):
     t2.step(torch.zeros(16, 80, device="cuda"))
     assert t2.obs_buf.data_ptr() == t2._engine_obs.data_ptr()
     t2.engine.close()
+
+
+def test_actor_params_randomisation(torch_cuda):
+    """actor_params of cfg/TenAnt.yaml:97-122 through BaseTask.apply_randomizations (base_task.py:343-395): ranges, setup_only,
+    the frequency / reset gate, and that the engine is switched to the randomised kernel."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.model import default_cfg
+    from massive_marl_benchmark_amd.tasks.one_ant import OneAnt
+    from massive_marl_benchmark_amd.tasks.ten_ant import TenAnt
+    np.random.seed(3)
+    cfg = default_cfg("TenAnt")
+    cfg["env"]["numEnvs"] = 128
+    cfg["task"]["randomize"] = True
+    cfg["task"]["randomization_params"]["frequency"] = 5
+    task = TenAnt(cfg, None, "physx", "cuda", 0, True, is_multi_agent=False)
+    dr = task.engine.tensor("dr_params").view(128, 10, 33).clone()
+    mass, damp, lims = dr[..., 0:9], dr[..., 9:17], dr[..., 17:33]
+    assert 0.5 <= float(mass.min()) < 0.6 and 1.4 < float(mass.max()) <= 1.5
+    assert 0.5 <= float(damp.min()) < 0.6 and 1.4 < float(damp.max()) <= 1.5
+    assert abs(float(lims.std()) - 0.01) < 0.001 and abs(float(lims.mean())) < 0.001
+    assert float((dr[:, 0] - dr[:, 1]).abs().max()) > 0.1            # every ant its own draw
+    a = torch.zeros(128, 80, device="cuda")
+    for _ in range(8):                                                  # first step resets everything: frequency not reached yet
+        task.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(task.engine.tensor("dr_params").view(128, 10, 33), dr)
+    task.reset_buf[:64] = 1                                             # 64 envs reset after >= 5 steps: they are redrawn ...
+    task.step(a)
+    torch.cuda.synchronize()
+    new = task.engine.tensor("dr_params").view(128, 10, 33)
+    assert torch.equal(new[64:], dr[64:])
+    assert float((new[:64, :, 9:] - dr[:64, :, 9:]).abs().min(dim=-1).values.max()) > 0    # damping and limits: new draws
+    assert torch.equal(new[:64, :, 0:9], dr[:64, :, 0:9])               # ... except the mass: setup_only
+    assert bool(torch.isfinite(task.obs_buf).all())
+    task.engine.close()
+    cfg = default_cfg("OneAnt")
+    cfg["env"]["numEnvs"] = 32
+    cfg["task"]["randomize"] = True
+    cfg["task"]["randomization_params"]["actor_params"]["ant"]["rigid_shape_properties"] = {"friction": {"range": [0.7, 1.3], "operation": "scaling", "distribution": "uniform"}}
+    with pytest.raises(NotImplementedError):
+        OneAnt(cfg, None, "physx", "cuda", 0, True)
 
 
 def test_bound_obs_out_and_graph_replay(torch_cuda):

@@ -134,6 +134,68 @@ def test_joint_limits_hold_under_full_torque():
         assert np.isfinite(root).all()
 
 
+def substep_dr(m, root, dof, dr, tau=None, n=1, h=H):
+    tau = f32(np.zeros(8) if tau is None else tau)
+    wrench, sens = np.zeros(6, np.float32), np.zeros((4, 6), np.float32)
+    for _ in range(n):
+        lib().mo_ant_substep_dr(ctypes.byref(m), h, fp(root), fp(dof), fp(tau), None, fp(wrench), fp(sens), fp(dr))
+
+
+def nominal_dr():
+    dr = np.zeros(33, np.float32)
+    dr[:17] = 1.0
+    return dr
+
+
+def test_domain_randomisation_parameters():
+    """Physical DR block (include/mms.h mms_set_dr): the nominal block is the nominal model; free fall does not depend on the
+    mass; a heavier link reacts less to the same torque; more damping decays faster; limit offsets move the stops."""
+    m = model()
+    ra, da = ant_state(z=5.0, qvel=1.0, angvel=[0.2, -0.1, 0.3])
+    rb, db = ra.copy(), da.copy()
+    substep(m, ra, da, n=5)
+    substep_dr(m, rb, db, nominal_dr(), n=5)
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(da, db)
+    # rigid free fall: all masses doubled -> the same trajectory
+    ra, da = ant_state(z=5.0)
+    da[:, 1] = 0
+    rb, db = ra.copy(), da.copy()
+    dr = nominal_dr()
+    dr[:9] = 2.0
+    substep(m, ra, da, n=20)
+    substep_dr(m, rb, db, dr, n=20)
+    assert np.max(np.abs(ra - rb)) < 1e-5 and np.max(np.abs(da - db)) < 1e-4
+    # joint response to a torque: the foot on leg 0 three times as heavy -> smaller ankle acceleration
+    m0 = model(gravity=0.0)
+    acc = []
+    for scale in (1.0, 3.0):
+        r, d = ant_state(z=5.0)
+        dr = nominal_dr()
+        dr[5] = scale
+        tau = np.zeros(8, np.float32)
+        tau[1] = 1.0
+        substep_dr(m0, r, d, dr, tau=tau)
+        acc.append(d[1, 1])
+    assert 0 < acc[1] < 0.95 * acc[0]
+    # damping scale: free swinging joints lose their velocity faster
+    left = []
+    for scale in (0.5, 1.5):
+        r, d = ant_state(z=5.0, qvel=2.0, seed=3)
+        dr = nominal_dr()
+        dr[9:17] = scale
+        substep_dr(m0, r, d, dr, n=10)
+        left.append(float(np.sum(d[:, 1] ** 2)))
+    assert left[1] < 0.8 * left[0]
+    # limit offsets: under full torque the joints settle at the shifted stops
+    hi = np.array(m0.dof_upper[:])
+    dr = nominal_dr()
+    dr[25:33] = np.linspace(-0.05, 0.05, 8)
+    r, d = ant_state(z=5.0)
+    substep_dr(m0, r, d, dr, tau=15.0 * np.ones(8), n=300)
+    assert np.max(np.abs(d[:, 0] - (hi + dr[25:33]))) < 0.005
+
+
 def test_rest_on_ground():
     m = model()
     root, dof = ant_state(z=0.8)
