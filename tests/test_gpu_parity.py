@@ -922,3 +922,62 @@ def test_optional_observation_rows(torch_cuda):
         assert torch.equal(e2.tensor("obs"), e1.tensor("obs")) and torch.equal(e2.tensor("obs_clipped"), e1.tensor("obs_clipped"))
         e1.close()
         e2.close()
+
+
+def test_rollout_kernels_random_shapes(torch_cuda):
+    """GAE scans, the advantage normalisation and the MARL view gather against the oracle on ragged sizes: one env, one
+    step, sizes that are not multiples of the 256-thread blocks, an empty batch."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    from oracle.oracle import U8, fp, lib as olib_
+    olib, L = olib_(), _lib.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(12)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for (T, N) in ((1, 1), (8, 1), (1, 257), (8, 4097), (13, 1000), (3, 65536 + 5)):
+        rew = (5 * rng.standard_normal((T, N))).astype(np.float32)
+        val = rng.standard_normal((T, N)).astype(np.float32)
+        done = (rng.random((T, N)) < 0.15).astype(np.uint8)
+        last = rng.standard_normal(N).astype(np.float32)
+        ret, adv = np.zeros((T, N), np.float32), np.zeros((T, N), np.float32)
+        norm = T * N > 1
+        olib.mo_gae_ppo(T, N, fp(rew), done.ctypes.data_as(U8), fp(val), fp(last), 0.96, 0.95, fp(ret), fp(adv), 1 if norm else 0)
+        d = {k: cu(v) for k, v in (("rew", rew), ("done", done), ("val", val), ("last", last))}
+        gret, gadv = torch.zeros(T, N, device="cuda"), torch.zeros(T, N, device="cuda")
+        stats = torch.zeros(3, dtype=torch.float64, device="cuda")
+        _lib.check(L.mms_gae_ppo(0, p(d["rew"]), p(d["done"]), p(d["val"]), p(d["last"]), p(gret), p(gadv), p(stats), T, N, 0.96, 0.95, stream), None, "gae")
+        if norm:
+            _lib.check(L.mms_adv_normalize(0, p(gadv), p(stats), T * N, stream), None, "norm")
+        torch.cuda.synchronize()
+        assert np.max(np.abs(to_np(gret) - ret)) < 1e-4, (T, N)
+        assert np.max(np.abs(to_np(gadv) - adv)) < 2e-5 * max(1.0, float(np.abs(adv).max())), (T, N)
+        # MARL scan on the same data (masks = 1 - done, value_preds with the bootstrap row appended)
+        vp = np.concatenate([val, last[None]], 0)
+        masks = np.concatenate([np.ones((1, N), np.float32), 1.0 - done.astype(np.float32)], 0)
+        for use_norm, mean, var in ((0, 0.0, 1.0), (1, 0.3, 2.5)):
+            mret = np.zeros((T + 1, N), np.float32)
+            olib.mo_gae_marl(T, N, fp(rew), fp(vp), fp(masks), 0.99, 0.95, use_norm, mean, var, fp(mret))
+            gm = torch.zeros(T + 1, N, device="cuda")
+            tm, tv = torch.tensor([mean], device="cuda"), torch.tensor([var], device="cuda")
+            tvp, tmask = cu(vp), cu(masks)                  # named: a temporary would be freed (and its block reused) before the launch
+            _lib.check(L.mms_gae_marl(0, p(d["rew"]), p(tvp), p(tmask), p(gm), T, N, 0.99, 0.95, use_norm, p(tm), p(tv), stream), None, "marl")
+            torch.cuda.synchronize()
+            assert np.max(np.abs(to_np(gm)[:T] - mret[:T])) < 1e-4 * max(1.0, float(np.abs(mret).max())), (T, N, use_norm)
+    for (n, agents, per, shared) in ((1, 1, 3, 2), (7, 10, 38, 8), (300, 100, 38, 8), (5, 4, 13, 0)):
+        row = agents * per + shared
+        obs = (6 * rng.standard_normal((n, row))).astype(np.float32)
+        want = np.zeros((n, agents, per + shared), np.float32)
+        olib.mo_marl_views(n, agents, per, shared, 7.0, fp(obs), fp(want))
+        got = torch.zeros(n, agents, per + shared, device="cuda")
+        clipped = cu(np.clip(obs, -7.0, 7.0))
+        _lib.check(L.mms_marl_views(0, p(clipped), p(got), n, agents, per, shared, stream), None, "views")
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(to_np(got), want)
+    # empty batches are accepted and touch nothing
+    z = torch.zeros(4, device="cuda")
+    zc = torch.zeros(4, dtype=torch.int64, device="cuda")
+    _lib.check(L.mms_ppo_act(0, p(z), p(z), p(z), 1, p(zc), 0, 1, p(z), None, None, None, None, None, 0, 4, stream), None, "empty act")
+    _lib.check(L.mms_marl_views(0, p(z), p(z), 0, 2, 1, 0, stream), None, "empty views")
+    torch.cuda.synchronize()
+    assert int(zc.sum()) == 0
