@@ -189,6 +189,30 @@ def test_domain_randomised_physics_parity(torch_cuda, task, n):
     eng.close()
 
 
+@pytest.mark.parametrize("task,n", [("TenAnt", 7), ("OneAnt", 5)])
+def test_unpacked_launch_shapes(torch_cuda, task, n, monkeypatch):
+    """MMS_PACKING=0 (one env per workgroup: the A/B switch of mms_create) runs the same lane code through the one-wave
+    reductions (DPP / permute instead of LDS): parity with the oracle, ants pressed against the box included."""
+    torch = torch_cuda
+    monkeypatch.setenv("MMS_PACKING", "0")
+    kw = dict(num_envs=n, seed=21)
+    eng, ora = make_pair(task, **kw)
+    rng = np.random.default_rng(8)
+    verr, perr, flips = [], [], []
+    for t in range(50):
+        if t == 15:
+            shove_ants_into_box(ora, rng)
+        push_state(torch, eng, ora)
+        act = rng.uniform(-1, 1, (n, ora.num_actions)).astype(np.float32)
+        eng.tensor("actions").copy_(torch.from_numpy(act).to(eng.device))
+        eng.step()
+        ora.step(act)
+        torch.cuda.synchronize()
+        compare_step(task, eng, ora, "%s unpacked step %d" % (task, t), verr, perr, flips)
+    check_distribution(verr, perr)
+    eng.close()
+
+
 @pytest.mark.parametrize("task,n,agents", [("TenAnt", 1, 10), ("OneAnt", 1, 1), ("MultiIngenuity", 1, 4), ("TenAnt", 9, 2),
                                             ("TenAnt", 5, 14), ("TenAnt", 3, 15), ("TenAnt", 2, 33)])
 def test_edge_shapes_and_timeouts(torch_cuda, task, n, agents):
