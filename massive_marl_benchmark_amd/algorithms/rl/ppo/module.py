@@ -68,6 +68,10 @@ class ActorCritic(nn.Module):
     # library's skinny GEMM + mms_ppo_act (12.2 us against 14.6 us at N 4096, H 512, A 80) but inside the two-stream rollout,
     # next to the critic's GEMMs, the rollout step measured 371.8 us with it and 365.5 us without (profiles/r01_v8_rollout_ab.txt)
     fuse_head = False
+    # hidden layers of both networks through mms_linear2_act (own fp32-MFMA GEMM with bias + ELU fused, one launch per layer).
+    # Opt-in: 107 TFLOP/s at 4096 x 1024 x 1024 against 117 for the library GEMM + separate ELU, and the two-stream library path
+    # is faster still (profiles/r01_v11_linear_probe.txt); kept as the starting point for the tuned version.
+    fuse_layers = False
     two_streams = True      # critic beside the actor on a second stream
     defer_value = False     # opt-in: `act` returns before the critic has finished; the owner calls join() before reading values
 
@@ -80,6 +84,29 @@ class ActorCritic(nn.Module):
         mu / sigma into slot `storage.step` and returns views of those slots, which `add_transitions` recognises and does
         not copy again) and `actions_out` (e.g. the engine's "actions" buffer)."""
         self._bound = (storage, actions_out)
+
+    def _fused_hidden(self, x, critic_in):
+        """Hidden layers of BOTH networks, one mms_linear2_act launch per layer (fp32 MFMA, bias + ELU in the epilogue).
+        Returns (actor hidden, critic hidden) or None when the two MLPs are not ELU networks of identical hidden shapes."""
+        a_lin = [m for m in self.actor if isinstance(m, nn.Linear)]
+        c_lin = [m for m in self.critic if isinstance(m, nn.Linear)]
+        acts = [m for m in list(self.actor) + list(self.critic) if not isinstance(m, nn.Linear)]
+        if (len(a_lin) != len(c_lin) or len(a_lin) < 2 or not all(isinstance(m, nn.ELU) and m.alpha == 1.0 for m in acts)
+                or any(la.weight.shape != lc.weight.shape or la.weight.dtype != torch.float32 or la.in_features % 4
+                       for la, lc in zip(a_lin[:-1], c_lin[:-1]))):
+            return None
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        dev = x.device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        ha, hc = x.contiguous(), critic_in.contiguous()
+        M = ha.shape[0]
+        for la, lc in zip(a_lin[:-1], c_lin[:-1]):
+            ya, yc = torch.empty(M, la.out_features, device=dev), torch.empty(M, la.out_features, device=dev)
+            _lib.check(_lib.lib().mms_linear2_act(idx, M, la.out_features, la.in_features, p(ha), p(la.weight.detach()), p(la.bias.detach()), p(ya),
+                                                  p(hc), p(lc.weight.detach()), p(lc.bias.detach()), p(yc), 1, current_stream_ptr(dev)),
+                       None, "mms_linear2_act")
+            ha, hc = ya, yc
+        return ha, hc
 
     def _actor_pass(self, x):
         """The actor MLP up to what the sampling kernel takes: (mean, None) or, when the last Linear layer can run inside
@@ -132,6 +159,11 @@ class ActorCritic(nn.Module):
         with torch.no_grad():
             dtype = self.log_std.dtype                              # a bf16 copy of the module takes fp32 observations
             critic_in = (states if self.asymmetric else observations).to(dtype)
+            if self.fuse_layers and observations.is_cuda and dtype == torch.float32:
+                hidden = self._fused_hidden(observations, critic_in)
+                if hidden is not None:
+                    ha, hc = hidden
+                    return self._sample(self.actor[-1](ha), self.critic[-1](hc))
             if not (observations.is_cuda and self.two_streams):
                 mean, hidden = self._actor_pass(observations.to(dtype))
                 return self._sample(mean, self.critic(critic_in), hidden)

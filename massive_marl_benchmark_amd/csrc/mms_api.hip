@@ -21,6 +21,15 @@ hipError_t launch_gae_marl(const float*, const float*, const float*, float*, int
 hipError_t launch_marl_views(const float*, float*, int64_t, int, int, int, hipStream_t);
 hipError_t launch_gae_marl_agents(const float*, const float*, const float*, float*, int, int64_t, int, float, float, int, const float*, const float*, hipStream_t);
 hipError_t launch_ppo_act(const float*, const float*, const float*, uint64_t, int64_t*, int64_t, int, float*, float*, float*, float*, float*, float*, int64_t, int, hipStream_t);
+struct LinearArgs {
+    const float* x[2];
+    const float* w[2];
+    const float* b[2];
+    float* y[2];
+    int M, N, K;
+    int act;
+};
+hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
 hipError_t launch_ppo_head_act(const float*, const float*, const float*, int, const float*, const float*, uint64_t, int64_t*, int64_t, int, float*, float*, float*,
                                float*, float*, float*, int64_t, int, hipStream_t);
 }  // namespace mms
@@ -382,6 +391,21 @@ __attribute__((visibility("default"))) int mms_ppo_head_act(int device, const fl
     }
     MMS_FREE(mms::launch_ppo_head_act(hidden, weight, bias, H, value, log_std, seed, counters, row_offset, reference_scale, actions_out, act_slot,
                                       logp_slot, value_slot, mu_slot, sigma_slot, N, A, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const float* x0, const float* w0, const float* b0,
+                                                           float* y0, const float* x1, const float* w1, const float* b1, float* y1, int32_t act,
+                                                           void* s) {
+    if (dev_guard(device)) return 1;
+    if (!x0 || !w0 || !b0 || !y0 || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || (K % 4) != 0 || (act != 0 && act != 1)) {
+        g_create_error = "mms_linear2_act: bad arguments (K must be a positive multiple of 4, act 0 or 1)";
+        return 1;
+    }
+    const bool two = x1 || w1 || b1 || y1;
+    if (two && !(x1 && w1 && b1 && y1)) { g_create_error = "mms_linear2_act: the second problem needs all four pointers"; return 1; }
+    mms::LinearArgs a{{x0, x1}, {w0, w1}, {b0, b1}, {y0, y1}, (int)M, N, K, act};
+    MMS_FREE(mms::launch_linear_act(a, two ? 2 : 1, (hipStream_t)s));
     return 0;
 }
 

@@ -1,0 +1,159 @@
+// policy_kernels.hip -- the hidden layers of the PPO policy (agents/algorithms/rl/ppo/module.py:27-52: nn.Linear + activation,
+// actor and critic of the same shape) as ONE launch per layer for both networks: Y = ELU(X W^T + b) on the fp32 matrix cores
+// with bias and activation in the epilogue.
+//
+// This IS a dense contraction, so it belongs on MFMA: v_mfma_f32_32x32x2_f32 (exact fp32 products and sums; the reference's
+// networks are fp32).  Tiling for gfx950: a 256-thread block owns a 128 x 128 output tile, each of its four waves a 64 x 64
+// quarter as 2 x 2 MFMA tiles (64 accumulator registers); K is walked in slices of 32 through LDS, double buffered -- the
+// global loads of slice k+1 are in flight while the 64 MFMAs of slice k issue (4096 cycles per wave), one barrier per slice.
+// Both networks (blockIdx.z) and all tiles of a layer make 512 blocks at M = 4096, N = 1024: two resident blocks per CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mms {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTM = 128, kTN = 128;
+
+struct LinearArgs {
+    const float* x[2];
+    const float* w[2];
+    const float* b[2];
+    float* y[2];
+    int M, N, K;
+    int act;        // 0: identity, 1: ELU (alpha = 1)
+};
+
+// LDS layout: both operand tiles row-major, [128 rows][32 k + 4 pad] -- exactly how they arrive from HBM, so staging is a plain
+// 16-B store per 16-B load.  The MFMA wants lane (i, h) to supply A[i][k] for ONE k per instruction; which k it supplies in
+// which instruction is free as long as the B operand uses the same map, because the k of a dot product may be summed in any
+// order.  So lane (i, h) reads the four consecutive k = 8c + 4h .. 8c + 4h + 3 of its row as ONE ds_read_b128 and feeds them
+// to four consecutive MFMAs: 4 LDS reads per 16 MFMAs.  Row pitch 36 floats: eight consecutive rows start in eight different
+// 16-B bank groups, so the 128-bit reads and writes are conflict free.
+constexpr int kBK = 32, kPitch = kBK + 4;
+constexpr size_t kLinearLds = (size_t)2 * 2 * 128 * kPitch * sizeof(float);     // two operands, two buffers: 73.7 KB
+
+__global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int g = blockIdx.z;
+    const float* __restrict__ X = a.x[g];
+    const float* __restrict__ W = a.w[g];
+    const float* __restrict__ Bv = a.b[g];
+    float* __restrict__ Y = a.y[g];
+    const int M = a.M, N = a.N, K = a.K;
+    const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64; // this wave's quarter of the tile
+    const int li = lane & 31, lh = lane >> 5;
+    float* As = smem;                                       // [2][128][kPitch]
+    float* Bs = smem + 2 * 128 * kPitch;
+    // staging: 128 rows x 8 float4 per operand and slice = 4 float4 per thread: rows sr + 32 j, k offset sk
+    const int sr = t >> 3, sk = (t & 7) * 4;
+
+    // two register sets: while slice kt is multiplied out of LDS, slice kt+1 waits in one set and slice kt+2 is in flight into
+    // the other -- one slice of MFMAs (1.7 us) is not always enough to cover an HBM round trip under load
+    float4 ra[2][4], rb[2][4];
+    auto load_slice = [&](int kt, int set) {
+        const int k = kt * kBK + sk;                        // K % 4 == 0: k < K implies k + 3 < K
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int row = m0 + sr + 32 * j, col = n0 + sr + 32 * j;
+            ra[set][j] = (row < M && k < K) ? *reinterpret_cast<const float4*>(X + (size_t)row * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[set][j] = (col < N && k < K) ? *reinterpret_cast<const float4*>(W + (size_t)col * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_slice = [&](int buf, int set) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            *reinterpret_cast<float4*>(As + ((size_t)buf * 128 + sr + 32 * j) * kPitch + sk) = ra[set][j];
+            *reinterpret_cast<float4*>(Bs + ((size_t)buf * 128 + sr + 32 * j) * kPitch + sk) = rb[set][j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    auto multiply_slice = [&](int buf) {
+        const float* a_base = As + ((size_t)buf * 128 + wr + li) * kPitch + 4 * lh;
+        const float* b_base = Bs + ((size_t)buf * 128 + wc + li) * kPitch + 4 * lh;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {              // 16 k at a time: 8 fragment reads (32 registers), then 32 MFMAs
+            float4 af[2][2], bf[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int ko = 16 * half + 8 * c;
+                af[c][0] = *reinterpret_cast<const float4*>(a_base + ko);
+                af[c][1] = *reinterpret_cast<const float4*>(a_base + 32 * kPitch + ko);
+                bf[c][0] = *reinterpret_cast<const float4*>(b_base + ko);
+                bf[c][1] = *reinterpret_cast<const float4*>(b_base + 32 * kPitch + ko);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // keep the machine scheduler from sinking the reads back to their uses
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+#define MMS_STEP(e)                                                                                          \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0].e, bf[c][0].e, acc[0][0], 0, 0, 0);            \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0].e, bf[c][1].e, acc[0][1], 0, 0, 0);            \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1].e, bf[c][0].e, acc[1][0], 0, 0, 0);            \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1].e, bf[c][1].e, acc[1][1], 0, 0, 0);
+                MMS_STEP(x) MMS_STEP(y) MMS_STEP(z) MMS_STEP(w)
+#undef MMS_STEP
+            }
+        }
+    };
+
+    const int nkt = (K + kBK - 1) / kBK;
+    load_slice(0, 0);
+    store_slice(0, 0);
+    if (nkt > 1) load_slice(1, 1);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {                   // two slices per trip so that the register sets alternate by name
+        if (kt + 2 < nkt) load_slice(kt + 2, 0);
+        multiply_slice(0);
+        if (kt + 1 < nkt) store_slice(1, 1);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            if (kt + 3 < nkt) load_slice(kt + 3, 1);
+            multiply_slice(1);
+            if (kt + 2 < nkt) store_slice(0, 0);
+            __syncthreads();
+        }
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int col = n0 + wc + 32 * j + li;
+        const float bias = (col < N) ? Bv[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r] + bias;
+                if (a.act == 1) v = (v > 0.f) ? v : (expf(v) - 1.f);         // torch.nn.ELU, alpha = 1
+                if (row < M && col < N) Y[(size_t)row * N + col] = v;
+            }
+        }
+    }
+}
+
+hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
+    if (a.M == 0 || a.N == 0) return hipSuccess;
+    dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, groups);
+    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in, once per process
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinearLds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(linear_act_kernel, grid, dim3(256), kLinearLds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace mms

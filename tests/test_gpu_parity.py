@@ -861,6 +861,34 @@ def test_ppo_head_act_kernel(torch_cuda):
     assert rc != 0 and "multiple of 64" in _lib.last_error(None)
 
 
+def test_linear2_act_kernel(torch_cuda):
+    """mms_linear2_act (hidden layer of both policy networks: fp32 MFMA GEMM + bias + ELU) against torch's Linear + ELU; ragged
+    M / N / K (partial tiles, K not a multiple of the 32-wide slice), one or two problems, identity epilogue."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    L = _lib.lib()
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(5)
+    for (M, N, K, act, two) in ((4096, 1024, 388, 1, True), (300, 200, 36, 1, True), (1, 1, 4, 0, False), (129, 257, 1024, 0, True),
+                                 (64, 512, 1028, 1, False)):
+        x = [torch.randn(M, K, device="cuda") for _ in range(2)]
+        w = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(2)]
+        b = [torch.randn(N, device="cuda") for _ in range(2)]
+        y = [torch.full((M, N), float("nan"), device="cuda") for _ in range(2)]
+        rc = L.mms_linear2_act(0, M, N, K, p(x[0]), p(w[0]), p(b[0]), p(y[0]), p(x[1] if two else None), p(w[1] if two else None),
+                               p(b[1] if two else None), p(y[1] if two else None), act, stream)
+        assert rc == 0, _lib.last_error(None)
+        torch.cuda.synchronize()
+        for g in range(2 if two else 1):
+            ref = torch.nn.functional.linear(x[g].double(), w[g].double(), b[g].double())
+            if act:
+                ref = torch.nn.functional.elu(ref)
+            scale = x[g].abs().double() @ w[g].abs().double().t() + b[g].abs().double()
+            assert float(((y[g].double() - ref).abs() / scale).max()) < 5e-7, (M, N, K, act, g)   # fp32 products and sums, K <= 1028
+    assert L.mms_linear2_act(0, 8, 8, 6, p(x[0]), p(w[0]), p(b[0]), p(y[0]), None, None, None, None, 1, stream) != 0     # K % 4
+
+
 def test_fused_act_and_bound_rollout(torch_cuda):
     """ActorCritic.act (fused tail) + RolloutStorage + engine, all zero-copy: slot t of the storage holds exactly what the
     reference's act -> step -> add_transitions sequence would have copied there."""
@@ -899,6 +927,13 @@ def test_fused_act_and_bound_rollout(torch_cuda):
         assert torch.equal(st.actions[t], actions) and torch.equal(st.actions_log_prob[t].view(-1), logp)
         cur = eng.tensor("obs_clipped").clone()
     assert st.step == T
+    # hidden layers through mms_linear2_act: same means / values as the library path
+    ac.fuse_layers = True
+    st.clear()
+    _, _, v_f, mu_f, _ = ac.act(st.observations[0], states)
+    ac.fuse_layers = False
+    with torch.no_grad():
+        assert float((ac.actor(st.observations[0]) - mu_f).abs().max()) < 1e-5 and float((ac.critic(st.observations[0]) - v_f).abs().max()) < 1e-5
     # deferred critic: act returns before the value is there; after join() the slot holds the critic's output
     st.clear()
     ac.defer_value = True
