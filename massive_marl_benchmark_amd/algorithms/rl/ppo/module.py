@@ -69,8 +69,8 @@ class ActorCritic(nn.Module):
     # next to the critic's GEMMs, the rollout step measured 371.8 us with it and 365.5 us without (profiles/r01_v8_rollout_ab.txt)
     fuse_head = False
     # hidden layers of both networks through mms_linear2_act (own fp32-MFMA GEMM with bias + ELU fused, one launch per layer).
-    # Opt-in: 107 TFLOP/s at 4096 x 1024 x 1024 against 117 for the library GEMM + separate ELU, and the two-stream library path
-    # is faster still (profiles/r01_v11_linear_probe.txt); kept as the starting point for the tuned version.
+    # Opt-in: 112-120 TFLOP/s on the 1024- / 512-wide layers (library GEMM + separate ELU: 108-116), 305 us for the three hidden
+    # layers against ~290 us for the two-stream library path (profiles/r01_v11_linear_probe.txt): parity, not yet a win.
     fuse_layers = False
     two_streams = True      # critic beside the actor on a second stream
     defer_value = False     # opt-in: `act` returns before the critic has finished; the owner calls join() before reading values

@@ -9,6 +9,7 @@
 // Both networks (blockIdx.z) and all tiles of a layer make 512 blocks at M = 4096, N = 1024: two resident blocks per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace mms {
 
@@ -143,16 +144,151 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
     }
 }
 
+// Fast path for M % 128 == 0, N % 128 == 0, K % 64 == 0 (the 1024- and 512-wide hidden layers): the same tiling with the K
+// loop written as a software pipeline in program order.  One wave issues in order, so whatever is not an MFMA has to sit BETWEEN
+// MFMAs (each keeps the matrix pipe busy for 64 cycles) instead of in front of them: per slice of 32 k = four groups of 16 MFMAs,
+//   group 0: fragment reads of group 1,            16 MFMAs with the 8 global loads of slice kt+2 between them
+//   group 1: fragment reads of group 2,            16 MFMAs with the 8 LDS stores of slice kt+1 between them
+//   group 2: fragment reads of group 3,            16 MFMAs, then the slice barrier
+//   group 3: fragment reads of group 0 of kt+1,    16 MFMAs
+// sched_barrier(0) pins that order against the machine scheduler, which otherwise sinks every read next to its first use.
+#define MMS_MFMA4(S, e)                                                                                      \
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][0].e, fb[S][0].e, acc00, 0, 0, 0);                     \
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][0].e, fb[S][1].e, acc01, 0, 0, 0);                     \
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][1].e, fb[S][0].e, acc10, 0, 0, 0);                     \
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][1].e, fb[S][1].e, acc11, 0, 0, 0);                     \
+    __builtin_amdgcn_sched_barrier(0);
+#define MMS_FRAGS(S, abase, bbase, ko)                                                                       \
+    fa[S][0] = *reinterpret_cast<const float4*>((abase) + (ko));                                             \
+    fa[S][1] = *reinterpret_cast<const float4*>((abase) + 32 * kPitch + (ko));                               \
+    fb[S][0] = *reinterpret_cast<const float4*>((bbase) + (ko));                                             \
+    fb[S][1] = *reinterpret_cast<const float4*>((bbase) + 32 * kPitch + (ko));                               \
+    __builtin_amdgcn_sched_barrier(0);
+
+__global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int g = blockIdx.z;
+    const float* __restrict__ X = a.x[g];
+    const float* __restrict__ W = a.w[g];
+    const float* __restrict__ Bv = a.b[g];
+    float* __restrict__ Y = a.y[g];
+    const int N = a.N, K = a.K;
+    const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    float* As = smem;                                       // [2][128][kPitch]
+    float* Bs = smem + 2 * 128 * kPitch;
+    const int sr = t >> 3, sk = (t & 7) * 4;
+    const float* xg = X + (size_t)(m0 + sr) * K + sk;       // this thread's staging source: rows + 32 j, advancing by 32 k per slice
+    const float* wg = W + (size_t)(n0 + sr) * K + sk;
+    const size_t rs = (size_t)32 * K;
+    float* as_st = As + (size_t)sr * kPitch + sk;           // ... and its staging destination (buffer 0)
+    float* bs_st = Bs + (size_t)sr * kPitch + sk;
+    const float* a_fr = As + (size_t)(wr + li) * kPitch + 4 * lh;   // this lane's fragment rows (buffer 0)
+    const float* b_fr = Bs + (size_t)(wc + li) * kPitch + 4 * lh;
+    constexpr int kBuf = 128 * kPitch;                      // floats per buffer
+
+    f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    float4 ra0_0, ra0_1, ra0_2, ra0_3, rb0_0, rb0_1, rb0_2, rb0_3;   // staged slices: set 0 = even slices,
+    float4 ra1_0, ra1_1, ra1_2, ra1_3, rb1_0, rb1_1, rb1_2, rb1_3;   // set 1 = odd slices (named scalars: arrays of them land in scratch)
+    float4 fa[2][2], fb[2][2];                              // fragment sets, alternating per group
+
+    const int nkt = K / kBK;                                // even
+#define MMS_LD(SET, J, KOFF) ra##SET##_##J = *reinterpret_cast<const float4*>(xg + (J) * rs + (KOFF)); rb##SET##_##J = *reinterpret_cast<const float4*>(wg + (J) * rs + (KOFF));
+#define MMS_ST(SET, J, BOFF) *reinterpret_cast<float4*>(as_st + (BOFF) + (J) * 32 * kPitch) = ra##SET##_##J; *reinterpret_cast<float4*>(bs_st + (BOFF) + (J) * 32 * kPitch) = rb##SET##_##J;
+    MMS_LD(0, 0, 0) MMS_LD(0, 1, 0) MMS_LD(0, 2, 0) MMS_LD(0, 3, 0)
+    MMS_LD(1, 0, kBK) MMS_LD(1, 1, kBK) MMS_LD(1, 2, kBK) MMS_LD(1, 3, kBK)
+    MMS_ST(0, 0, 0) MMS_ST(0, 1, 0) MMS_ST(0, 2, 0) MMS_ST(0, 3, 0)
+    __syncthreads();
+    MMS_FRAGS(0, a_fr, b_fr, 0)
+
+    // one slice: computes from buffer BUF, stores staged set ST (slice kt+1) into the other buffer, loads slice kt+2 into set LD
+#define MMS_SLICE(BUF, ST, LD, KT)                                                                                              \
+    {                                                                                                                            \
+        const float* ab = a_fr + (BUF) * kBuf;                                                                                   \
+        const float* bb = b_fr + (BUF) * kBuf;                                                                                   \
+        const int kl = ((KT) + 2 < nkt ? (KT) + 2 : nkt - 1) * kBK;      /* past the end: reload the last slice, never stored */ \
+        MMS_FRAGS(1, ab, bb, 8)                                                                                                  \
+        MMS_MFMA4(0, x)                                                                                                          \
+        MMS_LD(LD, 0, kl)            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        MMS_MFMA4(0, y)                                                                                                          \
+        MMS_LD(LD, 1, kl) \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        MMS_MFMA4(0, z)                                                                                                          \
+        MMS_LD(LD, 2, kl) \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        MMS_MFMA4(0, w)                                                                                                          \
+        MMS_LD(LD, 3, kl) \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        MMS_FRAGS(0, ab, bb, 16)                                                                                                 \
+        MMS_MFMA4(1, x)                                                                                                          \
+        MMS_ST(ST, 0, (1 - (BUF)) * kBuf) \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        MMS_MFMA4(1, y)                                                                                                          \
+        MMS_ST(ST, 1, (1 - (BUF)) * kBuf) \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        MMS_MFMA4(1, z)                                                                                                          \
+        MMS_ST(ST, 2, (1 - (BUF)) * kBuf) \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        MMS_MFMA4(1, w)                                                                                                          \
+        MMS_ST(ST, 3, (1 - (BUF)) * kBuf) \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        MMS_FRAGS(1, ab, bb, 24)                                                                                                 \
+        MMS_MFMA4(0, x) MMS_MFMA4(0, y) MMS_MFMA4(0, z) MMS_MFMA4(0, w)                                                          \
+        __syncthreads();                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        MMS_FRAGS(0, a_fr + (1 - (BUF)) * kBuf, b_fr + (1 - (BUF)) * kBuf, 0)                                                    \
+        MMS_MFMA4(1, x) MMS_MFMA4(1, y) MMS_MFMA4(1, z) MMS_MFMA4(1, w)                                                          \
+    }
+
+    for (int kt = 0; kt < nkt; kt += 2) {
+        MMS_SLICE(0, 1, 0, kt)
+        MMS_SLICE(1, 0, 1, kt + 1)
+    }
+#undef MMS_SLICE
+#undef MMS_LD
+#undef MMS_ST
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#define MMS_EPI(ACC, I, J)                                                                                   \
+    {                                                                                                        \
+        const int col = n0 + wc + 32 * (J) + li;                                                             \
+        const float bias = Bv[col];                                                                          \
+        float* yp = Y + (size_t)(m0 + wr + 32 * (I) + 4 * lh) * N + col;                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                     \
+            float v = ACC[r] + bias;                                                                         \
+            if (a.act == 1) v = (v > 0.f) ? v : (expf(v) - 1.f);                                             \
+            yp[(size_t)((r & 3) + 8 * (r >> 2)) * N] = v;                                                    \
+        }                                                                                                    \
+    }
+    MMS_EPI(acc00, 0, 0) MMS_EPI(acc01, 0, 1) MMS_EPI(acc10, 1, 0) MMS_EPI(acc11, 1, 1)
+#undef MMS_EPI
+}
+#undef MMS_MFMA4
+#undef MMS_FRAGS
+
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
     dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, groups);
     static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in, once per process
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinearLds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(linear_act_kernel, grid, dim3(256), kLinearLds, s, a);
+    static bool attr_fast = false;
+    if (!attr_fast) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_act_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_fast = true;
+    }
+    const bool fast = a.M % kTM == 0 && a.N % kTN == 0 && a.K % (2 * kBK) == 0 && !getenv("MMS_LINEAR_GENERIC");
+    if (fast) hipLaunchKernelGGL(linear_act_fast_kernel, grid, dim3(256), kLinearLds, s, a);
+    else hipLaunchKernelGGL(linear_act_kernel, grid, dim3(256), kLinearLds, s, a);
     return hipGetLastError();
 }
 

@@ -870,7 +870,9 @@ def test_linear2_act_kernel(torch_cuda):
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     torch.manual_seed(5)
-    for (M, N, K, act, two) in ((4096, 1024, 388, 1, True), (300, 200, 36, 1, True), (1, 1, 4, 0, False), (129, 257, 1024, 0, True),
+    # (the first three shapes take the software-pipelined fast path: M, N multiples of 128, K of 64; the rest the generic kernel)
+    for (M, N, K, act, two) in ((4096, 512, 1024, 1, True), (256, 128, 64, 0, True), (128, 256, 192, 1, False),
+                                 (4096, 1024, 388, 1, True), (300, 200, 36, 1, True), (1, 1, 4, 0, False), (129, 257, 1024, 0, True),
                                  (64, 512, 1028, 1, False)):
         x = [torch.randn(M, K, device="cuda") for _ in range(2)]
         w = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(2)]
