@@ -228,6 +228,14 @@ int mms_ppo_head_act(int device, const float* hidden, const float* weight, const
 int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const float* x0, const float* w0, const float* b0, float* y0,
                     const float* x1, const float* w1, const float* b1, float* y1, int32_t act, void* hip_stream);
 
+/* The same layer with bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16) and bf16 output, for a bf16 copy of the
+ * policy.  x [M,K]: bf16, or f32 when x_is_f32 (the first layer takes the observation row as it is and rounds it while staging);
+ * w [N,ldw] bf16 with rows padded with zeros to ldw, a multiple of 64 >= K; b [N] f32; y [M,N] bf16.  K a multiple of 4 for
+ * f32 x, of 64 for bf16 x. */
+int mms_linear2_act_bf16(int device, int64_t M, int32_t N, int32_t K, int32_t ldw, int32_t x_is_f32, const void* x0, const void* w0,
+                         const float* b0, void* y0, const void* x1, const void* w1, const float* b1, void* y1, int32_t act,
+                         void* hip_stream);
+
 const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
 int mms_abi_version(void);
 

@@ -30,6 +30,15 @@ struct LinearArgs {
     int act;
 };
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
+struct LinearBf16Args {
+    const void* x[2];
+    const __bf16* w[2];
+    const float* b[2];
+    __bf16* y[2];
+    int M, N, K, ldw;
+    int act;
+};
+hipError_t launch_linear_act_bf16(const LinearBf16Args& a, int groups, int x_is_f32, hipStream_t s);
 hipError_t launch_ppo_head_act(const float*, const float*, const float*, int, const float*, const float*, uint64_t, int64_t*, int64_t, int, float*, float*, float*,
                                float*, float*, float*, int64_t, int, hipStream_t);
 }  // namespace mms
@@ -406,6 +415,22 @@ __attribute__((visibility("default"))) int mms_linear2_act(int device, int64_t M
     if (two && !(x1 && w1 && b1 && y1)) { g_create_error = "mms_linear2_act: the second problem needs all four pointers"; return 1; }
     mms::LinearArgs a{{x0, x1}, {w0, w1}, {b0, b1}, {y0, y1}, (int)M, N, K, act};
     MMS_FREE(mms::launch_linear_act(a, two ? 2 : 1, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_linear2_act_bf16(int device, int64_t M, int32_t N, int32_t K, int32_t ldw, int32_t x_is_f32,
+                                                                const void* x0, const void* w0, const float* b0, void* y0, const void* x1,
+                                                                const void* w1, const float* b1, void* y1, int32_t act, void* s) {
+    if (dev_guard(device)) return 1;
+    if (!x0 || !w0 || !b0 || !y0 || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || ldw < K || (ldw % 64) != 0 || (act != 0 && act != 1) ||
+        (x_is_f32 ? (K % 4) != 0 : (K % 64) != 0)) {
+        g_create_error = "mms_linear2_act_bf16: bad arguments (ldw a multiple of 64 >= K; K a multiple of 4 for fp32 x, of 64 for bf16 x)";
+        return 1;
+    }
+    const bool two = x1 || w1 || b1 || y1;
+    if (two && !(x1 && w1 && b1 && y1)) { g_create_error = "mms_linear2_act_bf16: the second problem needs all four pointers"; return 1; }
+    mms::LinearBf16Args a{{x0, x1}, {(const __bf16*)w0, (const __bf16*)w1}, {b0, b1}, {(__bf16*)y0, (__bf16*)y1}, (int)M, N, K, ldw, act};
+    MMS_FREE(mms::launch_linear_act_bf16(a, two ? 2 : 1, x_is_f32, (hipStream_t)s));
     return 0;
 }
 

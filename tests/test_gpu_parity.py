@@ -891,6 +891,41 @@ def test_linear2_act_kernel(torch_cuda):
     assert L.mms_linear2_act(0, 8, 8, 6, p(x[0]), p(w[0]), p(b[0]), p(y[0]), None, None, None, None, 1, stream) != 0     # K % 4
 
 
+def test_linear2_act_bf16_kernel(torch_cuda):
+    """mms_linear2_act_bf16 (bf16 MFMA, fp32 accumulation, bias + ELU, bf16 out; fp32 or bf16 input) against a float64 product of
+    the SAME bf16-rounded operands: what is left is the rounding of the bf16 result (2^-9 relative)."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    L = _lib.lib()
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bf = torch.bfloat16
+    torch.manual_seed(6)
+    for (M, N, K, xf32, act, two) in ((4096, 1024, 388, True, 1, True), (300, 200, 36, True, 1, True), (129, 257, 128, False, 0, True),
+                                       (64, 512, 1024, False, 1, False), (1, 1, 4, True, 0, False)):
+        ldw = (K + 63) // 64 * 64
+        x = [torch.randn(M, K, device="cuda") for _ in range(2)]
+        if not xf32:
+            x = [t.to(bf) for t in x]
+        w = []
+        for _ in range(2):
+            q = torch.zeros(N, ldw, device="cuda", dtype=bf)
+            q[:, :K] = (torch.randn(N, K, device="cuda") / K ** 0.5).to(bf)
+            w.append(q)
+        b = [torch.randn(N, device="cuda") for _ in range(2)]
+        y = [torch.full((M, N), float("nan"), device="cuda", dtype=bf) for _ in range(2)]
+        rc = L.mms_linear2_act_bf16(0, M, N, K, ldw, 1 if xf32 else 0, p(x[0]), p(w[0]), p(b[0]), p(y[0]), p(x[1] if two else None),
+                                    p(w[1] if two else None), p(b[1] if two else None), p(y[1] if two else None), act, stream)
+        assert rc == 0, _lib.last_error(None)
+        torch.cuda.synchronize()
+        for g in range(2 if two else 1):
+            ref = torch.nn.functional.linear(x[g].to(bf).double(), w[g][:, :K].double(), b[g].double())
+            if act:
+                ref = torch.nn.functional.elu(ref)
+            assert float(((y[g].double() - ref).abs() / (1.0 + ref.abs())).max()) < 5e-3, (M, N, K, xf32, act, g)
+    assert L.mms_linear2_act_bf16(0, 8, 8, 64, 100, 0, p(x[0]), p(w[0]), p(b[0]), p(y[0]), None, None, None, None, 1, stream) != 0   # ldw % 64
+
+
 def test_fused_act_and_bound_rollout(torch_cuda):
     """ActorCritic.act (fused tail) + RolloutStorage + engine, all zero-copy: slot t of the storage holds exactly what the
     reference's act -> step -> add_transitions sequence would have copied there."""
