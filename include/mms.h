@@ -70,6 +70,7 @@ typedef struct mms_model {
     float gnd_k, gnd_c, gnd_mu, slip_eps, pen_ramp;
     float antbox_k, antbox_c;
     float boxgnd_k, boxgnd_c;
+    float boxgnd_mu;                     /* box-ground Coulomb friction; 0 = the frictionless box of this model (default) */
     /* box */
     float box_half[3], box_mass, box_inertia[3];
     /* helicopter (MultiIngenuity): one rigid body */

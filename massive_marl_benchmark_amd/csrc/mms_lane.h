@@ -746,6 +746,58 @@ MMS_HD void box_finish(const mms_model* M, float h, RigidState& B, const M3& R, 
     quat_integrate(B.qx, B.qy, B.qz, B.qw, B.ang, h);
 }
 
+// The same with Coulomb friction between the box and the ground (model.boxgnd_mu > 0): the tangential terms couple all six
+// accelerations, so a corner contributes a full (sparse-filled) 6x6 + 6-vector and the box is solved like an ant's torso.
+struct BoxCornerF { Sym6 IA; S6 pA; };
+MMS_HD BoxCornerF box_corner_friction(const mms_model* M, float h, const RigidState& B, const M3& R, int corner) {
+    BoxCornerF o;
+    sym_zero(o.IA);
+    o.pA = S6{V3{0, 0, 0}, V3{0, 0, 0}};
+    V3 loc = V3{(corner & 1 ? 1.f : -1.f) * M->box_half[0], (corner & 2 ? 1.f : -1.f) * M->box_half[1],
+                (corner & 4 ? 1.f : -1.f) * M->box_half[2]};
+    V3 xc = mul(R, loc);
+    float d = -(B.pos.z + xc.z);
+    if (d <= -kContactMargin) return o;
+    V3 vp = B.vel + cross(B.ang, xc);
+    float w = ramp01(fmaxf(d, d - h * vp.z), M->pen_ramp);
+    if (!(w > 0.f)) return o;
+    Contact c = contact_none();
+    c.active = 1.f;
+    c.xc = xc;
+    c.n = V3{0.f, 0.f, 1.f};
+    c.gn = w * (h * M->boxgnd_k + M->boxgnd_c);
+    c.kd = w * M->boxgnd_k * d;
+    float fn = fmaxf(c.kd - c.gn * vp.z, 0.f);
+    float vt = sqrtf(vp.x * vp.x + vp.y * vp.y);
+    c.ct = M->boxgnd_mu * fn / fmaxf(vt, M->slip_eps);
+    c.vrel = vp;
+    contact_fold_ground(c, h, o.IA, o.pA);
+    return o;
+}
+MMS_HD void box_finish_friction(const mms_model* M, float h, RigidState& B, const M3& R, const BoxCornerF& c, S6 wrench) {
+    Sym6 A = c.IA;
+    V3 d = V3{M->box_inertia[0], M->box_inertia[1], M->box_inertia[2]};
+    float ixx = d.x * R.c0.x * R.c0.x + d.y * R.c1.x * R.c1.x + d.z * R.c2.x * R.c2.x;
+    float ixy = d.x * R.c0.x * R.c0.y + d.y * R.c1.x * R.c1.y + d.z * R.c2.x * R.c2.y;
+    float ixz = d.x * R.c0.x * R.c0.z + d.y * R.c1.x * R.c1.z + d.z * R.c2.x * R.c2.z;
+    float iyy = d.x * R.c0.y * R.c0.y + d.y * R.c1.y * R.c1.y + d.z * R.c2.y * R.c2.y;
+    float iyz = d.x * R.c0.y * R.c0.z + d.y * R.c1.y * R.c1.z + d.z * R.c2.y * R.c2.z;
+    float izz = d.x * R.c0.z * R.c0.z + d.y * R.c1.z * R.c1.z + d.z * R.c2.z * R.c2.z;
+    A.m[sidx(0, 0)] += ixx; A.m[sidx(0, 1)] += ixy; A.m[sidx(0, 2)] += ixz;
+    A.m[sidx(1, 1)] += iyy; A.m[sidx(1, 2)] += iyz; A.m[sidx(2, 2)] += izz;
+    A.m[sidx(3, 3)] += M->box_mass; A.m[sidx(4, 4)] += M->box_mass; A.m[sidx(5, 5)] += M->box_mass;
+    V3 Iw_w = V3{ixx * B.ang.x + ixy * B.ang.y + ixz * B.ang.z, ixy * B.ang.x + iyy * B.ang.y + iyz * B.ang.z,
+                 ixz * B.ang.x + iyz * B.ang.y + izz * B.ang.z};
+    V3 gyro = cross(B.ang, Iw_w);
+    S6 rhs = S6{wrench.a - gyro - c.pA.a, wrench.l + V3{0.f, 0.f, -M->box_mass * M->gravity} - c.pA.l};
+    S6 acc = solve6(A, rhs);
+    B.ang = B.ang + h * acc.a;
+    B.vel = B.vel + h * acc.l;
+    clamp_angvel(B.ang, kMaxAngVel);
+    B.pos = B.pos + h * B.vel;
+    quat_integrate(B.qx, B.qy, B.qz, B.qw, B.ang, h);
+}
+
 // ---------------------------------------------------------------------------------------------
 // helicopter (one lane per helicopter; oracle heli_substep)
 // ---------------------------------------------------------------------------------------------

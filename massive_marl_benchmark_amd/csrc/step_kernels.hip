@@ -274,9 +274,18 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
                 if (!kOneWave) w = gather_wrench();
                 RigidState B = load_rigid(s_box);
                 M3 R = s_bp->R;
-                BoxCorner bc = box_corner(M, h, B, R, corner);
-                oct_sum(bc);
-                if (simulate) box_finish(M, h, B, R, bc, w);
+                if (M->boxgnd_mu > 0.f) {                            // uniform: box-ground friction couples all six accelerations
+                    BoxCornerF bf = box_corner_friction(M, h, B, R, corner);
+#pragma unroll
+                    for (int k = 0; k < 21; k++) bf.IA.m[k] = oct_sum(bf.IA.m[k]);
+                    bf.pA.a.x = oct_sum(bf.pA.a.x); bf.pA.a.y = oct_sum(bf.pA.a.y); bf.pA.a.z = oct_sum(bf.pA.a.z);
+                    bf.pA.l.x = oct_sum(bf.pA.l.x); bf.pA.l.y = oct_sum(bf.pA.l.y); bf.pA.l.z = oct_sum(bf.pA.l.z);
+                    if (simulate) box_finish_friction(M, h, B, R, bf, w);
+                } else {
+                    BoxCorner bc = box_corner(M, h, B, R, corner);
+                    oct_sum(bc);
+                    if (simulate) box_finish(M, h, B, R, bc, w);
+                }
                 if (corner == 0) box_store(B);
             }
             __syncthreads();

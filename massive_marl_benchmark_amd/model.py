@@ -37,7 +37,7 @@ class MmsModel(ctypes.Structure):
         ("gnd_k", ctypes.c_float), ("gnd_c", ctypes.c_float), ("gnd_mu", ctypes.c_float),
         ("slip_eps", ctypes.c_float), ("pen_ramp", ctypes.c_float),
         ("antbox_k", ctypes.c_float), ("antbox_c", ctypes.c_float),
-        ("boxgnd_k", ctypes.c_float), ("boxgnd_c", ctypes.c_float),
+        ("boxgnd_k", ctypes.c_float), ("boxgnd_c", ctypes.c_float), ("boxgnd_mu", ctypes.c_float),
         ("box_half", ctypes.c_float * 3), ("box_mass", ctypes.c_float), ("box_inertia", ctypes.c_float * 3),
         ("heli_mass", ctypes.c_float), ("heli_inertia", ctypes.c_float * 3), ("heli_com_z", ctypes.c_float),
         ("heli_rotor_z", ctypes.c_float * 2), ("heli_half", ctypes.c_float), ("heli_max_angvel", ctypes.c_float),
@@ -213,6 +213,7 @@ def build_model(task, num_agents, dt, substeps, gravity):
     m.antbox_c = min(100.0, 0.25 * mass / h)
     m.boxgnd_k = 3.0e3 * mass
     m.boxgnd_c = 60.0 * mass
+    m.boxgnd_mu = 0.0                       # frictionless box; cfg["env"]["boxGroundFriction"] overrides
     # --- helicopter: chassis box 0.12^3 density 50 + two rotor discs r 0.15, half height 0.005, density 1000
     mc = 50.0 * 0.12 ** 3
     mr = 1000.0 * math.pi * 0.15 ** 2 * 0.01
@@ -325,6 +326,9 @@ def make_config(task, cfg=None, num_envs=None, num_agents=None, device=0, seed=0
         c.box_start[0], c.box_start[1], c.box_start[2] = 4.0, 0.0, 1.0
     gravity = 3.721 if task == "MultiIngenuity" else -float(sim.get("gravity", [0, 0, -9.81])[2])
     c.model = build_model(task, int(num_agents), c.dt, c.substeps, gravity)
+    # not a key of the reference YAML: opt-in Coulomb friction between the box and the ground (0.5 = what PhysX's "average"
+    # combine rule would make of the box's 0 and the plane's 1.0; default 0 = this model's frictionless box)
+    c.model.boxgnd_mu = float(env.get("boxGroundFriction", 0.0))
     return c
 
 

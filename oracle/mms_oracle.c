@@ -1037,6 +1037,11 @@ static void box_substep(const mms_model* M, float h, float root[13], const float
         memcpy(ct.xc, xc, sizeof(xc));
         ct.n[0] = 0.f; ct.n[1] = 0.f; ct.n[2] = 1.f;
         ct.kd = w * M->boxgnd_k * d; ct.gn = gn; ct.ct = 0.f;
+        if (M->boxgnd_mu > 0.f) {                                    /* optional Coulomb friction, regularised like the ants' */
+            float fn = fmaxf(w * M->boxgnd_k * d - gn * vp[2], 0.f);
+            float vt = sqrtf(vp[0] * vp[0] + vp[1] * vp[1]);
+            ct.ct = M->boxgnd_mu * fn / fmaxf(vt, M->slip_eps);
+        }
         memcpy(ct.vrel, vp, sizeof(vp));
         float p[6] = {0, 0, 0, 0, 0, 0};
         contact_fold(&ct, h, A, p);

@@ -93,6 +93,15 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
             }
             float wt[6];
             for (int c = 0; c < 6; c++) { float tsum = 0.f; for (int t = 0; t < nl; t++) tsum += get(wr[t], c); wt[c] = tsum; }
+            if (M->boxgnd_mu > 0.f) {
+                BoxCornerF bc[8], bt;
+                for (int c = 0; c < 8; c++) bc[c] = box_corner_friction(M, h, B, bp.R, c);
+                auto osum = [&](auto get) { return ((get(0) + get(1)) + (get(2) + get(3))) + ((get(4) + get(5)) + (get(6) + get(7))); };
+                for (int k = 0; k < 21; k++) bt.IA.m[k] = osum([&](int c) { return bc[c].IA.m[k]; });
+                float* pp[6] = {&bt.pA.a.x, &bt.pA.a.y, &bt.pA.a.z, &bt.pA.l.x, &bt.pA.l.y, &bt.pA.l.z};
+                for (int k = 0; k < 6; k++) *pp[k] = osum([&](int c) { return get(bc[c].pA, k); });
+                box_finish_friction(M, h, B, bp.R, bt, S6{V3{wt[0], wt[1], wt[2]}, V3{wt[3], wt[4], wt[5]}});
+            } else {
             BoxCorner bc[8], bt;
             for (int c = 0; c < 8; c++) bc[c] = box_corner(M, h, B, bp.R, c);
             for (int k = 0; k < 9; k++) {                          // quad sums, then the half-mirror pair
@@ -100,6 +109,7 @@ static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_phys
                 bt.t[k] = q0 + q1;
             }
             box_finish(M, h, B, bp.R, bt, S6{V3{wt[0], wt[1], wt[2]}, V3{wt[3], wt[4], wt[5]}});
+            }
         }
     }
     progress += 1;

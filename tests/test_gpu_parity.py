@@ -189,6 +189,38 @@ def test_domain_randomised_physics_parity(torch_cuda, task, n):
     eng.close()
 
 
+@pytest.mark.parametrize("task,n", [("TenAnt", 8), ("OneAnt", 9)])
+def test_box_ground_friction_parity(torch_cuda, task, n):
+    """cfg env.boxGroundFriction = 0.5: the friction branch of the box phase (27-value corner reduction + 6x6 solve) against the
+    oracle while ants push the box; with friction the pushed box must end up slower than the frictionless one."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.model import default_cfg
+    speeds = {}
+    for mu in (0.5, 0.0):
+        cfg = default_cfg(task)
+        cfg["env"]["boxGroundFriction"] = mu
+        eng, ora = make_pair(task, cfg=cfg, num_envs=n, seed=17, total_envs=64, env_offset=5)
+        rng = np.random.default_rng(3)
+        zero = np.zeros((n, ora.num_actions), np.float32)
+        for _ in range(12):
+            ora.step(zero)
+        shove_ants_into_box(ora, rng)
+        verr, perr, flips = [], [], []
+        A = ora.num_agents
+        for t in range(50):
+            push_state(torch, eng, ora)
+            act = rng.uniform(-1, 1, (n, ora.num_actions)).astype(np.float32)
+            eng.tensor("actions").copy_(torch.from_numpy(act).to(eng.device))
+            eng.step()
+            ora.step(act)
+            torch.cuda.synchronize()
+            compare_step(task, eng, ora, "%s box friction %.1f step %d" % (task, mu, t), verr, perr, flips)
+        check_distribution(verr, perr)
+        speeds[mu] = float(np.abs(ora.tensor("root_states").reshape(n, A + 1, 13)[:, A, 7:9]).max())
+        eng.close()
+    assert speeds[0.5] < speeds[0.0]
+
+
 @pytest.mark.parametrize("task,n", [("TenAnt", 7), ("OneAnt", 5)])
 def test_unpacked_launch_shapes(torch_cuda, task, n, monkeypatch):
     """MMS_PACKING=0 (one env per workgroup: the A/B switch of mms_create) runs the same lane code through the one-wave

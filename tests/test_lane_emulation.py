@@ -195,6 +195,32 @@ def test_domain_randomised_physics_parity(emu, task, n):
     assert np.max(np.abs(nominal.tensor("dof_state") - o.tensor("dof_state"))) > 1e-2
 
 
+@pytest.mark.parametrize("task,n", [("TenAnt", 4), ("OneAnt", 6)])
+def test_box_ground_friction_parity(emu, task, n):
+    """cfg env.boxGroundFriction = 0.5: the general 6x6 box solve of the lane code against the oracle, ants pushing the box."""
+    from massive_marl_benchmark_amd.model import default_cfg
+    cfg = default_cfg(task)
+    cfg["env"]["boxGroundFriction"] = 0.5
+    kw = dict(cfg=cfg, num_envs=n, seed=17, total_envs=64, env_offset=5)
+    o = OracleEngine(task, **kw)
+    e = EmuEngine(emu, task, **kw)
+    assert abs(o.config.model.boxgnd_mu - 0.5) < 1e-7
+    rng = np.random.default_rng(3)
+    zero = f32(np.zeros((n, o.num_actions)))
+    for _ in range(12):
+        o.step(zero)
+    shove_ants_into_box(o, rng)
+    verr, perr, flips = [], [], []
+    for t in range(50):
+        for name in STATE:
+            e.buf[name][...] = o.tensor(name)
+        act = f32(rng.uniform(-1, 1, (n, o.num_actions)))
+        o.step(act)
+        e.step(act)
+        compare(o, e, "%s box friction step %d" % (task, t), verr, perr, flips)
+    check_distribution(verr, perr)
+
+
 @pytest.mark.parametrize("task,n,steps", [("TenAnt", 4, 25), ("OneAnt", 4, 25), ("MultiIngenuity", 4, 60)])
 def test_free_running_parity(emu, task, n, steps):
     kw = dict(num_envs=n, seed=9)

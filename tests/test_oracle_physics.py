@@ -249,6 +249,29 @@ def test_box_slides_without_friction_and_rests():
     assert np.max(np.abs(box[10:13])) < 1e-3
 
 
+def test_box_ground_friction_option():
+    """model.boxgnd_mu > 0 (cfg env.boxGroundFriction): a sliding box decelerates at mu g and comes to rest; at rest it stays."""
+    for task in ("TenAnt", "OneAnt"):
+        m = model(task)
+        m.boxgnd_mu = 0.5
+        box = np.zeros(13, np.float32)
+        box[2], box[6], box[7] = m.box_half[2] + 0.0005, 1.0, 2.0
+        for _ in range(24):
+            lib().mo_box_substep(ctypes.byref(m), H, fp(box), fp(np.zeros(6, np.float32)))     # settle on the ground first
+        v0 = float(box[7])
+        for _ in range(12):
+            lib().mo_box_substep(ctypes.byref(m), H, fp(box), fp(np.zeros(6, np.float32)))
+        decel = (v0 - float(box[7])) / (12 * H)
+        assert abs(decel - 0.5 * 9.81) < 0.5, (task, decel)          # the friction bound uses the explicit normal-force estimate
+        for _ in range(200):
+            lib().mo_box_substep(ctypes.byref(m), H, fp(box), fp(np.zeros(6, np.float32)))
+        x_rest = float(box[0])
+        assert abs(box[7]) < 2e-2 and abs(box[2] - m.box_half[2]) < 2e-3
+        for _ in range(100):
+            lib().mo_box_substep(ctypes.byref(m), H, fp(box), fp(np.zeros(6, np.float32)))
+        assert abs(float(box[0]) - x_rest) < 5e-3                          # regularised friction: creep below 3 cm/s
+
+
 def test_ant_box_action_reaction():
     """Total linear momentum of ant + box is conserved through their contact (no gravity, no ground)."""
     m = model(gravity=0.0)
