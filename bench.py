@@ -258,8 +258,8 @@ def main():
         run_steps(K)
         barrier()
         elapsed_ = time.perf_counter() - t0
-        # the step kernel inside the rollout (caches cold after the policy GEMMs): HIP events around each of 4 x NSTEPS
-        # eager rollout steps, outside the timed region
+        # the step kernel inside the rollout (right after the policy GEMMs the core clock is lowered for ~100 us and the VALU-bound
+        # kernel follows it): HIP events around each of 4 x NSTEPS eager rollout steps, outside the timed region
         pairs = []
         plain_step = eng.step
 
@@ -339,9 +339,10 @@ def main():
                          "launch_ms_back_to_back": kernel_ms_b2b, "launch_ms_in_rollout": kernel_ms_roll,
                          "launches": {"back_to_back": n_b2b, "in_rollout": n_roll},
                          "frac_back_to_back": ALGO_BYTES_PER_ENV_STEP * N / (kernel_ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "launch_note": "HIP events on the launch stream: 2 x 256 back-to-back launches (state hot in L2 / MALL) and 32 launches "
-                                        "inside eager rollout steps (cold after the policy GEMMs); launch_ms = average over all step-kernel "
-                                        "launches of this run, the figure a kernel trace of the same command averages"},
+                         "launch_note": "HIP events on the launch stream: 2 x 256 back-to-back launches and 32 launches inside eager rollout steps "
+                                        "(right after the policy GEMMs, when the core clock is lowered: the kernel is VALU-issue bound and follows "
+                                        "it); launch_ms = average over all step-kernel launches of this run, the figure a kernel trace of the same "
+                                        "command averages"},
             "cpu_baseline": cpu,
         }
         if bf_K:
