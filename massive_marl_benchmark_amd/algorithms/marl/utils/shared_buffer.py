@@ -87,6 +87,29 @@ class _AgentView:
             self._p.compute_returns(nv, norms)
 
 
+GATHERED = ("share_obs", "obs", "value_preds", "returns", "actions", "action_log_probs", "rewards", "masks", "active_masks", "factor")
+
+
+def all_gather_envs(tensors, group=None):
+    """The one real exchange step of the MARL path: envs are sharded over ranks for the rollout, and when
+    TRAINING is agent-parallel (rank g updates agents g, g + world, ...) every rank needs the rollout of ALL envs -- above all
+    the centralised critic's `share_obs` rows.  `tensors`: dict name -> [T(+1), N_local, ...] (env dimension 1); returns
+    dict name -> [T(+1), world * N_local, ...] with rank r's envs at [r N_local, (r + 1) N_local), i.e. in global env order
+    (rank r simulates the global envs [r N, (r + 1) N): the engine's env_offset).  One `all_gather_into_tensor` per buffer --
+    over RCCL it drives all seven xGMI links of a GPU at once, which a ring would not; the big one is share_obs,
+    (T + 1) N 388 floats = 57 MB per rank at 4096 envs."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = {}
+    for name, t in tensors.items():
+        t = t.contiguous()
+        flat = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)   # ranks concatenated along dim 0
+        dist.all_gather_into_tensor(flat, t, group=group)
+        # [world, T, N, ...] -> [T, world * N, ...]
+        out[name] = flat.view((world,) + tuple(t.shape)).transpose(0, 1).reshape((t.shape[0], world * t.shape[1]) + tuple(t.shape[2:]))
+    return out
+
+
 class SharedRolloutBuffers:
     def __init__(self, config, env, device):
         self.T = config["episode_length"]
@@ -168,6 +191,10 @@ class SharedRolloutBuffers:
         total, count = (running * done).sum(), done.sum()
         running.mul_((~done).to(running.dtype))
         return total, count
+
+    def all_gather(self, group=None):
+        """All ranks' rollouts in global env order (see all_gather_envs): dict of the buffers a trainer reads."""
+        return all_gather_envs({k: getattr(self, k) for k in GATHERED}, group)
 
     # -- learner side --------------------------------------------------------------------------------------------
     def after_update(self):

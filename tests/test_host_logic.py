@@ -168,6 +168,16 @@ assert np.max(np.abs(norm - ref[:, rank * 32:(rank + 1) * 32])) < 1e-5
 from bench import shard_for_rank
 off, total = shard_for_rank(rank, world, 4096)
 assert (off, total) == (rank * 4096, world * 4096)
+# the MARL exchange step: all-gather of the env-sharded rollout into global env order (centralised critic, agent-parallel training)
+from massive_marl_benchmark_amd.algorithms.marl.utils.shared_buffer import all_gather_envs
+T, NL = 3, 5
+glob = {"share_obs": rng.standard_normal((T + 1, world * NL, 7)).astype(np.float32),
+        "value_preds": rng.standard_normal((T + 1, world * NL, 10)).astype(np.float32),
+        "rewards": rng.standard_normal((T, world * NL, 1)).astype(np.float32)}
+local = {k: torch.from_numpy(np.ascontiguousarray(v[:, rank * NL:(rank + 1) * NL])) for k, v in glob.items()}
+got = all_gather_envs(local)
+for k, v in glob.items():
+    assert got[k].shape == v.shape and np.array_equal(got[k].numpy(), v), k
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
