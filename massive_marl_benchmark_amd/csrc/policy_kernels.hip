@@ -383,16 +383,25 @@ __global__ void __launch_bounds__(256, 2) linear_act_bf16_kernel(LinearBf16Args 
     }
 }
 
+// More than 64 KB of dynamic LDS needs an opt-in per kernel and per device; remembered so that it is asked for once.
+static hipError_t allow_large_lds(const void* kernel, int slot) {
+    static bool done[4][64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !done[slot][dev]) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[slot][dev] = true;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_linear_act_bf16(const LinearBf16Args& a, int groups, int x_is_f32, hipStream_t s) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
     dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, groups);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_act_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_act_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_bf16_kernel<true>), 0); e != hipSuccess) return e;
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_bf16_kernel<false>), 1); e != hipSuccess) return e;
     if (x_is_f32) hipLaunchKernelGGL(linear_act_bf16_kernel<true>, grid, dim3(256), kLinearBf16Lds, s, a);
     else hipLaunchKernelGGL(linear_act_bf16_kernel<false>, grid, dim3(256), kLinearBf16Lds, s, a);
     return hipGetLastError();
@@ -401,18 +410,8 @@ hipError_t launch_linear_act_bf16(const LinearBf16Args& a, int groups, int x_is_
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
     dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, groups);
-    static bool attr_set = false;                           // > 64 KB of dynamic LDS needs the opt-in, once per process
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    static bool attr_fast = false;
-    if (!attr_fast) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_act_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_fast = true;
-    }
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel), 2); e != hipSuccess) return e;
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel), 3); e != hipSuccess) return e;
     const bool fast = a.M % kTM == 0 && a.N % kTN == 0 && a.K % (2 * kBK) == 0 && !getenv("MMS_LINEAR_GENERIC");
     if (fast) hipLaunchKernelGGL(linear_act_fast_kernel, grid, dim3(256), kLinearLds, s, a);
     else hipLaunchKernelGGL(linear_act_kernel, grid, dim3(256), kLinearLds, s, a);
