@@ -82,18 +82,22 @@ class RolloutStorage:
         _lib.check(L.mms_adv_normalize(idx, p(self.advantages), p(self._stats), T * N, stream), None, "mms_adv_normalize")
 
     def get_statistics(self):
-        done = self.dones.cpu().clone()
-        done[-1] = 1
-        flat_dones = done.permute(1, 0, 2).reshape(-1, 1)
-        done_indices = torch.cat((flat_dones.new_tensor([-1], dtype=torch.int64), flat_dones.nonzero(as_tuple=False)[:, 0]))
-        trajectory_lengths = (done_indices[1:] - done_indices[:-1])
-        return trajectory_lengths.float().mean(), self.rewards.mean()
+        """(mean trajectory length, mean reward) of the stored rollout, storage.py:67-72: trajectories are cut at every done
+        and at the end of the buffer, walked env by env."""
+        ended = self.dones.detach().to("cpu", copy=True)
+        ended[-1] = 1                                                   # the buffer end closes every open trajectory
+        per_env = ended.permute(1, 0, 2).reshape(-1)                    # env-major order, as the reference flattens it
+        cut = torch.nonzero(per_env, as_tuple=False).flatten()
+        lengths = torch.diff(cut, prepend=cut.new_tensor([-1]))
+        return lengths.float().mean(), self.rewards.mean()
 
     def mini_batch_generator(self, num_mini_batches):
-        batch_size = self.num_envs * self.num_transitions_per_env
-        mini_batch_size = batch_size // num_mini_batches
+        """Index batches over the T x N transitions (storage.py:74-87): in order for 'sequential', shuffled for 'random'."""
+        total = self.num_envs * self.num_transitions_per_env
         if self.sampler == "sequential":
-            subset = SequentialSampler(range(batch_size))
+            order = SequentialSampler(range(total))
         elif self.sampler == "random":
-            subset = SubsetRandomSampler(range(batch_size))
-        return BatchSampler(subset, mini_batch_size, drop_last=True)
+            order = SubsetRandomSampler(range(total))
+        else:
+            raise ValueError("sampler must be 'sequential' or 'random', not %r" % (self.sampler,))
+        return BatchSampler(order, total // num_mini_batches, drop_last=True)

@@ -35,25 +35,12 @@ class VecTask:
     def get_number_of_agents(self):
         return self.num_agents
 
-    @property
-    def observation_space(self):
-        return self.obs_space
-
-    @property
-    def action_space(self):
-        return self.act_space
-
-    @property
-    def num_envs(self):
-        return self.num_environments
-
-    @property
-    def num_acts(self):
-        return self.num_actions
-
-    @property
-    def num_obs(self):
-        return self.num_observations
+    # read-only views the algorithms use (vec_task.py:45-64)
+    observation_space = property(lambda self: self.obs_space)
+    action_space = property(lambda self: self.act_space)
+    num_envs = property(lambda self: self.num_environments)
+    num_acts = property(lambda self: self.num_actions)
+    num_obs = property(lambda self: self.num_observations)
 
 
 class VecTaskPython(VecTask):
