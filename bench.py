@@ -6,8 +6,9 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one PPO rollout step over this rank's 4096 envs: actor + critic inference (the reference's
-ActorCritic, agents/algorithms/rl/ppo/module.py: two MLPs [1024,1024,512], ELU, fp32 -- rocBLAS / hipBLASLt GEMMs),
-Gaussian action sample + log-prob + the add_transitions stores (mms_ppo_act, one HIP launch), the fused VecTask
+ActorCritic, agents/algorithms/rl/ppo/module.py: two MLPs [1024,1024,512], ELU, fp32 -- each hidden layer of both networks one
+fp32-MFMA launch with bias + ELU fused, mms_linear2_act), both last layers + Gaussian action sample + log-prob + the
+add_transitions stores (mms_ppo_heads_act, one HIP launch), the fused VecTask
 step (mms_step: physics substeps + reset + obs + reward in one HIP launch, writing observation / reward / done
 straight into the rollout slots), and every nsteps=8 steps the GAE scan + advantage normalisation
 (the span timed as collection_time in agents/algorithms/rl/ppo/ppo.py:123-161 plus compute_returns).
@@ -67,7 +68,8 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--policy-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout step eagerly instead of replaying a hipGraph")
-    ap.add_argument("--fuse-head", action="store_true", help="A/B: the actor's last Linear layer inside the sampling kernel (mms_ppo_head_act)")
+    ap.add_argument("--library-gemms", action="store_true",
+                    help="A/B: the policy's layers as library GEMMs + separate ELU passes (critic on a second stream) instead of mms_linear2_act / mms_ppo_heads_act")
     ap.add_argument("--fuse-bf16", action="store_true", help="A/B (bf16-policy series): mms_linear2_act_bf16 instead of the library bf16 GEMMs + ELU")
     ap.add_argument("--one-stream", action="store_true", help="A/B: actor and critic MLPs on one stream")
     ap.add_argument("--defer-critic", action="store_true",
@@ -171,8 +173,9 @@ def main():
         ac_ = ac if pdtype == torch.float32 else ac_bf16
         ac_.bind_rollout(None if args.unfused else storage, None if args.unfused else actions_buf)
         ac_.two_streams = not args.one_stream
-        ac_.fuse_head = args.fuse_head
+        ac_.fuse_head = not args.library_gemms
         ac_.fuse_layers_bf16 = args.fuse_bf16
+        ac_.fuse_layers = not args.library_gemms
         ac_.defer_value = args.defer_critic and not args.one_stream
 
         def rollout_step_fused():
@@ -328,7 +331,7 @@ def main():
             "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
                                    "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "actor_head_in_kernel": bool(args.fuse_head),
+                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else "mms_linear2_act + mms_ppo_heads_act",
                        "critic_deferred": bool(args.defer_critic), "finite": finite, "resets_total": resets_seen},
             "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
                          "note": "engine step with pre-drawn actions (ring of 16)", "hipgraph": sim_graph is not None},

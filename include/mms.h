@@ -221,6 +221,14 @@ int mms_ppo_head_act(int device, const float* hidden, const float* weight, const
                      float* actions_out, float* act_slot, float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot,
                      int64_t N, int32_t A, void* hip_stream);
 
+/* mms_ppo_head_act that also evaluates the critic's last layer (module.py:49: nn.Linear(vf_hid_sizes[-1], 1)) when vhidden is
+ * given: value_i = vhidden[i, :] . vweight + vbias[0] (vhidden [N,VH] f32 = output of the critic's last activation, VH a multiple
+ * of 4) goes to value_slot; `value` is ignored then.  vhidden = NULL: exactly mms_ppo_head_act. */
+int mms_ppo_heads_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H, const float* value,
+                      const float* vhidden, const float* vweight, const float* vbias, int32_t VH, const float* log_std, uint64_t seed,
+                      int64_t* counters, int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
+                      float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N, int32_t A, void* hip_stream);
+
 /* One hidden layer of the PPO policy for BOTH networks in one launch (module.py:27-52: nn.Linear + activation, actor and
  * critic of the same shape): y_g = act(x_g @ w_g^T + b_g), g = 0, 1, on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact
  * fp32 products and sums) with bias and activation in the epilogue.  x [M,K], w [N,K] and b [N] in torch's Linear layout,

@@ -65,14 +65,14 @@ class ActorCritic(nn.Module):
         for idx, module in enumerate(m for m in sequential if isinstance(m, nn.Linear)):
             torch.nn.init.orthogonal_(module.weight, gain=scales[idx])
 
-    # last actor Linear inside the sampling kernel (mms_ppo_head_act) when its shape allows.  Opt-in: stand-alone it beats the
-    # library's skinny GEMM + mms_ppo_act (12.2 us against 14.6 us at N 4096, H 512, A 80) but inside the two-stream rollout,
-    # next to the critic's GEMMs, the rollout step measured 371.8 us with it and 365.5 us without (profiles/r01_v8_rollout_ab.txt)
-    fuse_head = False
-    # hidden layers of both networks through mms_linear2_act (own fp32-MFMA GEMM with bias + ELU fused, one launch per layer).
-    # Opt-in: 112-120 TFLOP/s on the 1024- / 512-wide layers (library GEMM + separate ELU: 108-116), 305 us for the three hidden
-    # layers against ~290 us for the two-stream library path (profiles/r01_v11_linear_probe.txt): parity, not yet a win.
-    fuse_layers = False
+    # Hidden layers of both networks through mms_linear2_act (own fp32-MFMA GEMM, bias + ELU in the epilogue, one launch per layer
+    # for both networks) and both last layers inside the sampling kernel (mms_ppo_heads_act): five launches per `act`.  Used when
+    # the networks qualify (fp32, ELU, actor and critic of the same hidden shapes, last hidden width a multiple of 64); otherwise
+    # the library path below.  Rollout step at 4096 envs: 350 us, against 361 us for the library GEMMs + separate ELU passes with the
+    # critic on a second stream (profiles/r01_v12_*).  With fuse_layers off, fuse_head alone puts only the actor's last layer into
+    # the sampling kernel (no gain next to the critic's GEMMs: 371.8 us against 365.5 us, profiles/r01_v8_rollout_ab.txt).
+    fuse_layers = True
+    fuse_head = True
     # the same for a bf16 copy of the module (mms_linear2_act_bf16).  Opt-in: 102 us for the three hidden layers of both networks
     # (~480 TFLOP/s on the 1024-wide layer) against ~85 us of library bf16 GEMMs + the ELU / cast passes; inside the rollout the
     # bf16-policy series measured 22.1 M env-steps/s with it and 23.1 M without (profiles/r01_v11_linear_probe.txt)
@@ -162,9 +162,10 @@ class ActorCritic(nn.Module):
             return None, self._trunk[0](x)
         return self.actor(x), None
 
-    def _sample(self, mean, value, hidden=None):
-        """mean [N, A] (or None with hidden [N, H]: the last actor layer runs in the kernel); value [N, 1] or None (the caller
-        stores the value itself).  Returns act, logp, val, mu, sigma."""
+    def _sample(self, mean, value, hidden=None, vhidden=None):
+        """mean [N, A] (or None with hidden [N, H]: the last actor layer runs in the kernel); value [N, 1], or None with vhidden
+        [N, VH] (the last critic layer runs in the kernel too), or None alone (the caller stores the value itself).
+        Returns act, logp, val, mu, sigma."""
         src = mean if mean is not None else hidden
         N, A = src.shape[0], self.log_std.shape[0]
         dev = src.device
@@ -193,9 +194,13 @@ class ActorCritic(nn.Module):
         else:
             last = self.actor[-1]
             hidden = hidden.contiguous()
-            _lib.check(L.mms_ppo_head_act(idx, p(hidden), p(last.weight.detach()), p(last.bias.detach()), last.in_features, p(value),
-                                          p(log_std), self.seed, p(self._counters), self.row_offset, 1, p(actions_out), p(act), p(logp),
-                                          p(val), p(mu), p(sigma), N, A, current_stream_ptr(dev)), None, "mms_ppo_head_act")
+            vlast = self.critic[-1]
+            vh = None if vhidden is None else vhidden.contiguous()
+            _lib.check(L.mms_ppo_heads_act(idx, p(hidden), p(last.weight.detach()), p(last.bias.detach()), last.in_features, p(value), p(vh),
+                                           None if vh is None else p(vlast.weight.detach()), None if vh is None else p(vlast.bias.detach()),
+                                           0 if vh is None else vlast.in_features, p(log_std), self.seed, p(self._counters), self.row_offset, 1,
+                                           p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A, current_stream_ptr(dev)),
+                       None, "mms_ppo_heads_act")
         return act, logp.view(-1), val, mu, sigma
 
     def act(self, observations, states):
@@ -211,7 +216,11 @@ class ActorCritic(nn.Module):
                 hidden = self._fused_hidden(observations, critic_in)
                 if hidden is not None:
                     ha, hc = hidden
-                    return self._sample(self.actor[-1](ha), self.critic[-1](hc))
+                    la, lc = self.actor[-1], self.critic[-1]
+                    if (self.fuse_head and la.in_features % 64 == 0 and la.out_features <= 128 and la.bias is not None
+                            and lc.in_features % 4 == 0 and lc.out_features == 1 and lc.bias is not None):
+                        return self._sample(None, None, hidden=ha, vhidden=hc)       # both heads + sampling in one launch
+                    return self._sample(la(ha), lc(hc))
             if not (observations.is_cuda and self.two_streams):
                 mean, hidden = self._actor_pass(observations.to(dtype))
                 return self._sample(mean, self.critic(critic_in), hidden)

@@ -39,8 +39,8 @@ struct LinearBf16Args {
     int act;
 };
 hipError_t launch_linear_act_bf16(const LinearBf16Args& a, int groups, int x_is_f32, hipStream_t s);
-hipError_t launch_ppo_head_act(const float*, const float*, const float*, int, const float*, const float*, uint64_t, int64_t*, int64_t, int, float*, float*, float*,
-                               float*, float*, float*, int64_t, int, hipStream_t);
+hipError_t launch_ppo_head_act(const float*, const float*, const float*, int, const float*, const float*, const float*, const float*, int, const float*, uint64_t,
+                               int64_t*, int64_t, int, float*, float*, float*, float*, float*, float*, int64_t, int, hipStream_t);
 }  // namespace mms
 
 struct mms_buffer {
@@ -393,13 +393,27 @@ __attribute__((visibility("default"))) int mms_ppo_head_act(int device, const fl
                                                             int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
                                                             float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N,
                                                             int32_t A, void* s) {
+    return mms_ppo_heads_act(device, hidden, weight, bias, H, value, nullptr, nullptr, nullptr, 0, log_std, seed, counters, row_offset,
+                             reference_scale, actions_out, act_slot, logp_slot, value_slot, mu_slot, sigma_slot, N, A, s);
+}
+
+__attribute__((visibility("default"))) int mms_ppo_heads_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H,
+                                                             const float* value, const float* vhidden, const float* vweight, const float* vbias,
+                                                             int32_t VH, const float* log_std, uint64_t seed, int64_t* counters,
+                                                             int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
+                                                             float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N,
+                                                             int32_t A, void* s) {
     if (dev_guard(device)) return 1;
     if (!hidden || !weight || !bias || !log_std || !counters || N < 0 || A <= 0 || A > 128 || H <= 0 || (H % 64) != 0) {
         g_create_error = "mms_ppo_head_act: bad arguments (A must be in 1..128, H a positive multiple of 64)";
         return 1;
     }
-    MMS_FREE(mms::launch_ppo_head_act(hidden, weight, bias, H, value, log_std, seed, counters, row_offset, reference_scale, actions_out, act_slot,
-                                      logp_slot, value_slot, mu_slot, sigma_slot, N, A, (hipStream_t)s));
+    if (vhidden && (!vweight || !vbias || VH <= 0 || (VH % 4) != 0)) {
+        g_create_error = "mms_ppo_heads_act: the value head needs weight, bias and a hidden width that is a multiple of 4";
+        return 1;
+    }
+    MMS_FREE(mms::launch_ppo_head_act(hidden, weight, bias, H, value, vhidden, vweight, vbias, VH, log_std, seed, counters, row_offset, reference_scale,
+                                      actions_out, act_slot, logp_slot, value_slot, mu_slot, sigma_slot, N, A, (hipStream_t)s));
     return 0;
 }
 

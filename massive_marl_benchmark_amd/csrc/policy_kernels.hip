@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
     }
 }
 
-// Fast path for M % 128 == 0, N % 128 == 0, K % 64 == 0 (the 1024- and 512-wide hidden layers): the same tiling with the K
+// Fast path for M % 128 == 0 and N % 128 == 0 (all three hidden layers at 4096 envs): the same tiling with the K
 // loop written as a software pipeline in program order.  One wave issues in order, so whatever is not an MFMA has to sit BETWEEN
 // MFMAs (each keeps the matrix pipe busy for 64 cycles) instead of in front of them: per slice of 32 k = four groups of 16 MFMAs,
 //   group 0: fragment reads of group 1,            16 MFMAs with the 8 global loads of slice kt+2 between them
@@ -165,6 +165,9 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
     fb[S][1] = *reinterpret_cast<const float4*>((bbase) + 32 * kPitch + (ko));                               \
     __builtin_amdgcn_sched_barrier(0);
 
+// TAIL: K is any multiple of 4 (the 388-wide first layer): K is walked to the next multiple of 32, a float4 whose k lies beyond K
+// is read from the last valid float4 of its row instead and multiplied by zero (no branch in the pipeline).
+template <bool TAIL>
 __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = blockIdx.z;
@@ -196,11 +199,23 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
     float4 ra1_0, ra1_1, ra1_2, ra1_3, rb1_0, rb1_1, rb1_2, rb1_3;   // set 1 = odd slices (named scalars: arrays of them land in scratch)
     float4 fa[2][2], fb[2][2];                              // fragment sets, alternating per group
 
-    const int nkt = K / kBK;                                // even
-#define MMS_LD(SET, J, KOFF) ra##SET##_##J = *reinterpret_cast<const float4*>(xg + (J) * rs + (KOFF)); rb##SET##_##J = *reinterpret_cast<const float4*>(wg + (J) * rs + (KOFF));
+    const int nkt = (K + kBK - 1) / kBK;
+    const int k_last = K - 4 - sk;                          // (TAIL) offset of this thread's column group clamped to the last valid float4
+#define MMS_LD(SET, J, KOFF)                                                                                                    \
+    {                                                                                                                            \
+        const bool ok = !TAIL || (KOFF) + sk < K;                                                                                \
+        const int ko = ok ? (KOFF) : k_last;                                                                                     \
+        const float m = ok ? 1.f : 0.f;                                                                                          \
+        ra##SET##_##J = *reinterpret_cast<const float4*>(xg + (J) * rs + ko);                                                    \
+        rb##SET##_##J = *reinterpret_cast<const float4*>(wg + (J) * rs + ko);                                                    \
+        if (TAIL) {                                                                                                              \
+            ra##SET##_##J.x *= m; ra##SET##_##J.y *= m; ra##SET##_##J.z *= m; ra##SET##_##J.w *= m;                              \
+            rb##SET##_##J.x *= m; rb##SET##_##J.y *= m; rb##SET##_##J.z *= m; rb##SET##_##J.w *= m;                              \
+        }                                                                                                                        \
+    }
 #define MMS_ST(SET, J, BOFF) *reinterpret_cast<float4*>(as_st + (BOFF) + (J) * 32 * kPitch) = ra##SET##_##J; *reinterpret_cast<float4*>(bs_st + (BOFF) + (J) * 32 * kPitch) = rb##SET##_##J;
     MMS_LD(0, 0, 0) MMS_LD(0, 1, 0) MMS_LD(0, 2, 0) MMS_LD(0, 3, 0)
-    MMS_LD(1, 0, kBK) MMS_LD(1, 1, kBK) MMS_LD(1, 2, kBK) MMS_LD(1, 3, kBK)
+    { const int k1 = nkt > 1 ? kBK : 0; MMS_LD(1, 0, k1) MMS_LD(1, 1, k1) MMS_LD(1, 2, k1) MMS_LD(1, 3, k1) }
     MMS_ST(0, 0, 0) MMS_ST(0, 1, 0) MMS_ST(0, 2, 0) MMS_ST(0, 3, 0)
     __syncthreads();
     MMS_FRAGS(0, a_fr, b_fr, 0)
@@ -245,8 +260,9 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
         MMS_MFMA4(1, x) MMS_MFMA4(1, y) MMS_MFMA4(1, z) MMS_MFMA4(1, w)                                                          \
     }
 
-    for (int kt = 0; kt < nkt; kt += 2) {
+    for (int kt = 0; kt < nkt; kt += 2) {                   // two slices per trip so that the register sets alternate by name
         MMS_SLICE(0, 1, 0, kt)
+        if (kt + 1 >= nkt) break;
         MMS_SLICE(1, 0, 1, kt + 1)
     }
 #undef MMS_SLICE
@@ -385,7 +401,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_bf16_kernel(LinearBf16Args 
 
 // More than 64 KB of dynamic LDS needs an opt-in per kernel and per device; remembered so that it is asked for once.
 static hipError_t allow_large_lds(const void* kernel, int slot) {
-    static bool done[4][64] = {};
+    static bool done[5][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -411,9 +427,11 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
     dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, groups);
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel), 2); e != hipSuccess) return e;
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel), 3); e != hipSuccess) return e;
-    const bool fast = a.M % kTM == 0 && a.N % kTN == 0 && a.K % (2 * kBK) == 0 && !getenv("MMS_LINEAR_GENERIC");
-    if (fast) hipLaunchKernelGGL(linear_act_fast_kernel, grid, dim3(256), kLinearLds, s, a);
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<false>), 3); e != hipSuccess) return e;
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<true>), 4); e != hipSuccess) return e;
+    const bool fast = a.M % kTM == 0 && a.N % kTN == 0 && a.K >= 8 && !getenv("MMS_LINEAR_GENERIC");
+    if (fast && a.K % kBK == 0) hipLaunchKernelGGL(linear_act_fast_kernel<false>, grid, dim3(256), kLinearLds, s, a);
+    else if (fast) hipLaunchKernelGGL(linear_act_fast_kernel<true>, grid, dim3(256), kLinearLds, s, a);
     else hipLaunchKernelGGL(linear_act_kernel, grid, dim3(256), kLinearLds, s, a);
     return hipGetLastError();
 }

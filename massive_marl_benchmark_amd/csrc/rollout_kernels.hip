@@ -145,7 +145,7 @@ struct PpoActOut {
 };
 __device__ __forceinline__ void ppo_sample_row(const float* mean_row, const float* __restrict__ value, const float* __restrict__ log_std,
                                                uint64_t seed, int64_t* __restrict__ counters, int64_t row_offset, int ref_scale,
-                                               const PpoActOut& o, int64_t row, int A, int lane) {
+                                               const PpoActOut& o, int64_t row, int A, int lane, bool have_value = false, float value_now = 0.f) {
     const int64_t c = counters[row];
     float lp = 0.f;
     for (int j = lane; j < A; j += 64) {
@@ -166,7 +166,7 @@ __device__ __forceinline__ void ppo_sample_row(const float* mean_row, const floa
     for (int m = 32; m >= 1; m >>= 1) lp += __shfl_xor(lp, m, 64);
     if (lane == 0) {
         if (o.logp_slot) o.logp_slot[row] = lp;
-        if (o.value_slot && value) o.value_slot[row] = value[row];
+        if (o.value_slot && (have_value || value)) o.value_slot[row] = have_value ? value_now : value[row];
         counters[row] = c + 1;
     }
 }
@@ -190,6 +190,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NCT, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* __restrict__ hidden, const float* __restrict__ weight,
                                                            const float* __restrict__ bias, int H, const float* __restrict__ value,
+                                                           const float* __restrict__ vhidden, const float* __restrict__ vweight,
+                                                           const float* __restrict__ vbias, int VH,
                                                            const float* __restrict__ log_std, uint64_t seed, int64_t* __restrict__ counters,
                                                            int64_t row_offset, int ref_scale, PpoActOut o, int64_t N, int A) {
     extern __shared__ __attribute__((aligned(16))) float s_part[];      // [WAVES][16 rows][AP], then [16][AP] means
@@ -252,7 +254,19 @@ __global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* _
     constexpr int RPW = 16 / WAVES;                                          // rows sampled per wave (WAVES in 1, 2, 4, 8)
     for (int r = wave * RPW; r < wave * RPW + RPW; r++) {
         const int64_t row = r0 + r;
-        if (row < N) ppo_sample_row(s_mean + r * AP, value, log_std, seed, counters, row_offset, ref_scale, o, row, A, lane);
+        if (row >= N) continue;
+        float v_row = 0.f;
+        if (vhidden) {                           // the critic's last layer (module.py:49: nn.Linear(hidden, 1)): one dot product per row
+            const float* hv = vhidden + row * (int64_t)VH;
+            for (int k = lane * 4; k < VH; k += 256) {
+                const float4 h4 = *reinterpret_cast<const float4*>(hv + k), w4 = *reinterpret_cast<const float4*>(vweight + k);
+                v_row += h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v_row += __shfl_xor(v_row, m, 64);
+            v_row += vbias[0];
+        }
+        ppo_sample_row(s_mean + r * AP, value, log_std, seed, counters, row_offset, ref_scale, o, row, A, lane, vhidden != nullptr, v_row);
     }
 }
 
@@ -290,7 +304,8 @@ hipError_t launch_ppo_act(const float* mean, const float* value, const float* lo
     hipLaunchKernelGGL(ppo_act_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, mean, value, log_std, seed, counters, row_offset, ref_scale, o, N, A);
     return hipGetLastError();
 }
-hipError_t launch_ppo_head_act(const float* hidden, const float* weight, const float* bias, int H, const float* value, const float* log_std,
+hipError_t launch_ppo_head_act(const float* hidden, const float* weight, const float* bias, int H, const float* value, const float* vhidden,
+                               const float* vweight, const float* vbias, int VH, const float* log_std,
                                uint64_t seed, int64_t* counters, int64_t row_offset, int ref_scale, float* actions_out, float* act_slot,
                                float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N, int A, hipStream_t s) {
     if (N == 0) return hipSuccess;
@@ -300,8 +315,8 @@ hipError_t launch_ppo_head_act(const float* hidden, const float* weight, const f
     const size_t lds = (size_t)(waves + 1) * 16 * (nct * 16) * sizeof(float);
     const dim3 grid((unsigned)((N + 15) / 16));
 #define MMS_HEAD_W(NCT, W)                                                                                                                        \
-    hipLaunchKernelGGL((ppo_head_act_kernel<NCT, W>), grid, dim3(64 * W), lds, s, hidden, weight, bias, H, value, log_std, seed, counters, row_offset, \
-                       ref_scale, o, N, A)
+    hipLaunchKernelGGL((ppo_head_act_kernel<NCT, W>), grid, dim3(64 * W), lds, s, hidden, weight, bias, H, value, vhidden, vweight, vbias, VH, \
+                       log_std, seed, counters, row_offset, ref_scale, o, N, A)
 #define MMS_HEAD(NCT)                                                                                                                              \
     case NCT:                                                                                                                                      \
         if (waves == 8) MMS_HEAD_W(NCT, 8);                                                                                                        \

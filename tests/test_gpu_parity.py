@@ -996,8 +996,15 @@ def test_fused_act_and_bound_rollout(torch_cuda):
         assert torch.equal(st.actions[t], actions) and torch.equal(st.actions_log_prob[t].view(-1), logp)
         cur = eng.tensor("obs_clipped").clone()
     assert st.step == T
-    # hidden layers through mms_linear2_act: same means / values as the library path
-    ac.fuse_layers = True
+    # hidden layers through mms_linear2_act (+ both heads in the sampling kernel): same means / values as the library path
+    for heads in (False, True):
+        ac.fuse_layers, ac.fuse_head = True, heads
+        st.clear()
+        _, _, v_f, mu_f, _ = ac.act(st.observations[0], states)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            assert float((ac.actor(st.observations[0]) - mu_f).abs().max()) < 1e-5 and float((ac.critic(st.observations[0]) - v_f).abs().max()) < 1e-5
+    ac.fuse_layers, ac.fuse_head = True, True
     st.clear()
     _, _, v_f, mu_f, _ = ac.act(st.observations[0], states)
     ac.fuse_layers = False
