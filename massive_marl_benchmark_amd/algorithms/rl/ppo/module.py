@@ -90,15 +90,21 @@ class ActorCritic(nn.Module):
         not copy again) and `actions_out` (e.g. the engine's "actions" buffer)."""
         self._bound = (storage, actions_out)
 
+    def _fp32_layers_qualify(self):
+        """mms_linear2_act applies: fp32 ELU networks, actor and critic with the same hidden shapes, input widths multiples of 4."""
+        a_lin = [m for m in self.actor if isinstance(m, nn.Linear)]
+        c_lin = [m for m in self.critic if isinstance(m, nn.Linear)]
+        acts = [m for m in list(self.actor) + list(self.critic) if not isinstance(m, nn.Linear)]
+        return (len(a_lin) == len(c_lin) and len(a_lin) >= 2 and all(isinstance(m, nn.ELU) and m.alpha == 1.0 for m in acts)
+                and all(la.weight.shape == lc.weight.shape and la.weight.dtype == torch.float32 and la.in_features % 4 == 0
+                        and la.bias is not None and lc.bias is not None for la, lc in zip(a_lin[:-1], c_lin[:-1])))
+
     def _fused_hidden(self, x, critic_in):
         """Hidden layers of BOTH networks, one mms_linear2_act launch per layer (fp32 MFMA, bias + ELU in the epilogue).
         Returns (actor hidden, critic hidden) or None when the two MLPs are not ELU networks of identical hidden shapes."""
         a_lin = [m for m in self.actor if isinstance(m, nn.Linear)]
         c_lin = [m for m in self.critic if isinstance(m, nn.Linear)]
-        acts = [m for m in list(self.actor) + list(self.critic) if not isinstance(m, nn.Linear)]
-        if (len(a_lin) != len(c_lin) or len(a_lin) < 2 or not all(isinstance(m, nn.ELU) and m.alpha == 1.0 for m in acts)
-                or any(la.weight.shape != lc.weight.shape or la.weight.dtype != torch.float32 or la.in_features % 4
-                       for la, lc in zip(a_lin[:-1], c_lin[:-1]))):
+        if not self._fp32_layers_qualify():
             return None
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         dev = x.device
@@ -212,7 +218,7 @@ class ActorCritic(nn.Module):
                 if hidden is not None:
                     ha, hc = hidden
                     return self._sample(self.actor[-1](ha), self.critic[-1](hc))
-            if self.fuse_layers and observations.is_cuda and dtype == torch.float32:
+            if self.fuse_layers and observations.is_cuda and dtype == torch.float32 and not self.defer_value:
                 hidden = self._fused_hidden(observations, critic_in)
                 if hidden is not None:
                     ha, hc = hidden
