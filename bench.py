@@ -338,6 +338,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "mms::ant_step_kernel<TEN_ANT, 192, 4, 10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (tr or {}).get("source"),
+                         "traffic_note": "launches of the rollout step (one observation row per env-step); the stand-alone engine "
+                                         "configuration of the back-to-back launches also writes its raw + clamped observation "
+                                         "buffers: %s bytes per launch" % ((tr or {}).get("engine_buffers_configuration") or {}).get("traffic_bytes_per_launch"),
                          "bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "launch_ms": kernel_ms,
                          "launch_ms_back_to_back": kernel_ms_b2b, "launch_ms_in_rollout": kernel_ms_roll,
                          "launches": {"back_to_back": n_b2b, "in_rollout": n_roll},

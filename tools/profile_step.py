@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--rollout-outputs", action="store_true",
+                    help="write what bench.py's rollout step writes: ONE clamped observation row per env-step (into a bound "
+                         "rollout slot) plus the reward / done slots, instead of the engine's raw + clamped observation buffers")
     args = ap.parse_args()
     import torch
     from massive_marl_benchmark_amd.engine import Engine
@@ -25,8 +28,15 @@ def main():
     g = torch.Generator().manual_seed(1234)
     ring = [(torch.rand(args.num_envs, eng.num_actions, generator=g) * 2 - 1).cuda() for _ in range(16)]
     act = eng.tensor("actions")
+    if args.rollout_outputs:
+        slots = torch.empty(8, args.num_envs, eng.obs_dim, device="cuda")
+        rew, done = torch.empty(8, args.num_envs, device="cuda"), torch.empty(8, args.num_envs, dtype=torch.uint8, device="cuda")
+        eng.set_obs_outputs(raw=False, clipped=False)
     for i in range(args.warmup + args.steps):
         act.copy_(ring[i % 16])
+        if args.rollout_outputs:
+            eng.bind_obs_out(slots[i % 8])
+            eng.bind_rollout_out(rew[i % 8], done[i % 8])
         eng.step()
     torch.cuda.synchronize()
     print("resets", int(eng.tensor("reset_count").sum()), "finite", bool(torch.isfinite(eng.tensor("obs")).all()))
