@@ -230,7 +230,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
                 const float tau1 = s_act[0] * L.gear[0] * C->power_scale;    // ten_ant.py:889
                 const float tau2 = s_act[1] * L.gear[1] * C->power_scale;
                 leg_inward<kSensors, DR>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0, park, s_dr);
-            } else { sym_zero(IA0); pA0 = S6{V3{0, 0, 0}, V3{0, 0, 0}}; }
+            }
+            // (quads never mix ant and box lanes, and `simulate` is per env: a quad that skipped the inward pass skips the outward
+            // pass too, so what the reduction leaves in its lanes is never read -- no zero fill)
             quad_sum(IA0, pA0);
             if (is_ant && simulate) leg_outward<kSensors>(M, L, h, S, leg, *s_bp, P, &SP, IA0, pA0, wr, sens, park);
             return wr;
