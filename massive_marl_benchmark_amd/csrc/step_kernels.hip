@@ -106,7 +106,10 @@ __host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
 // DR: per-env physical domain randomisation (mass / damping scales, limit offsets) read from a.dr; a separate instantiation so
 // that the nominal kernel carries none of it.
 template <int TASK, int BLOCK, int EPB, int AT, bool DR>
-__global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK == 192 ? MMS_WAVES_PER_EU_PACKED : 1)) ant_step_kernel(StepArgs a) {
+#ifndef MMS_WAVES_PER_EU_WIDE
+#define MMS_WAVES_PER_EU_WIDE 1
+#endif
+__global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK == 192 ? MMS_WAVES_PER_EU_PACKED : MMS_WAVES_PER_EU_WIDE)) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const mms_config* __restrict__ C = a.cfg;
     const mms_model* __restrict__ M = &C->model;
