@@ -98,8 +98,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # MMS_BENCH_BACKEND=gloo is a rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
+        # the devices round robin; the timing it prints is not a scaling figure).  The driver's runs use RCCL, one rank per GPU.
+        backend = os.environ.get("MMS_BENCH_BACKEND", "nccl")
+        if backend == "gloo":
+            local_rank = local_rank % torch.cuda.device_count()
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -308,6 +315,8 @@ def main():
     kernel_ms = (n_b2b * kernel_ms_b2b + n_roll * kernel_ms_roll) / (n_b2b + n_roll)
     tmax = torch.tensor([elapsed, sim_wall, kernel_ms, bf_elapsed, kernel_ms_b2b, kernel_ms_roll], dtype=torch.float64, device=device)
     if dist is not None:
+        if dist.get_backend() == "gloo":
+            tmax = tmax.cpu()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, sim_wall, kernel_ms, bf_elapsed, kernel_ms_b2b, kernel_ms_roll = [float(x) for x in tmax.tolist()]
     finite = bool(torch.isfinite(obs_clipped).all().item()) and bool(torch.isfinite(rew).all().item())
