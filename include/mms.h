@@ -232,7 +232,8 @@ int mms_ppo_heads_act(int device, const float* hidden, const float* weight, cons
 /* One hidden layer of the PPO policy for BOTH networks in one launch (module.py:27-52: nn.Linear + activation, actor and
  * critic of the same shape): y_g = act(x_g @ w_g^T + b_g), g = 0, 1, on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact
  * fp32 products and sums) with bias and activation in the epilogue.  x [M,K], w [N,K] and b [N] in torch's Linear layout,
- * y [M,N], all f32 and contiguous; K a multiple of 4; act 0 = identity, 1 = ELU(alpha 1) (cfg/ppo/config.yaml:9).
+ * y [M,N], all f32 and contiguous; K a multiple of 4; act 0 = identity, 1 = ELU(alpha 1) (cfg/ppo/config.yaml:9),
+ * 2 = ReLU (the DDPG / TD3 actor, rl/ddpg/module.py:37), 3 = tanh (its output layer, :18).
  * x1 = w1 = b1 = y1 = NULL runs a single problem.  x0 and x1 may be the same buffer (first layer). */
 int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const float* x0, const float* w0, const float* b0, float* y0,
                     const float* x1, const float* w1, const float* b1, float* y1, int32_t act, void* hip_stream);

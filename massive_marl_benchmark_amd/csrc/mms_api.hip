@@ -421,8 +421,8 @@ __attribute__((visibility("default"))) int mms_linear2_act(int device, int64_t M
                                                            float* y0, const float* x1, const float* w1, const float* b1, float* y1, int32_t act,
                                                            void* s) {
     if (dev_guard(device)) return 1;
-    if (!x0 || !w0 || !b0 || !y0 || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || (K % 4) != 0 || (act != 0 && act != 1)) {
-        g_create_error = "mms_linear2_act: bad arguments (K must be a positive multiple of 4, act 0 or 1)";
+    if (!x0 || !w0 || !b0 || !y0 || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || (K % 4) != 0 || act < 0 || act > 3) {
+        g_create_error = "mms_linear2_act: bad arguments (K must be a positive multiple of 4, act 0..3)";
         return 1;
     }
     const bool two = x1 || w1 || b1 || y1;
@@ -436,7 +436,7 @@ __attribute__((visibility("default"))) int mms_linear2_act_bf16(int device, int6
                                                                 const void* x0, const void* w0, const float* b0, void* y0, const void* x1,
                                                                 const void* w1, const float* b1, void* y1, int32_t act, void* s) {
     if (dev_guard(device)) return 1;
-    if (!x0 || !w0 || !b0 || !y0 || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || ldw < K || (ldw % 64) != 0 || (act != 0 && act != 1) ||
+    if (!x0 || !w0 || !b0 || !y0 || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || ldw < K || (ldw % 64) != 0 || act < 0 || act > 3 ||
         (x_is_f32 ? (K % 4) != 0 : (K % 64) != 0)) {
         g_create_error = "mms_linear2_act_bf16: bad arguments (ldw a multiple of 64 >= K; K a multiple of 4 for fp32 x, of 64 for bf16 x)";
         return 1;

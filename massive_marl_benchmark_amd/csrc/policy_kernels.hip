@@ -17,13 +17,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTM = 128, kTN = 128;
 
+// epilogue activation (uniform per launch): 0 identity, 1 ELU (alpha = 1, torch.nn.ELU), 2 ReLU, 3 tanh
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return (v > 0.f) ? v : (expf(v) - 1.f);
+    if (act == 2) return fmaxf(v, 0.f);
+    if (act == 3) return tanhf(v);
+    return v;
+}
+
 struct LinearArgs {
     const float* x[2];
     const float* w[2];
     const float* b[2];
     float* y[2];
     int M, N, K;
-    int act;        // 0: identity, 1: ELU (alpha = 1)
+    int act;        // 0: identity, 1: ELU (alpha = 1), 2: ReLU, 3: tanh
 };
 
 // LDS layout: both operand tiles row-major, [128 rows][32 k + 4 pad] -- exactly how they arrive from HBM, so staging is a plain
@@ -35,7 +43,11 @@ struct LinearArgs {
 constexpr int kBK = 32, kPitch = kBK + 4;
 constexpr size_t kLinearLds = (size_t)2 * 2 * 128 * kPitch * sizeof(float);     // two operands, two buffers: 73.7 KB
 
+// MI = 2: 128 x 128 output tile, each of the four waves a 64 x 64 quarter; MI = 1: 64 x 128 tile, each wave 32 x 64 -- twice
+// the blocks for problems whose 128-row tiling would leave CUs idle (the 8192 x 256 layers of the DDPG / TD3 actor).
+template <int MI>
 __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
+    constexpr int TM = 64 * MI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = blockIdx.z;
     const float* __restrict__ X = a.x[g];
@@ -43,9 +55,9 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
     const float* __restrict__ Bv = a.b[g];
     float* __restrict__ Y = a.y[g];
     const int M = a.M, N = a.N, K = a.K;
-    const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * kTN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64; // this wave's quarter of the tile
+    const int wr = (wave >> 1) * (32 * MI), wc = (wave & 1) * 64; // this wave's quarter of the tile
     const int li = lane & 31, lh = lane >> 5;
     float* As = smem;                                       // [2][128][kPitch]
     float* Bs = smem + 2 * 128 * kPitch;
@@ -60,21 +72,21 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int row = m0 + sr + 32 * j, col = n0 + sr + 32 * j;
-            ra[set][j] = (row < M && k < K) ? *reinterpret_cast<const float4*>(X + (size_t)row * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < 2 * MI) ra[set][j] = (row < M && k < K) ? *reinterpret_cast<const float4*>(X + (size_t)row * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             rb[set][j] = (col < N && k < K) ? *reinterpret_cast<const float4*>(W + (size_t)col * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_slice = [&](int buf, int set) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            *reinterpret_cast<float4*>(As + ((size_t)buf * 128 + sr + 32 * j) * kPitch + sk) = ra[set][j];
+            if (j < 2 * MI) *reinterpret_cast<float4*>(As + ((size_t)buf * 128 + sr + 32 * j) * kPitch + sk) = ra[set][j];
             *reinterpret_cast<float4*>(Bs + ((size_t)buf * 128 + sr + 32 * j) * kPitch + sk) = rb[set][j];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -90,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
             for (int c = 0; c < 2; c++) {
                 const int ko = 16 * half + 8 * c;
                 af[c][0] = *reinterpret_cast<const float4*>(a_base + ko);
-                af[c][1] = *reinterpret_cast<const float4*>(a_base + 32 * kPitch + ko);
+                if (MI == 2) af[c][1] = *reinterpret_cast<const float4*>(a_base + 32 * kPitch + ko);
                 bf[c][0] = *reinterpret_cast<const float4*>(b_base + ko);
                 bf[c][1] = *reinterpret_cast<const float4*>(b_base + 32 * kPitch + ko);
             }
@@ -100,8 +112,10 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
 #define MMS_STEP(e)                                                                                          \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0].e, bf[c][0].e, acc[0][0], 0, 0, 0);            \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0].e, bf[c][1].e, acc[0][1], 0, 0, 0);            \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1].e, bf[c][0].e, acc[1][0], 0, 0, 0);            \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1].e, bf[c][1].e, acc[1][1], 0, 0, 0);
+    if (MI == 2) {                                                                                           \
+        acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1].e, bf[c][0].e, acc[MI - 1][0], 0, 0, 0); \
+        acc[MI - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1].e, bf[c][1].e, acc[MI - 1][1], 0, 0, 0); \
+    }
                 MMS_STEP(x) MMS_STEP(y) MMS_STEP(z) MMS_STEP(w)
 #undef MMS_STEP
             }
@@ -132,12 +146,12 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
         const int col = n0 + wc + 32 * j + li;
         const float bias = (col < N) ? Bv[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < MI; i++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = acc[i][j][r] + bias;
-                if (a.act == 1) v = (v > 0.f) ? v : (expf(v) - 1.f);         // torch.nn.ELU, alpha = 1
+                v = apply_act(v, a.act);
                 if (row < M && col < N) Y[(size_t)row * N + col] = v;
             }
         }
@@ -277,7 +291,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
         float* yp = Y + (size_t)(m0 + wr + 32 * (I) + 4 * lh) * N + col;                                     \
         _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                     \
             float v = ACC[r] + bias;                                                                         \
-            if (a.act == 1) v = (v > 0.f) ? v : (expf(v) - 1.f);                                             \
+            v = apply_act(v, a.act);                                             \
             yp[(size_t)((r & 3) + 8 * (r >> 2)) * N] = v;                                                    \
         }                                                                                                    \
     }
@@ -392,7 +406,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_bf16_kernel(LinearBf16Args 
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = acc[i][j][r] + bias;
-                if (a.act == 1) v = (v > 0.f) ? v : (expf(v) - 1.f);
+                v = apply_act(v, a.act);
                 if (row < M && col < N) Y[(size_t)row * N + col] = (__bf16)v;
             }
         }
@@ -401,7 +415,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_bf16_kernel(LinearBf16Args 
 
 // More than 64 KB of dynamic LDS needs an opt-in per kernel and per device; remembered so that it is asked for once.
 static hipError_t allow_large_lds(const void* kernel, int slot) {
-    static bool done[5][64] = {};
+    static bool done[6][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -426,13 +440,19 @@ hipError_t launch_linear_act_bf16(const LinearBf16Args& a, int groups, int x_is_
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
     dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, groups);
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel), 2); e != hipSuccess) return e;
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel<2>), 2); e != hipSuccess) return e;
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<false>), 3); e != hipSuccess) return e;
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<true>), 4); e != hipSuccess) return e;
-    const bool fast = a.M % kTM == 0 && a.N % kTN == 0 && a.K >= 8 && !getenv("MMS_LINEAR_GENERIC");
-    if (fast && a.K % kBK == 0) hipLaunchKernelGGL(linear_act_fast_kernel<false>, grid, dim3(256), kLinearLds, s, a);
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel<1>), 5); e != hipSuccess) return e;
+    // 128-row tiles that would not give every CU a block (the small layers of the off-policy actor): 64-row tiles, twice the blocks
+    const bool small = (size_t)grid.x * grid.y * grid.z < 256 && a.M > 64 && !getenv("MMS_LINEAR_TALL_TILES");
+    const bool fast = !small && a.M % kTM == 0 && a.N % kTN == 0 && a.K >= 8 && !getenv("MMS_LINEAR_GENERIC");
+    if (small) {
+        grid.y = (a.M + 63) / 64;
+        hipLaunchKernelGGL(linear_act_kernel<1>, grid, dim3(256), kLinearLds, s, a);
+    } else if (fast && a.K % kBK == 0) hipLaunchKernelGGL(linear_act_fast_kernel<false>, grid, dim3(256), kLinearLds, s, a);
     else if (fast) hipLaunchKernelGGL(linear_act_fast_kernel<true>, grid, dim3(256), kLinearLds, s, a);
-    else hipLaunchKernelGGL(linear_act_kernel, grid, dim3(256), kLinearLds, s, a);
+    else hipLaunchKernelGGL(linear_act_kernel<2>, grid, dim3(256), kLinearLds, s, a);
     return hipGetLastError();
 }
 

@@ -477,6 +477,72 @@ def main():
           obs=o, actions=a_act, log_prob=lp_act, value=v_act, mu=mu_act, sigma=sg_act, eval_log_prob=lp_ev, eval_entropy=ent_ev,
           eval_value=v_ev, inference=a_inf, **sd)
 
+    # ---------------- replay_buffer ----------------
+    # ReplayBuffer of DDPG / TD3 / SAC (algorithms/rl/{ddpg,td3,sac}/storage.py): the ring's wrap-around rule (:29-33: on the first
+    # overflow the cursor becomes (replay_size + 1) % replay_size = 1, slot 0 keeps its old transition and the cursor then
+    # runs on to replay_size again), get_statistics (:46-52) and the `random.sample` mini-batches (:54-70).
+    import random as _random
+    rb = {}
+    for algo in ("ddpg", "td3", "sac"):
+        mod = _load_by_path("ref_%s_storage" % algo, os.path.join(REF, "agents/algorithms/rl/%s/storage.py" % algo))
+        NE, R, OD, AD = 6, 5, 13, 4
+        buf = mod.ReplayBuffer(NE, R, 8, 2, (OD,), (0,), (AD,), "cpu", "sequential")
+        g = torch.Generator().manual_seed(31)
+        ins = dict(obs=[], act=[], rew=[], nobs=[], done=[])
+        cursor, full = [], []
+        for t in range(13):
+            o, a = torch.randn(NE, OD, generator=g), torch.randn(NE, AD, generator=g)
+            r, no = torch.randn(NE, generator=g), torch.randn(NE, OD, generator=g)
+            d = (torch.rand(NE, generator=g) < 0.3).long()
+            buf.add_transitions(o, torch.zeros(NE, 0), a, r, no, d)
+            for k, x in zip(ins, (o, a, r, no, d)):
+                ins[k].append(x)
+            cursor.append(buf.step); full.append(int(buf.fullfill))
+        import copy
+        stats_len, stats_rew = copy.deepcopy(buf).get_statistics()      # see ppo_gae above: .cpu() aliases a CPU storage
+        _random.seed(32)
+        batches = buf.mini_batch_generator(3)
+        part = copy.deepcopy(mod.ReplayBuffer(NE, R, 8, 2, (OD,), (0,), (AD,), "cpu", "sequential"))
+        for t in range(3):
+            part.add_transitions(ins["obs"][t], torch.zeros(NE, 0), ins["act"][t], ins["rew"][t], ins["nobs"][t], ins["done"][t])
+        p_len, p_rew = copy.deepcopy(part).get_statistics()
+        _random.seed(33)
+        p_batches = part.mini_batch_generator(4)
+        rb[algo] = dict(cursor=np.array(cursor), full=np.array(full), observations=buf.observations, next_observations=buf.next_observations,
+                        actions=buf.actions, rewards=buf.rewards, dones=buf.dones, mean_traj_len=stats_len, mean_reward=stats_rew,
+                        batches=np.array(batches), part_mean_traj_len=p_len, part_mean_reward=p_rew, part_batches=np.array(p_batches))
+        if algo == "ddpg":
+            rb["in"] = {k: torch.stack(v) for k, v in ins.items()}
+    flat = {"in_" + k: v for k, v in rb["in"].items()}
+    for algo in ("ddpg", "td3", "sac"):
+        flat.update({algo + "_" + k: v for k, v in rb[algo].items()})
+    _save("replay_buffer", meta_common + "; ReplayBuffer.add_transitions/get_statistics/mini_batch_generator "
+          "(algorithms/rl/{ddpg,td3,sac}/storage.py), 6 envs, replay_size 5, batch_size 8, 13 adds (random.seed(32) before the "
+          "3 mini-batches of the full buffer; a second buffer with 3 adds, random.seed(33), 4 mini-batches)", **flat)
+
+    # ---------------- offpolicy_act ----------------
+    # MLPActorCritic.act of DDPG and TD3 (algorithms/rl/{ddpg,td3}/module.py:35-61): deterministic and with exploration noise
+    # (torch.manual_seed(42) right before the noisy call; the noise is torch.randn(shape) of the CPU generator), and the Q values.
+    from gym import spaces as _spaces
+    flat = {}
+    for algo in ("ddpg", "td3"):
+        mod = _load_by_path("ref_%s_module" % algo, os.path.join(REF, "agents/algorithms/rl/%s/module.py" % algo))
+        torch.manual_seed(41)
+        ac = mod.MLPActorCritic(_spaces.Box(-np.inf * np.ones(52), np.inf * np.ones(52)), _spaces.Box(-np.ones(24), np.ones(24)), 0.1, "cpu",
+                                hidden_sizes=[32, 32, 32])
+        g = torch.Generator().manual_seed(43)
+        o = 2.0 * torch.randn(N, 52, generator=g)
+        det = ac.act(o)
+        torch.manual_seed(42)
+        noisy = ac.act(o, deterministic=False)
+        with torch.no_grad():
+            qs = [ac.q(o, det)] if algo == "ddpg" else [ac.q1(o, det), ac.q2(o, det)]
+        flat.update({algo + "_sd_" + k.replace(".", "_"): v for k, v in ac.state_dict().items()})
+        flat.update({algo + "_obs": o, algo + "_det": det, algo + "_noisy": noisy, algo + "_q": torch.stack(qs)})
+        flat[algo + "_keys"] = np.array(list(ac.state_dict().keys()))
+    _save("offpolicy_act", meta_common + "; MLPActorCritic.act / q (algorithms/rl/{ddpg,td3}/module.py), obs 52, actions 24, hidden "
+          "[32,32,32] ReLU, act_noise 0.1, act_limit 1", **flat)
+
     # ---------------- marl_gae ----------------
     sb = __import__("agents.algorithms.marl.utils.separated_buffer", fromlist=["x"])
     popart = _load_by_path("ref_popart", os.path.join(REF, "agents/algorithms/marl/utils/popart.py"))

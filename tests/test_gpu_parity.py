@@ -1025,6 +1025,87 @@ def test_fused_act_and_bound_rollout(torch_cuda):
     eng.close()
 
 
+def test_replay_buffer_bound_slots(torch_cuda):
+    """The DDPG / TD3 collection loop (ddpg.py:151-159) on MultiIngenuity (BASELINE configs[2]) and OneAnt, twice: through the
+    wrapper's return values + copies, and with the step kernel bound to the ring row `ReplayBuffer.slot()` names.  Same seed,
+    same actions -> identical rings, across the overflow that skips row 0."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.algorithms.rl.td3.storage import ReplayBuffer
+    from massive_marl_benchmark_amd.engine import Engine
+    for task in ("MultiIngenuity", "OneAnt"):
+        n, R, steps = 200, 5, 13
+        e1 = Engine(task, num_envs=n, device=0, seed=6)
+        e2 = Engine(task, num_envs=n, device=0, seed=6)
+        W, AD = e1.obs_dim, e1.num_actions
+        b1 = ReplayBuffer(n, R, 64, 8, (W,), (0,), (AD,), "cuda:0")
+        b2 = ReplayBuffer(n, R, 64, 8, (W,), (0,), (AD,), "cuda:0")
+        g = torch.Generator().manual_seed(9)
+        states = torch.zeros(n, 0, device="cuda")
+        for e in (e1, e2):
+            e.tensor("actions").zero_()
+            e.step()                                                   # first step = full reset
+        cur1, cur2 = e1.tensor("obs_clipped").clone(), e2.tensor("obs_clipped").clone()
+        for t in range(steps):
+            a = (torch.rand(n, AD, generator=g) * 2 - 1).cuda()
+            # copies
+            e1.tensor("actions").copy_(a)
+            e1.step()
+            b1.add_transitions(cur1, states, a, e1.tensor("rew"), e1.tensor("obs_clipped"), e1.tensor("reset"))
+            cur1.copy_(e1.tensor("obs_clipped"))
+            # in place
+            k = b2.slot()
+            e2.bind_obs_out(b2.next_observations[k])
+            e2.bind_rollout_out(b2.rewards[k].view(-1), b2.dones[k].view(-1))
+            e2.tensor("actions").copy_(a)
+            e2.step()
+            b2.add_transitions(cur2, states, a, b2.rewards[k], b2.next_observations[k], b2.dones[k])
+            cur2.copy_(b2.next_observations[k])
+            assert b1.step == b2.step and b1.fullfill == b2.fullfill
+        torch.cuda.synchronize()
+        for name in ("observations", "next_observations", "actions", "rewards", "dones"):
+            assert torch.equal(getattr(b1, name), getattr(b2, name)), (task, name)
+        assert b1.fullfill and torch.isfinite(b1.next_observations).all()
+        s1, s2 = b1.get_statistics(), b2.get_statistics()
+        assert float(s1[0]) == float(s2[0]) and float(s1[1]) == float(s2[1])
+        e2.bind_obs_out(None)
+        e2.bind_rollout_out(None, None)
+        e1.close(); e2.close()
+
+
+def test_offpolicy_actor_fused_layers(torch_cuda):
+    """The DDPG / TD3 actor through mms_linear2_act (ReLU hidden layers, tanh output; act codes 2 and 3 of the kernel) against the
+    same nn.Sequential run by the library, on the three kernel variants (K tail, K % 32 == 0, ragged N); then act() on the
+    device: deterministic = the library forward, noisy = within the limit and N(0, act_noise) around it."""
+    torch = torch_cuda
+    import torch.nn as nn
+    from massive_marl_benchmark_amd import spaces
+    from massive_marl_benchmark_amd.algorithms.rl.ddpg.module import fused_mlp_forward, mlp
+    from massive_marl_benchmark_amd.algorithms.rl.td3.module import MLPActorCritic
+    torch.manual_seed(3)
+    for (M, sizes, act) in ((8192, [52, 256, 256, 256, 24], nn.ReLU), (1000, [60, 128, 64, 8], nn.ELU), (384, [388, 256, 128, 80], nn.Tanh),
+                            (7, [4, 12, 3], nn.Identity)):
+        seq = mlp(sizes, act, nn.Tanh).cuda()
+        x = 2.0 * torch.randn(M, sizes[0], device="cuda")
+        with torch.no_grad():
+            y = fused_mlp_forward(seq, x)
+            ref = seq(x)
+        assert y is not None and y.shape == ref.shape
+        assert float((y - ref).abs().max()) < 2e-5, (M, sizes)
+        assert fused_mlp_forward(seq, x) is None                     # gradients wanted: the library path keeps the graph
+    ac = MLPActorCritic(spaces.Box(-np.inf * np.ones(52), np.inf * np.ones(52)), spaces.Box(-np.ones(24), np.ones(24)), 0.1, "cuda:0",
+                        hidden_sizes=[256, 256, 256]).cuda()
+    o = torch.randn(8192, 52, device="cuda")
+    det = ac.act(o)
+    with torch.no_grad():
+        assert float((det - ac.act_limit * ac.pi.pi(o)).abs().max()) < 2e-5
+    noisy = ac.act(o, deterministic=False)
+    assert float(noisy.abs().max()) <= 1.0
+    inner = det.abs() < 0.5                                           # away from the clip
+    z = ((noisy - det) / 0.1)[inner]
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+    assert ac.pi(o).requires_grad
+
+
 def test_optional_observation_rows(torch_cuda):
     """mms_set_obs_outputs: a switched-off engine row keeps its last contents, the bound slot and everything else still follow
     the state; switching back on resumes."""

@@ -131,6 +131,77 @@ def test_actor_critic_matches_reference_fixture():
         ac.act(obs, torch.zeros(obs.shape[0], 0))          # no CPU fallback for the sampling kernel
 
 
+@pytest.mark.parametrize("algo", ["ddpg", "td3", "sac"])
+def test_replay_buffer_matches_reference_fixture(algo):
+    """ReplayBuffer (algorithms/rl/{ddpg,td3,sac}/storage.py) against what the reference's own class produced for the same 13
+    adds into a 5-row ring: cursor / fullfill after every add (the overflow rule that skips row 0), the ring's contents,
+    get_statistics and the random.sample mini-batches under the same random.seed."""
+    import importlib
+    import random
+
+    import torch
+    from conftest import load_golden
+    g = load_golden("replay_buffer")
+    ReplayBuffer = importlib.import_module("massive_marl_benchmark_amd.algorithms.rl.%s.storage" % algo).ReplayBuffer
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    NE, R, OD, AD = 6, 5, 13, 4
+    buf = ReplayBuffer(NE, R, 8, 2, (OD,), (0,), (AD,), "cpu", "sequential")
+    part = ReplayBuffer(NE, R, 8, 2, (OD,), (0,), (AD,), "cpu", "sequential")
+    for k in range(13):
+        assert buf.slot() == (k if k < R else g[algo + "_cursor"][k] - 1)
+        args = (t(g["in_obs"][k]), torch.zeros(NE, 0), t(g["in_act"][k]), t(g["in_rew"][k]), t(g["in_nobs"][k]), t(g["in_done"][k]))
+        buf.add_transitions(*args)
+        if k < 3:
+            part.add_transitions(*args)
+        assert buf.step == g[algo + "_cursor"][k] and int(buf.fullfill) == g[algo + "_full"][k]
+    for name in ("observations", "next_observations", "actions", "rewards", "dones"):
+        assert np.array_equal(getattr(buf, name).numpy(), g[algo + "_" + name]), name
+    ln, rw = buf.get_statistics()
+    assert float(ln) == float(g[algo + "_mean_traj_len"]) and abs(float(rw) - float(g[algo + "_mean_reward"])) < 1e-6
+    random.seed(32)
+    assert np.array_equal(np.array(buf.mini_batch_generator(3)), g[algo + "_batches"])
+    ln, rw = part.get_statistics()
+    assert float(ln) == float(g[algo + "_part_mean_traj_len"]) and abs(float(rw) - float(g[algo + "_part_mean_reward"])) < 1e-6
+    random.seed(33)
+    assert np.array_equal(np.array(part.mini_batch_generator(4)), g[algo + "_part_batches"])
+    # a row that is already in place (written by the engine into the slot) is not copied: same result, and the ring row
+    # keeps its address
+    k = part.slot()
+    row = part.next_observations[k]
+    row.copy_(t(g["in_nobs"][3]))
+    part.add_transitions(t(g["in_obs"][3]), torch.zeros(NE, 0), t(g["in_act"][3]), t(g["in_rew"][3]), row, t(g["in_done"][3]))
+    assert np.array_equal(part.next_observations[3].numpy(), g["in_nobs"][3]) and part.step == 4
+
+
+@pytest.mark.parametrize("algo", ["ddpg", "td3"])
+def test_offpolicy_actor_critic_matches_reference_fixture(algo):
+    """MLPActorCritic (algorithms/rl/{ddpg,td3}/module.py): the reference's state_dict loads key for key, deterministic and noisy
+    actions (same CPU generator stream under torch.manual_seed) and the Q values match what the reference produced."""
+    import importlib
+
+    import torch
+    from conftest import load_golden
+    from massive_marl_benchmark_amd import spaces
+    g = load_golden("offpolicy_act")
+    mod = importlib.import_module("massive_marl_benchmark_amd.algorithms.rl.%s.module" % algo)
+    ac = mod.MLPActorCritic(spaces.Box(-np.inf * np.ones(52), np.inf * np.ones(52)), spaces.Box(-np.ones(24), np.ones(24)), 0.1, "cpu",
+                            hidden_sizes=[32, 32, 32])
+    keys = [str(k) for k in g[algo + "_keys"]]
+    assert list(ac.state_dict().keys()) == keys
+    ac.load_state_dict({k: torch.from_numpy(g[algo + "_sd_" + k.replace(".", "_")]) for k in keys})
+    o = torch.from_numpy(g[algo + "_obs"])
+    det = ac.act(o)
+    assert not det.requires_grad and np.allclose(det.numpy(), g[algo + "_det"], atol=1e-6)
+    torch.manual_seed(42)
+    noisy = ac.act(o, deterministic=False)
+    assert np.allclose(noisy.numpy(), g[algo + "_noisy"], atol=1e-6) and float(noisy.abs().max()) <= 1.0
+    with torch.no_grad():
+        qs = [ac.q(o, det)] if algo == "ddpg" else [ac.q1(o, det), ac.q2(o, det)]
+    assert np.allclose(torch.stack(qs).numpy(), g[algo + "_q"], atol=1e-5)
+    # the training path keeps its graph (ddpg.py: loss_pi = -q(o, pi(o)))
+    assert ac.pi(o).requires_grad
+
+
 def test_sharded_env_grid_matches_single():
     """Env sharding: rank r of R owns envs [r*N, (r+1)*N); its env origins and RNG keys are
     those of the corresponding envs of one big engine.  Checked on the oracle (same host code path as the product)."""
