@@ -21,7 +21,7 @@ constexpr int kTM = 128, kTN = 128;
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return (v > 0.f) ? v : (expf(v) - 1.f);
     if (act == 2) return fmaxf(v, 0.f);
-    if (act == 3) return tanhf(v);
+    if (act == 3) return 1.f - 2.f / (__expf(2.f * v) + 1.f);     // tanh, absolute error ~1e-7; a few instructions where it is inlined 64 times
     return v;
 }
 
@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
 
 // TAIL: K is any multiple of 4 (the 388-wide first layer): K is walked to the next multiple of 32, a float4 whose k lies beyond K
 // is read from the last valid float4 of its row instead and multiplied by zero (no branch in the pipeline).
-template <bool TAIL>
+// ELU_ONLY: the PPO policy's activation compiled in (one compare per output element instead of the run-time dispatch).
+template <bool TAIL, bool ELU_ONLY>
 __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = blockIdx.z;
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
         float* yp = Y + (size_t)(m0 + wr + 32 * (I) + 4 * lh) * N + col;                                     \
         _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                     \
             float v = ACC[r] + bias;                                                                         \
-            v = apply_act(v, a.act);                                             \
+            v = ELU_ONLY ? ((v > 0.f) ? v : (expf(v) - 1.f)) : apply_act(v, a.act);                          \
             yp[(size_t)((r & 3) + 8 * (r >> 2)) * N] = v;                                                    \
         }                                                                                                    \
     }
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_bf16_kernel(LinearBf16Args 
 
 // More than 64 KB of dynamic LDS needs an opt-in per kernel and per device; remembered so that it is asked for once.
 static hipError_t allow_large_lds(const void* kernel, int slot) {
-    static bool done[6][64] = {};
+    static bool done[8][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -441,8 +442,10 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
     dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, groups);
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel<2>), 2); e != hipSuccess) return e;
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<false>), 3); e != hipSuccess) return e;
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<true>), 4); e != hipSuccess) return e;
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<false, true>), 3); e != hipSuccess) return e;
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<true, true>), 4); e != hipSuccess) return e;
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<false, false>), 6); e != hipSuccess) return e;
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<true, false>), 7); e != hipSuccess) return e;
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel<1>), 5); e != hipSuccess) return e;
     // 128-row tiles that would not give every CU a block (the small layers of the off-policy actor): 64-row tiles, twice the blocks
     const bool small = (size_t)grid.x * grid.y * grid.z < 256 && a.M > 64 && !getenv("MMS_LINEAR_TALL_TILES");
@@ -450,8 +453,13 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     if (small) {
         grid.y = (a.M + 63) / 64;
         hipLaunchKernelGGL(linear_act_kernel<1>, grid, dim3(256), kLinearLds, s, a);
-    } else if (fast && a.K % kBK == 0) hipLaunchKernelGGL(linear_act_fast_kernel<false>, grid, dim3(256), kLinearLds, s, a);
-    else if (fast) hipLaunchKernelGGL(linear_act_fast_kernel<true>, grid, dim3(256), kLinearLds, s, a);
+    } else if (fast && a.act == 1) {
+        if (a.K % kBK == 0) hipLaunchKernelGGL((linear_act_fast_kernel<false, true>), grid, dim3(256), kLinearLds, s, a);
+        else hipLaunchKernelGGL((linear_act_fast_kernel<true, true>), grid, dim3(256), kLinearLds, s, a);
+    } else if (fast) {
+        if (a.K % kBK == 0) hipLaunchKernelGGL((linear_act_fast_kernel<false, false>), grid, dim3(256), kLinearLds, s, a);
+        else hipLaunchKernelGGL((linear_act_fast_kernel<true, false>), grid, dim3(256), kLinearLds, s, a);
+    }
     else hipLaunchKernelGGL(linear_act_kernel<2>, grid, dim3(256), kLinearLds, s, a);
     return hipGetLastError();
 }
