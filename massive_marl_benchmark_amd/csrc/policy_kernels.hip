@@ -448,7 +448,8 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<true, false>), 7); e != hipSuccess) return e;
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel<1>), 5); e != hipSuccess) return e;
     // 128-row tiles that would not give every CU a block (the small layers of the off-policy actor): 64-row tiles, twice the blocks
-    const bool small = (size_t)grid.x * grid.y * grid.z < 256 && a.M > 64 && !getenv("MMS_LINEAR_TALL_TILES");
+    static const int small_max = getenv("MMS_LINEAR_SMALL_MAX") ? atoi(getenv("MMS_LINEAR_SMALL_MAX")) : 255;
+    const bool small = (size_t)grid.x * grid.y * grid.z <= (size_t)small_max && a.M > 64 && !getenv("MMS_LINEAR_TALL_TILES");
     const bool fast = !small && a.M % kTM == 0 && a.N % kTN == 0 && a.K >= 8 && !getenv("MMS_LINEAR_GENERIC");
     if (small) {
         grid.y = (a.M + 63) / 64;
