@@ -169,12 +169,14 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
 #define MMS_MFMA4(S, e)                                                                                      \
     acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][0].e, fb[S][0].e, acc00, 0, 0, 0);                     \
     acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][0].e, fb[S][1].e, acc01, 0, 0, 0);                     \
-    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][1].e, fb[S][0].e, acc10, 0, 0, 0);                     \
-    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][1].e, fb[S][1].e, acc11, 0, 0, 0);                     \
+    if (MI == 2) {                                                                                           \
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][1].e, fb[S][0].e, acc10, 0, 0, 0);                 \
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][1].e, fb[S][1].e, acc11, 0, 0, 0);                 \
+    }                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);
 #define MMS_FRAGS(S, abase, bbase, ko)                                                                       \
     fa[S][0] = *reinterpret_cast<const float4*>((abase) + (ko));                                             \
-    fa[S][1] = *reinterpret_cast<const float4*>((abase) + 32 * kPitch + (ko));                               \
+    if (MI == 2) fa[S][1] = *reinterpret_cast<const float4*>((abase) + 32 * kPitch + (ko));                  \
     fb[S][0] = *reinterpret_cast<const float4*>((bbase) + (ko));                                             \
     fb[S][1] = *reinterpret_cast<const float4*>((bbase) + 32 * kPitch + (ko));                               \
     __builtin_amdgcn_sched_barrier(0);
@@ -182,7 +184,9 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
 // TAIL: K is any multiple of 4 (the 388-wide first layer): K is walked to the next multiple of 32, a float4 whose k lies beyond K
 // is read from the last valid float4 of its row instead and multiplied by zero (no branch in the pipeline).
 // ELU_ONLY: the PPO policy's activation compiled in (one compare per output element instead of the run-time dispatch).
-template <bool TAIL, bool ELU_ONLY>
+// MI = 2: 128 x 128 tile per block (64 x 64 per wave); MI = 1: 64 x 128 (32 x 64 per wave), for launches whose 128-row tiling
+// would put one block on a CU: two waves per SIMD are what keeps the matrix pipe fed across barriers and fragment reads.
+template <bool TAIL, bool ELU_ONLY, int MI>
 __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = blockIdx.z;
@@ -191,9 +195,9 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
     const float* __restrict__ Bv = a.b[g];
     float* __restrict__ Y = a.y[g];
     const int N = a.N, K = a.K;
-    const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
+    const int m0 = blockIdx.y * (64 * MI), n0 = blockIdx.x * kTN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int wr = (wave >> 1) * (32 * MI), wc = (wave & 1) * 64;
     const int li = lane & 31, lh = lane >> 5;
     float* As = smem;                                       // [2][128][kPitch]
     float* Bs = smem + 2 * 128 * kPitch;
@@ -210,8 +214,8 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
     f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
-    float4 ra0_0, ra0_1, ra0_2, ra0_3, rb0_0, rb0_1, rb0_2, rb0_3;   // staged slices: set 0 = even slices,
-    float4 ra1_0, ra1_1, ra1_2, ra1_3, rb1_0, rb1_1, rb1_2, rb1_3;   // set 1 = odd slices (named scalars: arrays of them land in scratch)
+    float4 ra0_0, ra0_1, ra0_2 = {}, ra0_3 = {}, rb0_0, rb0_1, rb0_2, rb0_3;   // staged slices: set 0 = even slices,
+    float4 ra1_0, ra1_1, ra1_2 = {}, ra1_3 = {}, rb1_0, rb1_1, rb1_2, rb1_3;   // set 1 = odd slices (named scalars: arrays of them land in scratch)
     float4 fa[2][2], fb[2][2];                              // fragment sets, alternating per group
 
     const int nkt = (K + kBK - 1) / kBK;
@@ -221,14 +225,14 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
         const bool ok = !TAIL || (KOFF) + sk < K;                                                                                \
         const int ko = ok ? (KOFF) : k_last;                                                                                     \
         const float m = ok ? 1.f : 0.f;                                                                                          \
-        ra##SET##_##J = *reinterpret_cast<const float4*>(xg + (J) * rs + ko);                                                    \
+        if ((J) < 2 * MI) ra##SET##_##J = *reinterpret_cast<const float4*>(xg + (J) * rs + ko);                                  \
         rb##SET##_##J = *reinterpret_cast<const float4*>(wg + (J) * rs + ko);                                                    \
         if (TAIL) {                                                                                                              \
-            ra##SET##_##J.x *= m; ra##SET##_##J.y *= m; ra##SET##_##J.z *= m; ra##SET##_##J.w *= m;                              \
+            if ((J) < 2 * MI) { ra##SET##_##J.x *= m; ra##SET##_##J.y *= m; ra##SET##_##J.z *= m; ra##SET##_##J.w *= m; }        \
             rb##SET##_##J.x *= m; rb##SET##_##J.y *= m; rb##SET##_##J.z *= m; rb##SET##_##J.w *= m;                              \
         }                                                                                                                        \
     }
-#define MMS_ST(SET, J, BOFF) *reinterpret_cast<float4*>(as_st + (BOFF) + (J) * 32 * kPitch) = ra##SET##_##J; *reinterpret_cast<float4*>(bs_st + (BOFF) + (J) * 32 * kPitch) = rb##SET##_##J;
+#define MMS_ST(SET, J, BOFF) if ((J) < 2 * MI) *reinterpret_cast<float4*>(as_st + (BOFF) + (J) * 32 * kPitch) = ra##SET##_##J; *reinterpret_cast<float4*>(bs_st + (BOFF) + (J) * 32 * kPitch) = rb##SET##_##J;
     MMS_LD(0, 0, 0) MMS_LD(0, 1, 0) MMS_LD(0, 2, 0) MMS_LD(0, 3, 0)
     { const int k1 = nkt > 1 ? kBK : 0; MMS_LD(1, 0, k1) MMS_LD(1, 1, k1) MMS_LD(1, 2, k1) MMS_LD(1, 3, k1) }
     MMS_ST(0, 0, 0) MMS_ST(0, 1, 0) MMS_ST(0, 2, 0) MMS_ST(0, 3, 0)
@@ -296,7 +300,8 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
             yp[(size_t)((r & 3) + 8 * (r >> 2)) * N] = v;                                                    \
         }                                                                                                    \
     }
-    MMS_EPI(acc00, 0, 0) MMS_EPI(acc01, 0, 1) MMS_EPI(acc10, 1, 0) MMS_EPI(acc11, 1, 1)
+    MMS_EPI(acc00, 0, 0) MMS_EPI(acc01, 0, 1)
+    if (MI == 2) { MMS_EPI(acc10, 1, 0) MMS_EPI(acc11, 1, 1) }
 #undef MMS_EPI
 }
 #undef MMS_MFMA4
@@ -416,7 +421,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_bf16_kernel(LinearBf16Args 
 
 // More than 64 KB of dynamic LDS needs an opt-in per kernel and per device; remembered so that it is asked for once.
 static hipError_t allow_large_lds(const void* kernel, int slot) {
-    static bool done[8][64] = {};
+    static bool done[12][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -442,26 +447,33 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     if (a.M == 0 || a.N == 0) return hipSuccess;
     dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, groups);
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel<2>), 2); e != hipSuccess) return e;
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<false, true>), 3); e != hipSuccess) return e;
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<true, true>), 4); e != hipSuccess) return e;
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<false, false>), 6); e != hipSuccess) return e;
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_fast_kernel<true, false>), 7); e != hipSuccess) return e;
     if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_kernel<1>), 5); e != hipSuccess) return e;
-    // 128-row tiles that would not give every CU a block (the small layers of the off-policy actor): 64-row tiles, twice the blocks
+    // 128-row tiles that would leave CUs without a block: 64-row tiles, twice the blocks.  (At exactly one block per CU -- the
+    // policy's 512-wide layer -- both tilings measure the same, 72-78 us: the fixed cost of a launch dominates, not the slice rate.)
     static const int small_max = getenv("MMS_LINEAR_SMALL_MAX") ? atoi(getenv("MMS_LINEAR_SMALL_MAX")) : 255;
     const bool small = (size_t)grid.x * grid.y * grid.z <= (size_t)small_max && a.M > 64 && !getenv("MMS_LINEAR_TALL_TILES");
-    const bool fast = !small && a.M % kTM == 0 && a.N % kTN == 0 && a.K >= 8 && !getenv("MMS_LINEAR_GENERIC");
-    if (small) {
-        grid.y = (a.M + 63) / 64;
-        hipLaunchKernelGGL(linear_act_kernel<1>, grid, dim3(256), kLinearLds, s, a);
-    } else if (fast && a.act == 1) {
-        if (a.K % kBK == 0) hipLaunchKernelGGL((linear_act_fast_kernel<false, true>), grid, dim3(256), kLinearLds, s, a);
-        else hipLaunchKernelGGL((linear_act_fast_kernel<true, true>), grid, dim3(256), kLinearLds, s, a);
-    } else if (fast) {
-        if (a.K % kBK == 0) hipLaunchKernelGGL((linear_act_fast_kernel<false, false>), grid, dim3(256), kLinearLds, s, a);
-        else hipLaunchKernelGGL((linear_act_fast_kernel<true, false>), grid, dim3(256), kLinearLds, s, a);
+    const bool fast = a.M % (small ? 64 : kTM) == 0 && a.N % kTN == 0 && a.K >= 8 && !getenv("MMS_LINEAR_GENERIC");
+    if (small) grid.y = (a.M + 63) / 64;
+#define MMS_LAUNCH_FAST(TAIL, ELU, MI, SLOT)                                                                                   \
+    {                                                                                                                          \
+        auto kern = linear_act_fast_kernel<TAIL, ELU, MI>;                                                                     \
+        if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(kern), SLOT); e != hipSuccess) return e;              \
+        hipLaunchKernelGGL(kern, grid, dim3(256), kLinearLds, s, a);                                                           \
     }
+    const bool tail = a.K % kBK != 0, elu = a.act == 1;
+    if (fast && !small) {
+        if (!tail && elu) MMS_LAUNCH_FAST(false, true, 2, 3)
+        else if (tail && elu) MMS_LAUNCH_FAST(true, true, 2, 4)
+        else if (!tail) MMS_LAUNCH_FAST(false, false, 2, 6)
+        else MMS_LAUNCH_FAST(true, false, 2, 7)
+    } else if (fast) {
+        if (!tail && elu) MMS_LAUNCH_FAST(false, true, 1, 8)
+        else if (tail && elu) MMS_LAUNCH_FAST(true, true, 1, 9)
+        else if (!tail) MMS_LAUNCH_FAST(false, false, 1, 10)
+        else MMS_LAUNCH_FAST(true, false, 1, 11)
+    } else if (small) hipLaunchKernelGGL(linear_act_kernel<1>, grid, dim3(256), kLinearLds, s, a);
     else hipLaunchKernelGGL(linear_act_kernel<2>, grid, dim3(256), kLinearLds, s, a);
+#undef MMS_LAUNCH_FAST
     return hipGetLastError();
 }
 
