@@ -140,7 +140,7 @@ def main():
     for i in range(64):                         # reset-all + settle
         sim_step(i)
     barrier()
-    sim_steps = max((args.steps // 16) * 16, 256)
+    sim_steps = max((args.steps // 64) * 64, 256)
     sim_graph = None
     if not args.no_graph:                       # 16 steps (one pass over the ring) per hipGraph replay
         side = torch.cuda.Stream(device)
@@ -151,18 +151,26 @@ def main():
                 for i in range(16):
                     sim_step(i)
         torch.cuda.current_stream(device).wait_stream(side)
-        sim_graph.replay()
+        for _ in range(8):                      # the first replays of a fresh graph can carry a one-off runtime stall (tens of ms)
+            sim_graph.replay()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    if sim_graph is None:
-        for i in range(sim_steps):
-            sim_step(i)
-    else:
-        for _ in range(sim_steps // 16):
-            sim_graph.replay()
-    torch.cuda.synchronize()
-    sim_wall = time.perf_counter() - t0
+    # timed in four equal batches; the series' figure is the MEDIAN batch: early in a process a replay occasionally carries a
+    # one-off runtime stall of tens of ms (seen with every kernel layout, tools/scratch/sim_graph_probe.py), which would otherwise
+    # decide this informational series.  All four batch times are reported.
+    sim_batches = []
+    per_batch = sim_steps // 4
+    for b in range(4):
+        t0 = time.perf_counter()
+        if sim_graph is None:
+            for i in range(per_batch):
+                sim_step(b * per_batch + i)
+        else:
+            for _ in range(per_batch // 16):
+                sim_graph.replay()
+        torch.cuda.synchronize()
+        sim_batches.append(time.perf_counter() - t0)
+    sim_wall = 4.0 * sorted(sim_batches)[1]
     # step-kernel launch duration: back-to-back launches with nothing else on the stream, HIP events around them.
     # Measured twice -- here, after the sim-only series, and again right after the GEMM-heavy rollout series -- because the
     # kernel is VALU-issue bound and so follows the core clock, which the rollout's matrix-core bursts pull down.
@@ -310,7 +318,7 @@ def main():
     kernel_ms_roll = in_rollout_ms[-1]
     # average over the step-kernel launches of this run (what a kernel trace of the same command averages): back-to-back
     # launches (sim-only series, its warm-up, the timing loops) and launches inside rollout steps (all series)
-    n_b2b = 64 + 16 + sim_steps + 2 * 256
+    n_b2b = 64 + 8 * 16 + sim_steps + 2 * 256
     n_roll = sum(NSTEPS + w + k + 4 * NSTEPS for (w, k) in rollout_counts)
     kernel_ms = (n_b2b * kernel_ms_b2b + n_roll * kernel_ms_roll) / (n_b2b + n_roll)
     tmax = torch.tensor([elapsed, sim_wall, kernel_ms, bf_elapsed, kernel_ms_b2b, kernel_ms_roll], dtype=torch.float64, device=device)
@@ -326,6 +334,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(N, args.cpu_steps)
 
+    # which packed layout mms_step launches (csrc/step_kernels.hip: launch_step): 16 envs per 768-thread block once every CU gets one
+    force16 = os.environ.get("MMS_STEP_BLOCK16")
+    block16 = (force16[0] != "0") if force16 else N >= 16 * torch.cuda.get_device_properties(device).multi_processor_count
+    step_kernel_name = "mms::ant_step_kernel<TEN_ANT, 768, 16, 10>" if block16 else "mms::ant_step_kernel<TEN_ANT, 192, 4, 10>"
     if rank == 0:
         value = world * N * K / elapsed
         sim_value = world * N * sim_steps / sim_wall
@@ -343,8 +355,9 @@ def main():
                        "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else "mms_linear2_act + mms_ppo_heads_act",
                        "critic_deferred": bool(args.defer_critic), "finite": finite, "resets_total": resets_seen},
             "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
-                         "note": "engine step with pre-drawn actions (ring of 16)", "hipgraph": sim_graph is not None},
-            "roofline": {"bound": "hbm", "kernel": "mms::ant_step_kernel<TEN_ANT, 192, 4, 10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "note": "engine step with pre-drawn actions (ring of 16); four batches, median batch x 4",
+                         "batch_ms": [1e3 * b for b in sim_batches], "hipgraph": sim_graph is not None},
+            "roofline": {"bound": "hbm", "kernel": step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (tr or {}).get("source"),
                          "traffic_note": "launches of the rollout step (one observation row per env-step); the stand-alone engine "

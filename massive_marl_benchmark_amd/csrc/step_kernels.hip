@@ -109,7 +109,7 @@ template <int TASK, int BLOCK, int EPB, int AT, bool DR>
 #ifndef MMS_WAVES_PER_EU_WIDE
 #define MMS_WAVES_PER_EU_WIDE 1
 #endif
-__global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK == 192 ? MMS_WAVES_PER_EU_PACKED : MMS_WAVES_PER_EU_WIDE)) ant_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOCK == 192 || BLOCK == 768) ? MMS_WAVES_PER_EU_PACKED : MMS_WAVES_PER_EU_WIDE)) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const mms_config* __restrict__ C = a.cfg;
     const mms_model* __restrict__ M = &C->model;
@@ -266,8 +266,17 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             s_bp->pos = B.pos; s_bp->R = quat_to_mat(B.qx, B.qy, B.qz, B.qw); s_bp->v = B.vel; s_bp->w = B.ang;
         };
         // (the loop itself is block-uniform so that every lane reaches every barrier)
+        const bool box_friction = M->boxgnd_mu > 0.f;                // uniform: box-ground friction couples all six accelerations
         for (int s = 0; s < C->substeps; s++) {
             S6 wr = ant_phase();
+            // The box's own ground contacts do not depend on this substep's ant reactions: the corner lanes evaluate and reduce them
+            // BEFORE the barrier -- in the layouts whose box lanes fill waves of their own that is time in which those waves would
+            // only wait for the ant lanes; after the barrier the box needs the wrench, one small solve and the integration.
+            BoxCorner bc = {};
+            if (is_box && !box_friction) {
+                bc = box_corner(M, h, load_rigid(s_box), s_bp->R, corner);
+                oct_sum(bc);
+            }
             S6 w = S6{V3{0, 0, 0}, V3{0, 0, 0}};
             if (kOneWave) {                                          // one wave per env: the reaction wrench by DPP / permute
                 w = S6{V3{wave_sum(wr.a.x), wave_sum(wr.a.y), wave_sum(wr.a.z)}, V3{wave_sum(wr.l.x), wave_sum(wr.l.y), wave_sum(wr.l.z)}};
@@ -277,20 +286,16 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : (BLOCK
             }
             if (is_box) {                                            // waves without box lanes skip the whole box phase
                 if (!kOneWave) w = gather_wrench();
-                RigidState B = load_rigid(s_box);
+                RigidState B = load_rigid(s_box);                    // (again: cheaper than carrying 22 values across the barrier)
                 M3 R = s_bp->R;
-                if (M->boxgnd_mu > 0.f) {                            // uniform: box-ground friction couples all six accelerations
+                if (box_friction) {
                     BoxCornerF bf = box_corner_friction(M, h, B, R, corner);
 #pragma unroll
                     for (int k = 0; k < 21; k++) bf.IA.m[k] = oct_sum(bf.IA.m[k]);
                     bf.pA.a.x = oct_sum(bf.pA.a.x); bf.pA.a.y = oct_sum(bf.pA.a.y); bf.pA.a.z = oct_sum(bf.pA.a.z);
                     bf.pA.l.x = oct_sum(bf.pA.l.x); bf.pA.l.y = oct_sum(bf.pA.l.y); bf.pA.l.z = oct_sum(bf.pA.l.z);
                     if (simulate) box_finish_friction(M, h, B, R, bf, w);
-                } else {
-                    BoxCorner bc = box_corner(M, h, B, R, corner);
-                    oct_sum(bc);
-                    if (simulate) box_finish(M, h, B, R, bc, w);
-                }
+                } else if (simulate) box_finish(M, h, B, R, bc, w);
                 if (corner == 0) box_store(B);
             }
             __syncthreads();
@@ -543,12 +548,20 @@ static hipError_t launch_ant(const StepArgs& a, hipStream_t stream) {
     size_t lds = (4 * sizeof(LegConst) + 15) / 16 * 16 + (size_t)EPB * ((ant_env_lds_floats(a.obs_dim, a.num_agents) + 3) & ~(size_t)3) * sizeof(float) +
                  (size_t)6 * 4 * BLOCK * sizeof(float);          // + the kinematics parking space
     int grid = (a.num_envs + EPB - 1) / EPB;
-    if (a.dr) {
-        lds += (size_t)BLOCK * sizeof(LegDR);
-        hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, true>), dim3(grid), dim3(BLOCK), lds, stream, a);
-    } else {
-        hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, false>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    if (a.dr) lds += (size_t)BLOCK * sizeof(LegDR);
+    if (lds > 64 * 1024) {                                       // dynamic LDS beyond 64 KB has to be allowed per kernel and device
+        static bool allowed[2][64] = {};
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && !allowed[a.dr ? 1 : 0][dev]) {
+            const void* k = a.dr ? reinterpret_cast<const void*>(ant_step_kernel<TASK, BLOCK, EPB, AT, true>)
+                                 : reinterpret_cast<const void*>(ant_step_kernel<TASK, BLOCK, EPB, AT, false>);
+            if (hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
+            allowed[a.dr ? 1 : 0][dev] = true;
+        }
     }
+    if (a.dr) hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, true>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    else hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, false>), dim3(grid), dim3(BLOCK), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -562,6 +575,22 @@ hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {
     const int lpe = ((4 * a.num_agents + 7) & ~7) + 8;        // lanes one env needs
     if (task == MMS_TASK_ONE_ANT) return (a.packing != 0) ? launch_ant<MMS_TASK_ONE_ANT, 64, 4, 1>(a, stream) : launch_ant<MMS_TASK_ONE_ANT, 64, 1, 1>(a, stream);
     if (task != MMS_TASK_TEN_ANT) return hipErrorInvalidValue;
+    // TenAnt, two packed layouts.  <192,4>: 4 envs per block, the third wave half ant lanes / half box lanes -- many small blocks,
+    // best while there are fewer than 16 envs per CU.  <768,16>: 16 envs per block = ten pure ant waves + two pure box waves, one
+    // block per CU and exactly 3 waves per SIMD: no wave issues the ant phase for 32 idle lanes (26.3 against 28.0 us at 4096
+    // envs, and 31 against 38 us right after the policy GEMMs).  MMS_STEP_BLOCK16=0 / 1 forces one of them (A/B).
+    const char* force16 = getenv("MMS_STEP_BLOCK16");                 // read per launch: the tests switch it
+    bool block16;
+    if (force16) block16 = force16[0] != '0';
+    else {
+        static int cus[64] = {};
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidDevice;
+        block16 = a.num_envs >= 16 * cus[dev];
+    }
+    if (a.num_agents == 10 && a.packing != 0 && block16) return launch_ant<MMS_TASK_TEN_ANT, 768, 16, 10>(a, stream);
     if (a.num_agents == 10 && a.packing != 0) return launch_ant<MMS_TASK_TEN_ANT, 192, 4, 10>(a, stream);
     if (lpe <= 64) return launch_ant<MMS_TASK_TEN_ANT, 64, 1, 0>(a, stream);
     if (lpe <= 512) return launch_ant<MMS_TASK_TEN_ANT, 512, 1, 0>(a, stream);

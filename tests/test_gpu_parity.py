@@ -245,6 +245,53 @@ def test_unpacked_launch_shapes(torch_cuda, task, n, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("n,dr", [(70, False), (16, False), (37, True)])
+def test_sixteen_env_block_layout(torch_cuda, n, dr, monkeypatch):
+    """MMS_STEP_BLOCK16=1: the <768,16> layout of the TenAnt step (16 envs per block, ten pure ant waves + two pure box waves; the
+    default from 16 envs per CU up, i.e. at BASELINE's 4096 envs) on small grids with a partial last block: teacher-forced
+    parity with the oracle, ants shoved against the box half way, resets included; once with physical randomisation on."""
+    torch = torch_cuda
+    monkeypatch.setenv("MMS_STEP_BLOCK16", "1")
+    kw = dict(num_envs=n, seed=13, total_envs=4096, env_offset=500)
+    eng, ora = make_pair("TenAnt", **kw)
+    rng = np.random.default_rng(4)
+    if dr:
+        params = random_dr_params(rng, n * ora.num_agents)
+        ora.tensor("dr_params")[:] = params
+        eng.tensor("dr_params").copy_(torch.from_numpy(params).to(eng.device))
+        ora.set_dr(True)
+        eng.set_dr(True)
+    verr, perr, flips = [], [], []
+    for t in range(70):
+        if t == 25:
+            shove_ants_into_box(ora, rng)
+        push_state(torch, eng, ora)
+        act = rng.uniform(-1.2, 1.2, (n, ora.num_actions)).astype(np.float32)
+        eng.tensor("actions").copy_(torch.from_numpy(act).to(eng.device))
+        eng.step()
+        ora.step(act)
+        torch.cuda.synchronize()
+        compare_step("TenAnt", eng, ora, "TenAnt <768,16> step %d" % t, verr, perr, flips)
+    check_distribution(verr, perr)
+    eng.close()
+    # and the two layouts against each other, free running from the same seed: bit-identical trajectories (same lane code,
+    # same reduction orders)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MMS_STEP_BLOCK16", flag)
+        from massive_marl_benchmark_amd.engine import Engine
+        e = Engine("TenAnt", num_envs=n, device=0, seed=2)
+        g = torch.Generator().manual_seed(3)
+        for t in range(40):
+            e.tensor("actions").copy_((torch.rand(n, 80, generator=g) * 2 - 1).cuda())
+            e.step()
+        torch.cuda.synchronize()
+        outs.append((e.tensor("root_states").clone(), e.tensor("obs").clone(), e.tensor("rew").clone(), e.tensor("reset").clone()))
+        e.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("task,n,agents", [("TenAnt", 1, 10), ("OneAnt", 1, 1), ("MultiIngenuity", 1, 4), ("TenAnt", 9, 2),
                                             ("TenAnt", 5, 14), ("TenAnt", 3, 15), ("TenAnt", 2, 33)])
 def test_edge_shapes_and_timeouts(torch_cuda, task, n, agents):
