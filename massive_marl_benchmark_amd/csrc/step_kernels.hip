@@ -111,8 +111,14 @@ template <int TASK, int BLOCK, int EPB, int AT, bool DR>
 #endif
 __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOCK == 192 || BLOCK == 768) ? MMS_WAVES_PER_EU_PACKED : MMS_WAVES_PER_EU_WIDE)) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const mms_config* __restrict__ C = a.cfg;
-    const mms_model* __restrict__ M = &C->model;
+    // The config block (~0.6 KB, read all over the kernel) is copied into LDS by the prologue and read from there: the kernel
+    // writes global memory, so the compiler may not use scalar loads for it, and a uniform VECTOR load costs an L2 round trip at
+    // every point of use (53 of them per substep) where an LDS broadcast read costs tens of cycles.  Cg: the prologue's view.
+    const mms_config* __restrict__ Cg = a.cfg;
+    constexpr int kCfgFloats = (int)((sizeof(mms_config) + 15) / 16 * 4);
+    static_assert(sizeof(mms_config) % 4 == 0, "copied word by word");
+    const mms_config* C = reinterpret_cast<const mms_config*>(lds);
+    const mms_model* M = &C->model;
     const int A = AT > 0 ? AT : a.num_agents;
     const int LA = 4 * A;                                     // ant lanes per env
     const int ant_region = EPB * LA;
@@ -134,11 +140,11 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
 
     // per-leg constants and the box pose live in LDS and are read at the point of use: keeping them in registers
     // costs ~55 VGPRs per lane for values that are wave-uniform or 4-periodic
-    LegConst* s_leg = reinterpret_cast<LegConst*>(lds);                            // [4], shared by the block
+    LegConst* s_leg = reinterpret_cast<LegConst*>(lds + kCfgFloats);               // [4], shared by the block
     // per-env LDS block: the fixed-size parts first, at compile-time offsets from one lane-varying base
     constexpr int kBoxOff = 0, kBpOff = 16, kWtotOff = kBpOff + (int)((sizeof(BoxPose) + 15) / 16 * 4), kEpiOff = kWtotOff + 8, kRedOff = kEpiOff + 8;
     const size_t env_stride = (ant_env_lds_floats(obs_dim, A) + 3) & ~(size_t)3;
-    float* lds_envs = lds + (4 * sizeof(LegConst) + 15) / 16 * 4;
+    float* lds_envs = lds + kCfgFloats + (4 * sizeof(LegConst) + 15) / 16 * 4;
     // behind the env blocks: six 16-B words per lane where a leg lane parks its joint axes between the two passes of a substep
     float* lds_lanes = lds_envs + (size_t)EPB * ((ant_env_lds_floats(AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim, A) + 3) & ~(size_t)3);
     const KinPark park{lds_lanes + 4 * threadIdx.x, 4 * BLOCK};
@@ -178,18 +184,13 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
         ac = reinterpret_cast<const float2*>(a.actions + (size_t)env * A * 8)[tid];             // this lane's two actions
         if (DR) *s_dr = load_leg_dr(a.dr + ((size_t)env * A + ant) * MMS_DR_FLOATS, leg);       // read back by this lane only
     }
-    // the config block (~0.5 KB, read through the scalar cache all over the kernel): one lane per 64-B line touches it now, so
-    // that the later scalar loads find it in L2
-    if (threadIdx.x < (sizeof(mms_config) + 63) / 64) {
-        const int line = reinterpret_cast<const int*>(C)[threadIdx.x * 16];
-        asm volatile("" :: "v"(line));
-    }
-    if (threadIdx.x < 4) s_leg[threadIdx.x] = load_leg_const(M, threadIdx.x);
+    for (int i = threadIdx.x; i < (int)(sizeof(mms_config) / 4); i += BLOCK) lds[i] = reinterpret_cast<const float*>(Cg)[i];
+    if (threadIdx.x < 4) s_leg[threadIdx.x] = load_leg_const(&Cg->model, threadIdx.x);
     if (box_lead) {
         RigidState B0 = load_rigid(a.root_states + ((size_t)env * actors + A) * 13);
         store_rigid(s_box, B0);
         s_bp->pos = B0.pos; s_bp->R = quat_to_mat(B0.qx, B0.qy, B0.qz, B0.qw); s_bp->v = B0.vel; s_bp->w = B0.ang;
-        s_bp->half = V3{M->box_half[0], M->box_half[1], M->box_half[2]};
+        s_bp->half = V3{Cg->model.box_half[0], Cg->model.box_half[1], Cg->model.box_half[2]};
     }
     for (int i = threadIdx.x; i < EPB * prev_dim; i += BLOCK) {       // the caches of the block's envs are contiguous in HBM
         const int e = i / prev_dim, k = i - e * prev_dim;
@@ -204,8 +205,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
         si[0] = (int)(pr & 0xffffffff); si[1] = (int)(pr >> 32); si[2] = (int)(rc & 0xffffffff); si[3] = (int)(rc >> 32);
     }
     if (is_ant) {
-        s_act[0] = clampf(ac.x, -C->clip_actions, C->clip_actions);     // vec_task.py:127
-        s_act[1] = clampf(ac.y, -C->clip_actions, C->clip_actions);
+        s_act[0] = clampf(ac.x, -Cg->clip_actions, Cg->clip_actions);     // vec_task.py:127
+        s_act[1] = clampf(ac.y, -Cg->clip_actions, Cg->clip_actions);
     }
     __syncthreads();
     const LegConst& L = s_leg[leg];
@@ -545,7 +546,7 @@ __global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
 // ---- launchers ---------------------------------------------------------------------------------
 template <int TASK, int BLOCK, int EPB, int AT>
 static hipError_t launch_ant(const StepArgs& a, hipStream_t stream) {
-    size_t lds = (4 * sizeof(LegConst) + 15) / 16 * 16 + (size_t)EPB * ((ant_env_lds_floats(a.obs_dim, a.num_agents) + 3) & ~(size_t)3) * sizeof(float) +
+    size_t lds = (sizeof(mms_config) + 15) / 16 * 16 + (4 * sizeof(LegConst) + 15) / 16 * 16 + (size_t)EPB * ((ant_env_lds_floats(a.obs_dim, a.num_agents) + 3) & ~(size_t)3) * sizeof(float) +
                  (size_t)6 * 4 * BLOCK * sizeof(float);          // + the kinematics parking space
     int grid = (a.num_envs + EPB - 1) / EPB;
     if (a.dr) lds += (size_t)BLOCK * sizeof(LegDR);
