@@ -404,8 +404,21 @@ def cpu_baseline(n_envs, steps):
     for i in range(steps):
         ora.step(ring[i % 16])
     dt = time.perf_counter() - t0
-    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "oracle engine (C, OpenMP over envs), TenAnt %d envs x %d sim steps, %.1f s" % (n_envs, steps, dt)}
+    out = {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": "oracle engine (C, OpenMP over envs), TenAnt %d envs x %d sim steps, %.1f s" % (n_envs, steps, dt)}
+    # BASELINE configs[0]'s shape beside it ("TenAnt N=4096 and OneAnt N=64"): ~1 s of the same oracle
+    one_ant = OracleEngine("OneAnt", num_envs=64, seed=0)
+    acts = [rng.uniform(-1, 1, (64, 8)).astype(np.float32) for _ in range(16)]
+    for i in range(16):
+        one_ant.step(acts[i])
+    t0 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t0 < 1.0:
+        for i in range(16):
+            one_ant.step(acts[i])
+        n1 += 16
+    out["one_ant_64_envs"] = {"value": 64 * n1 / (time.perf_counter() - t0), "unit": "env-steps/s", "steps": n1}
+    return out
 
 
 if __name__ == "__main__":
