@@ -4,6 +4,7 @@ vectors produced from the reference's own functions.  Nothing here reads /root/r
 
 Tolerances: see the block below (same as tests/test_lane_emulation.py); integer outputs are bit-exact."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -1244,6 +1245,38 @@ def test_rollout_kernels_random_shapes(torch_cuda):
     _lib.check(L.mms_marl_views(0, p(z), p(z), 0, 2, 1, 0, stream), None, "empty views")
     torch.cuda.synchronize()
     assert int(zc.sum()) == 0
+
+
+def test_rccl_backend_world_size_one(torch_cuda):
+    """The collectives of the multi-GPU paths on the RCCL backend itself (the 2-rank tests run on gloo, CPU): a one-rank "nccl"
+    group on this GPU -- RolloutStorage's global advantage statistics (all_reduce of the float64 triple between the two
+    kernels) and all_gather_envs give what the group-less calls give."""
+    torch = torch_cuda
+    import torch.distributed as dist
+    from massive_marl_benchmark_amd.algorithms.marl.utils.shared_buffer import all_gather_envs
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.storage import RolloutStorage
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        T, N = 8, 1000
+        g = torch.Generator(device="cuda").manual_seed(5)
+        outs = []
+        for pg in (None, dist.group.WORLD):
+            st = RolloutStorage(N, T, (4,), (0,), (2,), device="cuda:0", process_group=pg)
+            g.manual_seed(5)
+            st.rewards.copy_(torch.randn(T, N, 1, generator=g, device="cuda"))
+            st.values.copy_(torch.randn(T, N, 1, generator=g, device="cuda"))
+            st.dones.copy_((torch.rand(T, N, 1, generator=g, device="cuda") < 0.1).byte())
+            st.compute_returns(torch.randn(N, 1, generator=g, device="cuda"), 0.96, 0.95)
+            torch.cuda.synchronize()
+            outs.append((st.returns.clone(), st.advantages.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        x = {"obs": torch.randn(T + 1, N, 46, device="cuda"), "rewards": torch.randn(T, N, 1, device="cuda")}
+        y = all_gather_envs(x, dist.group.WORLD)
+        assert all(torch.equal(x[k], y[k]) for k in x)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_long_soak_stays_bounded(torch_cuda):
