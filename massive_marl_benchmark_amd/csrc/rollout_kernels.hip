@@ -210,6 +210,26 @@ __global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* _
     f32x4 acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The critic's last layer (module.py:49: nn.Linear(hidden, 1)) for the rows this wave samples below: one dot product per row,
+    // evaluated here so that its loads travel with the actor head's operands instead of costing a round trip after the barriers.
+    constexpr int RPW = 16 / WAVES;                                          // rows sampled per wave (WAVES in 1, 2, 4, 8)
+    float v_rows[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; q++) {
+        v_rows[q] = 0.f;
+        const int64_t row = r0 + wave * RPW + q;
+        if (vhidden && row < N) {
+            const float* hv = vhidden + row * (int64_t)VH;
+            float part = 0.f;
+            for (int k = lane * 4; k < VH; k += 256) {
+                const float4 h4 = *reinterpret_cast<const float4*>(hv + k), w4 = *reinterpret_cast<const float4*>(vweight + k);
+                part += h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+            v_rows[q] = part + vbias[0];
+        }
+    }
     const int kq = H / WAVES;
     const int kbeg = wave * kq;
     // 64 k per trip (the launcher picks WAVES so that H / WAVES is a multiple of 64): the 4 x (1 + NCT) float4 loads of a
@@ -251,22 +271,12 @@ __global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* _
         s_mean[e] = sum + bias[j < A ? j : 0];
     }
     __syncthreads();
-    constexpr int RPW = 16 / WAVES;                                          // rows sampled per wave (WAVES in 1, 2, 4, 8)
-    for (int r = wave * RPW; r < wave * RPW + RPW; r++) {
+#pragma unroll
+    for (int q = 0; q < RPW; q++) {
+        const int r = wave * RPW + q;
         const int64_t row = r0 + r;
         if (row >= N) continue;
-        float v_row = 0.f;
-        if (vhidden) {                           // the critic's last layer (module.py:49: nn.Linear(hidden, 1)): one dot product per row
-            const float* hv = vhidden + row * (int64_t)VH;
-            for (int k = lane * 4; k < VH; k += 256) {
-                const float4 h4 = *reinterpret_cast<const float4*>(hv + k), w4 = *reinterpret_cast<const float4*>(vweight + k);
-                v_row += h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) v_row += __shfl_xor(v_row, m, 64);
-            v_row += vbias[0];
-        }
-        ppo_sample_row(s_mean + r * AP, value, log_std, seed, counters, row_offset, ref_scale, o, row, A, lane, vhidden != nullptr, v_row);
+        ppo_sample_row(s_mean + r * AP, value, log_std, seed, counters, row_offset, ref_scale, o, row, A, lane, vhidden != nullptr, v_rows[q]);
     }
 }
 
