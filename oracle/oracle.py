@@ -6,7 +6,7 @@ import subprocess
 
 import numpy as np
 
-from massive_marl_benchmark_amd.model import MmsConfig, MmsModel, make_config, task_dims  # struct layout = include/mms.h
+from massive_marl_benchmark_amd.model import MmsConfig, MmsModel, make_config  # struct layout = include/mms.h
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libmms_oracle.so")

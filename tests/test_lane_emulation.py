@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import random_dr_params, shove_ants_into_box
-from massive_marl_benchmark_amd.model import MmsConfig, make_config, task_dims
+from massive_marl_benchmark_amd.model import MmsConfig
 from oracle.oracle import F, I64, OracleEngine, f32, fp, ip
 
 HERE = os.path.dirname(os.path.abspath(__file__))

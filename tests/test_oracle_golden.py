@@ -2,10 +2,9 @@
 (tests/golden/make_fixtures.py).  Tolerance: 1e-4 abs fp32 (SURVEY.md section 8c), angles modulo 2*pi;
 integer outputs (reset flags) bit-exact."""
 import numpy as np
-import pytest
 
 from conftest import angle_close, load_golden
-from oracle.oracle import F, I64, U8, OracleEngine, f32, fp, i64, ip
+from oracle.oracle import U8, OracleEngine, f32, fp, i64, ip
 
 TOL = 1e-4
 REW_TOL = 5e-4

@@ -5,7 +5,6 @@ contact, friction, action-reaction with the box."""
 import ctypes
 
 import numpy as np
-import pytest
 
 from massive_marl_benchmark_amd.model import make_config
 from oracle.oracle import OracleEngine, f32, fp, lib
