@@ -63,7 +63,7 @@ class MLPActor(nn.Module):
         out = fused_mlp_forward(self.pi, obs)
         if out is None:
             out = self.pi(obs)
-        return self.act_limit * out
+        return out if self.act_limit == 1.0 else self.act_limit * out       # x 1.0 is exact: one launch less for the ant / helicopter tasks
 
 
 class MLPQFunction(nn.Module):
@@ -92,5 +92,8 @@ class MLPActorCritic(nn.Module):
         with torch.no_grad():
             a = self.pi(obs)
             if not deterministic:
-                a = torch.clamp(a + self.act_noise * torch.randn_like(a), -self.act_limit, self.act_limit)
+                if a.is_cuda:      # mean + std * N(0, 1) in one launch, clamp in place (the collection loop is launch bound)
+                    a = torch.normal(a, float(self.act_noise)).clamp_(-self.act_limit, self.act_limit)
+                else:
+                    a = torch.clamp(a + self.act_noise * torch.randn_like(a), -self.act_limit, self.act_limit)
         return a
