@@ -55,5 +55,21 @@ int main() {
                    flops / (best * 1e-3) / 1e12, mfmas_per_simd * 64.0 / (best * 1e-3) / 1e9);
         }
     }
+    // the same short launch (2 waves per SIMD, 128 iterations) 40 times back to back on one stream: does every launch start its
+    // clock ramp again, or only the first one after idle?
+    {
+        const int iters = 128, grid = 512, n = 40;
+        hipLaunchKernelGGL(mfma_kernel, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 0.5f);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < n; i++) hipLaunchKernelGGL(mfma_kernel, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 0.5f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flops = (double)n * grid * 4 * iters * 16 * 4096.0;
+        printf("%d launches of 128 iters back to back: %.1f us each, %.1f TFLOP/s, implied clock %.2f GHz\n", n, ms * 1e3 / n,
+               flops / (ms * 1e-3) / 1e12, (double)iters * 16 * 2 * 64.0 / (ms * 1e-3 / n) / 1e9);
+    }
     return 0;
 }
