@@ -261,21 +261,25 @@ def main():
             torch.cuda.synchronize()
 
         def run_steps(k):
-            if graph is None:
-                for _ in range(k):
-                    rollout_step()
-            else:
+            # whole rollouts (8 steps + GAE) as graph replays, the remaining k mod 8 steps of a last, unfinished rollout eagerly
+            # (after a replay the engine's clamped observation row is current, which is what the eager step 0 starts from)
+            if graph is not None:
                 for _ in range(k // NSTEPS):
                     graph.replay()
+                k = k % NSTEPS
+            for _ in range(k):
+                rollout_step()
 
-        K = K_req if graph is None else max(NSTEPS, (K_req // NSTEPS) * NSTEPS)
-        W = W_req if graph is None else max(NSTEPS, ((W_req + NSTEPS - 1) // NSTEPS) * NSTEPS)
+        K = max(1, K_req)                                   # timed: exactly K steps
+        W = W_req if graph is None else ((W_req + NSTEPS - 1) // NSTEPS) * NSTEPS    # warm-up: whole rollouts, at least W steps
+        storage.clear()
         run_steps(W)
         barrier()
         t0 = time.perf_counter()
         run_steps(K)
         barrier()
         elapsed_ = time.perf_counter() - t0
+        storage.clear()
         # the step kernel inside the rollout (right after the policy GEMMs the core clock is lowered for ~100 us and the VALU-bound
         # kernel follows it): HIP events around each of 4 x NSTEPS eager rollout steps, outside the timed region
         pairs = []
