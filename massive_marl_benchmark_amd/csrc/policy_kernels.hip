@@ -193,13 +193,26 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
 template <bool TAIL, bool ELU_ONLY, int MI>
 __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int g = blockIdx.z;
+    const int N = a.N, K = a.K;
+    // 1-D grid, XCD-aware: workgroups go to the 8 XCDs round robin by their linear id, so id % 8 names the L2 a block sits behind.
+    // Each XCD gets a contiguous eighth of the row panels and walks all column tiles of it: per network it reads its own 1/8 of x and
+    // all of w (12 MB at K = 1024) instead of one column tile of w and ALL of x (33 MB) as the (n, m, network) grid order would have it.
+    const int tiles_n = N / kTN, tiles_m = a.M / (64 * MI), per_net = tiles_n * tiles_m;
+    const int g = blockIdx.x / per_net, l = blockIdx.x - g * per_net;
+    int tm, tn;
+    if ((tiles_m & 7) == 0) {
+        const int xcd = l & 7, q = l >> 3;
+        tm = xcd * (tiles_m >> 3) + q / tiles_n;
+        tn = q % tiles_n;
+    } else {
+        tm = l / tiles_n;
+        tn = l - tm * tiles_n;
+    }
     const float* __restrict__ X = a.x[g];
     const float* __restrict__ W = a.w[g];
     const float* __restrict__ Bv = a.b[g];
     float* __restrict__ Y = a.y[g];
-    const int N = a.N, K = a.K;
-    const int m0 = blockIdx.y * (64 * MI), n0 = blockIdx.x * kTN;
+    const int m0 = tm * (64 * MI), n0 = tn * kTN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = (wave >> 1) * (32 * MI), wc = (wave & 1) * 64;
     const int li = lane & 31, lh = lane >> 5;
@@ -462,7 +475,7 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     {                                                                                                                          \
         auto kern = linear_act_fast_kernel<TAIL, ELU, MI>;                                                                     \
         if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(kern), SLOT); e != hipSuccess) return e;              \
-        hipLaunchKernelGGL(kern, grid, dim3(256), kLinearLds, s, a);                                                           \
+        hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(256), kLinearLds, s, a);                                 \
     }
     const bool tail = a.K % kBK != 0, elu = a.act == 1;
     if (fast && !small) {
