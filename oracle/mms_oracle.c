@@ -42,60 +42,100 @@
 #define PI_F 3.14159265358979323846f
 #define TWO_PI_F 6.28318530717958647692f
 
+/* The physics (and the small vector helpers it uses) is written on `real`.  Default build: real = float -- the oracle the HIP
+ * kernels are compared with.  -DMO_F64 (oracle/Makefile: _build/libmms_oracle_f64.so) compiles ONLY the physics, in double, behind
+ * mo_physics_f64: the same model and the same fp32 inputs, evaluated with 29 more bits.  The GPU parity tests use it as the
+ * yardstick: the HIP kernel may be at most a small multiple of as far from the double result as the fp32 oracle itself is. */
+#ifdef MO_F64
+typedef double real;
+#define r_sqrt sqrt
+#define r_fmax fmax
+#define r_fmin fmin
+#define r_fabs fabs
+#define r_cos cos
+#define r_sin sin
+#else
+typedef float real;
+#define r_sqrt sqrtf
+#define r_fmax fmaxf
+#define r_fmin fminf
+#define r_fabs fabsf
+#define r_cos cosf
+#define r_sin sinf
+#endif
+static inline real r_clamp(real x, real lo, real hi) { return r_fmax(r_fmin(x, hi), lo); }
+#define R3(name, src) const real name[3] = {(src)[0], (src)[1], (src)[2]}   /* fp32 model vector as `real` (a copy; exact) */
+
 /* ------------------------------------------------------------------------------------------ */
 /* small vector / matrix helpers                                                               */
 /* ------------------------------------------------------------------------------------------ */
-static inline void cross3(const float a[3], const float b[3], float o[3]) {
-    float x = a[1] * b[2] - a[2] * b[1];
-    float y = a[2] * b[0] - a[0] * b[2];
-    float z = a[0] * b[1] - a[1] * b[0];
+static inline void cross3(const real a[3], const real b[3], real o[3]) {
+    real x = a[1] * b[2] - a[2] * b[1];
+    real y = a[2] * b[0] - a[0] * b[2];
+    real z = a[0] * b[1] - a[1] * b[0];
     o[0] = x; o[1] = y; o[2] = z;
 }
-static inline float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-static inline void matvec3(const float R[3][3], const float v[3], float o[3]) {
-    float x = R[0][0] * v[0] + R[0][1] * v[1] + R[0][2] * v[2];
-    float y = R[1][0] * v[0] + R[1][1] * v[1] + R[1][2] * v[2];
-    float z = R[2][0] * v[0] + R[2][1] * v[1] + R[2][2] * v[2];
+static inline real dot3(const real a[3], const real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void matvec3(const real R[3][3], const real v[3], real o[3]) {
+    real x = R[0][0] * v[0] + R[0][1] * v[1] + R[0][2] * v[2];
+    real y = R[1][0] * v[0] + R[1][1] * v[1] + R[1][2] * v[2];
+    real z = R[2][0] * v[0] + R[2][1] * v[1] + R[2][2] * v[2];
     o[0] = x; o[1] = y; o[2] = z;
 }
-static inline void matTvec3(const float R[3][3], const float v[3], float o[3]) {
-    float x = R[0][0] * v[0] + R[1][0] * v[1] + R[2][0] * v[2];
-    float y = R[0][1] * v[0] + R[1][1] * v[1] + R[2][1] * v[2];
-    float z = R[0][2] * v[0] + R[1][2] * v[1] + R[2][2] * v[2];
+static inline void matTvec3(const real R[3][3], const real v[3], real o[3]) {
+    real x = R[0][0] * v[0] + R[1][0] * v[1] + R[2][0] * v[2];
+    real y = R[0][1] * v[0] + R[1][1] * v[1] + R[2][1] * v[2];
+    real z = R[0][2] * v[0] + R[1][2] * v[1] + R[2][2] * v[2];
     o[0] = x; o[1] = y; o[2] = z;
 }
-static inline void matmul3(const float A[3][3], const float B[3][3], float O[3][3]) {
-    float T[3][3];
+static inline void matmul3(const real A[3][3], const real B[3][3], real O[3][3]) {
+    real T[3][3];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) T[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
     memcpy(O, T, sizeof(T));
 }
 /* rotation matrix of a unit quaternion (xyzw) */
-static void quat_to_mat(const float q[4], float R[3][3]) {
-    float x = q[0], y = q[1], z = q[2], w = q[3];
+static void quat_to_mat(const real q[4], real R[3][3]) {
+    real x = q[0], y = q[1], z = q[2], w = q[3];
     R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - w * z);       R[0][2] = 2.f * (x * z + w * y);
     R[1][0] = 2.f * (x * y + w * z);       R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - w * x);
     R[2][0] = 2.f * (x * z - w * y);       R[2][1] = 2.f * (y * z + w * x);       R[2][2] = 1.f - 2.f * (x * x + y * y);
 }
 /* Rodrigues: rotation by `ang` about unit axis `a` */
-static void axis_angle_to_mat(const float a[3], float ang, float R[3][3]) {
-    float c = cosf(ang), s = sinf(ang), t = 1.f - c;
+static void axis_angle_to_mat(const real a[3], real ang, real R[3][3]) {
+    real c = r_cos(ang), s = r_sin(ang), t = 1.f - c;
     R[0][0] = c + t * a[0] * a[0];        R[0][1] = t * a[0] * a[1] - s * a[2]; R[0][2] = t * a[0] * a[2] + s * a[1];
     R[1][0] = t * a[0] * a[1] + s * a[2]; R[1][1] = c + t * a[1] * a[1];        R[1][2] = t * a[1] * a[2] - s * a[0];
     R[2][0] = t * a[0] * a[2] - s * a[1]; R[2][1] = t * a[1] * a[2] + s * a[0]; R[2][2] = c + t * a[2] * a[2];
 }
 /* q <- normalize(q + h/2 * (w,0) (x) q), world-frame angular velocity */
-static void quat_integrate(float q[4], const float w[3], float h) {
-    float x = q[0], y = q[1], z = q[2], s = q[3];
-    float hx = 0.5f * h * w[0], hy = 0.5f * h * w[1], hz = 0.5f * h * w[2];
-    float nx = x + (hx * s + hy * z - hz * y);
-    float ny = y + (hy * s + hz * x - hx * z);
-    float nz = z + (hz * s + hx * y - hy * x);
-    float ns = s - (hx * x + hy * y + hz * z);
-    float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz + ns * ns);
+static void quat_integrate(real q[4], const real w[3], real h) {
+    real x = q[0], y = q[1], z = q[2], s = q[3];
+    real hx = 0.5f * h * w[0], hy = 0.5f * h * w[1], hz = 0.5f * h * w[2];
+    real nx = x + (hx * s + hy * z - hz * y);
+    real ny = y + (hy * s + hz * x - hx * z);
+    real nz = z + (hz * s + hx * y - hy * x);
+    real ns = s - (hx * x + hy * y + hz * z);
+    real inv = 1.f / r_sqrt(nx * nx + ny * ny + nz * nz + ns * ns);
     q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = ns * inv;
 }
 
+/* MultiIngenuity thrust (multi_ingenuity.py:268-339): thrusts[8][3] for one env from actions[24]; rotor (2h + r) uses
+ * actions[6h + 3r .. 6h + 3r + 2].  Pinned through mo_ingenuity_thrust (fixture ingenuity_thrust). */
+static void ingenuity_thrust_real(const real actions[24], real dt, real thrusts[24]) {
+    for (int h = 0; h < 4; h++)
+        for (int r = 0; r < 2; r++) {
+            const real* a = actions + 6 * h + 3 * r;
+            real vert = r_clamp(a[2] * 2000.f, -2000.f, 2000.f);
+            real lx = r_clamp(a[0], -0.2f, 0.2f), ly = r_clamp(a[1], -0.2f, 0.2f);
+            real* t = thrusts + 3 * (2 * h + r);
+            t[2] = dt * vert;
+            t[0] = t[2] * lx;
+            t[1] = t[2] * ly;
+        }
+}
+
+#ifndef MO_F64   /* the fixture-pinned restatements below are fp32 only */
 /* ------------------------------------------------------------------------------------------ */
 /* isaacgym.torch_utils helper semantics, scalar                               */
 /* ------------------------------------------------------------------------------------------ */
@@ -412,18 +452,7 @@ MO_EXPORT void mo_oneant_reward_batch(int64_t n, const float* obs, const int64_t
 /* MultiIngenuity (multi_ingenuity.py:268-339 thrust, :381-453 reward)                         */
 /* ------------------------------------------------------------------------------------------ */
 /* thrusts[8][3] for one env from actions[24]: rotor (2h + r) uses actions[6h + 3r .. 6h + 3r + 2] */
-MO_EXPORT void mo_ingenuity_thrust(const float actions[24], float dt, float thrusts[24]) {
-    for (int h = 0; h < 4; h++)
-        for (int r = 0; r < 2; r++) {
-            const float* a = actions + 6 * h + 3 * r;
-            float vert = clampf(a[2] * 2000.f, -2000.f, 2000.f);
-            float lx = clampf(a[0], -0.2f, 0.2f), ly = clampf(a[1], -0.2f, 0.2f);
-            float* t = thrusts + 3 * (2 * h + r);
-            t[2] = dt * vert;
-            t[0] = t[2] * lx;
-            t[1] = t[2] * ly;
-        }
-}
+MO_EXPORT void mo_ingenuity_thrust(const float actions[24], float dt, float thrusts[24]) { ingenuity_thrust_real(actions, dt, thrusts); }
 MO_EXPORT void mo_ingenuity_thrust_batch(int64_t n, const float* actions, float dt, float* thrusts) {
     for (int64_t i = 0; i < n; i++) mo_ingenuity_thrust(actions + 24 * i, dt, thrusts + 24 * i);
 }
@@ -588,71 +617,72 @@ MO_EXPORT void mo_ppo_log_prob(int64_t n, int A, const float* mean, const float*
     }
 }
 
+#endif /* !MO_F64 */
 /* ------------------------------------------------------------------------------------------ */
 /* PHYSICS (this build's model; parity unpinned against Isaac Gym -- see header)               */
 /* ------------------------------------------------------------------------------------------ */
-typedef float m66[6][6];
+typedef real m66[6][6];
 
 static void m66_zero(m66 M) { memset(M, 0, sizeof(m66)); }
 static void m66_add(m66 A, const m66 B) { for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) A[i][j] += B[i][j]; }
-static void m66_mulv(const m66 M, const float v[6], float o[6]) {
-    float t[6];
-    for (int i = 0; i < 6; i++) { float s = 0.f; for (int j = 0; j < 6; j++) s += M[i][j] * v[j]; t[i] = s; }
+static void m66_mulv(const m66 M, const real v[6], real o[6]) {
+    real t[6];
+    for (int i = 0; i < 6; i++) { real s = 0.f; for (int j = 0; j < 6; j++) s += M[i][j] * v[j]; t[i] = s; }
     memcpy(o, t, sizeof(t));
 }
 /* spatial inertia about the frame origin for mass m, COM offset c, rotational inertia Ic about the COM */
-static void spatial_inertia(float m, const float c[3], const float Ic[3][3], m66 I) {
-    float cc = dot3(c, c);
+static void spatial_inertia(real m, const real c[3], const real Ic[3][3], m66 I) {
+    real cc = dot3(c, c);
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {
             I[i][j] = Ic[i][j] + m * ((i == j ? cc : 0.f) - c[i] * c[j]);
             I[3 + i][3 + j] = (i == j) ? m : 0.f;
         }
-    float cx[3][3] = {{0.f, -c[2], c[1]}, {c[2], 0.f, -c[0]}, {-c[1], c[0], 0.f}};
+    real cx[3][3] = {{0.f, -c[2], c[1]}, {c[2], 0.f, -c[0]}, {-c[1], c[0], 0.f}};
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) { I[i][3 + j] = m * cx[i][j]; I[3 + j][i] = m * cx[i][j]; }
 }
 /* capsule / axisymmetric body: Ic = It*1 + (Ia - It) u u^T */
-static void axisym_inertia(float Ia, float It, const float u[3], float Ic[3][3]) {
+static void axisym_inertia(real Ia, real It, const real u[3], real Ic[3][3]) {
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ic[i][j] = (i == j ? It : 0.f) + (Ia - It) * u[i] * u[j];
 }
 /* bias force p = v x* (I v) - (c x m g, m g) with g = (0,0,-grav) */
-static void bias_force(const m66 I, const float v[6], float m, const float c[3], float grav, float p[6]) {
-    float h[6];
+static void bias_force(const m66 I, const real v[6], real m, const real c[3], real grav, real p[6]) {
+    real h[6];
     m66_mulv(I, v, h);
-    float t1[3], t2[3], t3[3];
+    real t1[3], t2[3], t3[3];
     cross3(v, h, t1);          /* w x n */
     cross3(v + 3, h + 3, t2);  /* v x f */
     cross3(v, h + 3, t3);      /* w x f */
-    float fg[3] = {0.f, 0.f, -m * grav}, ng[3];
+    real fg[3] = {0.f, 0.f, -m * grav}, ng[3];
     cross3(c, fg, ng);
     for (int i = 0; i < 3; i++) { p[i] = t1[i] + t2[i] - ng[i]; p[3 + i] = t3[i] - fg[i]; }
 }
 /* motion cross product: (w,v) xm (sw,sv) */
-static void cross_motion(const float a[6], const float b[6], float o[6]) {
-    float t1[3], t2[3], t3[3];
+static void cross_motion(const real a[6], const real b[6], real o[6]) {
+    real t1[3], t2[3], t3[3];
     cross3(a, b, t1);
     cross3(a, b + 3, t2);
     cross3(a + 3, b, t3);
     for (int i = 0; i < 3; i++) { o[i] = t1[i]; o[3 + i] = t2[i] + t3[i]; }
 }
 /* symmetric positive definite 6x6 solve (LDL^T, no pivoting) */
-static void solve6(const m66 A, const float b[6], float x[6]) {
-    float L[6][6], D[6], y[6];
+static void solve6(const m66 A, const real b[6], real x[6]) {
+    real L[6][6], D[6], y[6];
     for (int j = 0; j < 6; j++) {
-        float d = A[j][j];
+        real d = A[j][j];
         for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
         D[j] = d;
-        float inv = 1.f / d;
+        real inv = 1.f / d;
         for (int i = j + 1; i < 6; i++) {
-            float s = A[i][j];
+            real s = A[i][j];
             for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k] * D[k];
             L[i][j] = s * inv;
         }
     }
-    for (int i = 0; i < 6; i++) { float s = b[i]; for (int k = 0; k < i; k++) s -= L[i][k] * y[k]; y[i] = s; }
+    for (int i = 0; i < 6; i++) { real s = b[i]; for (int k = 0; k < i; k++) s -= L[i][k] * y[k]; y[i] = s; }
     for (int i = 5; i >= 0; i--) {
-        float s = y[i] / D[i];
+        real s = y[i] / D[i];
         for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k];
         x[i] = s;
     }
@@ -661,46 +691,46 @@ static void solve6(const m66 A, const float b[6], float x[6]) {
 /* one active contact on a body of the articulation */
 typedef struct {
     int active;
-    float xc[3];     /* contact point relative to the spatial origin O */
-    float n[3];      /* unit normal, from the other object into this body */
-    float kd;        /* k * penetration */
-    float gn, ct;    /* normal gain h*k + c; tangential (friction) damper */
-    float vrel[3];   /* point velocity relative to the other object's point */
-    float f[3];      /* resulting force on this body (filled after the solve) */
+    real xc[3];     /* contact point relative to the spatial origin O */
+    real n[3];      /* unit normal, from the other object into this body */
+    real kd;        /* k * penetration */
+    real gn, ct;    /* normal gain h*k + c; tangential (friction) damper */
+    real vrel[3];   /* point velocity relative to the other object's point */
+    real f[3];      /* resulting force on this body (filled after the solve) */
 } contact_t;
 
 /* I^A += h P^T G P;  p^A -= P^T (kd n - G vrel);  P = [-[xc]x | 1], G = (gn-ct) n n^T + ct 1 */
-static void contact_fold(const contact_t* c, float h, m66 IA, float pA[6]) {
+static void contact_fold(const contact_t* c, real h, m66 IA, real pA[6]) {
     if (!c->active) return;
-    float G[3][3], P[3][6];
+    real G[3][3], P[3][6];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) G[i][j] = (c->gn - c->ct) * c->n[i] * c->n[j] + (i == j ? c->ct : 0.f);
-    const float* x = c->xc;
-    float ncx[3][3] = {{0.f, x[2], -x[1]}, {-x[2], 0.f, x[0]}, {x[1], -x[0], 0.f}};   /* -[xc]x */
+    const real* x = c->xc;
+    real ncx[3][3] = {{0.f, x[2], -x[1]}, {-x[2], 0.f, x[0]}, {x[1], -x[0], 0.f}};   /* -[xc]x */
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) { P[i][j] = ncx[i][j]; P[i][3 + j] = (i == j) ? 1.f : 0.f; }
-    float GP[3][6];
+    real GP[3][6];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 6; j++) GP[i][j] = G[i][0] * P[0][j] + G[i][1] * P[1][j] + G[i][2] * P[2][j];
     for (int i = 0; i < 6; i++)
         for (int j = 0; j < 6; j++) IA[i][j] += h * (P[0][i] * GP[0][j] + P[1][i] * GP[1][j] + P[2][i] * GP[2][j]);
-    float Gv[3], f0[3], m0[3];
+    real Gv[3], f0[3], m0[3];
     matvec3(G, c->vrel, Gv);
     for (int i = 0; i < 3; i++) f0[i] = c->kd * c->n[i] - Gv[i];
     cross3(x, f0, m0);
     for (int i = 0; i < 3; i++) { pA[i] -= m0[i]; pA[3 + i] -= f0[i]; }
 }
 /* f = kd n - G (vrel + h (a_lin + alpha x xc)) */
-static void contact_force(contact_t* c, float h, const float a[6]) {
+static void contact_force(contact_t* c, real h, const real a[6]) {
     if (!c->active) { c->f[0] = c->f[1] = c->f[2] = 0.f; return; }
-    float ax[3], u[3];
+    real ax[3], u[3];
     cross3(a, c->xc, ax);
     for (int i = 0; i < 3; i++) u[i] = c->vrel[i] + h * (a[3 + i] + ax[i]);
-    float un = dot3(c->n, u);
+    real un = dot3(c->n, u);
     for (int i = 0; i < 3; i++) c->f[i] = c->kd * c->n[i] - ((c->gn - c->ct) * un * c->n[i] + c->ct * u[i]);
 }
 
-typedef struct { float pos[3]; float R[3][3]; float v[3]; float w[3]; float half[3]; } box_pose;
+typedef struct { real pos[3]; real R[3][3]; real v[3]; real w[3]; real half[3]; } box_pose;
 
 /* A contact is ACTIVE while the pair penetrates (d > 0) or would penetrate by the end of the substep at
  * the current normal velocity (d - h v_n > 0); pairs farther apart than CONTACT_MARGIN are not examined.
@@ -711,33 +741,33 @@ typedef struct { float pos[3]; float R[3][3]; float v[3]; float w[3]; float half
  * the force is then a CONTINUOUS function of the state -- zero at the activation boundary, full strength once
  * the pair overlaps by `ramp` -- so rounding-level differences cannot flip a contact on or off with a force
  * jump.  Joint limits use the same construction. */
-static inline float ramp01(float d, float r) { return fminf(fmaxf(d / r, 0.f), 1.f); }
+static inline real ramp01(real d, real r) { return r_fmin(r_fmax(d / r, 0.f), 1.f); }
 
 /* Sphere (centre xs relative to O, O at world position Ow, radius rad) on a body with spatial velocity vb:
  * contact against the ground plane z = 0 -> cg, and against the box -> cb. */
-static void sphere_contacts(const mms_model* M, float h, const float Ow[3], const float xs[3], float rad,
-                            const float vb[6], const box_pose* box, contact_t* cg, contact_t* cb) {
+static void sphere_contacts(const mms_model* M, real h, const real Ow[3], const real xs[3], real rad,
+                            const real vb[6], const box_pose* box, contact_t* cg, contact_t* cb) {
     /* ground */
     cg->active = 0;
     {
-        float zc = Ow[2] + xs[2];
-        float d = rad - zc;
+        real zc = Ow[2] + xs[2];
+        real d = rad - zc;
         if (d > -CONTACT_MARGIN) {
-            float xc[3] = {xs[0], xs[1], xs[2] - rad};
-            float vp[3], wx[3];
+            real xc[3] = {xs[0], xs[1], xs[2] - rad};
+            real vp[3], wx[3];
             cross3(vb, xc, wx);
             for (int i = 0; i < 3; i++) vp[i] = vb[3 + i] + wx[i];
-            float w = ramp01(fmaxf(d, d - h * vp[2]), M->pen_ramp);   /* penetrating now or at the end of the step */
-            float gn = w * (h * M->gnd_k + M->gnd_c);
-            float fn = fmaxf(w * M->gnd_k * d - gn * vp[2], 0.f);     /* explicit estimate: friction bound only */
+            real w = ramp01(r_fmax(d, d - h * vp[2]), M->pen_ramp);   /* penetrating now or at the end of the step */
+            real gn = w * (h * M->gnd_k + M->gnd_c);
+            real fn = r_fmax(w * M->gnd_k * d - gn * vp[2], 0.f);     /* explicit estimate: friction bound only */
             if (w > 0.f) {
                 cg->active = 1;
                 memcpy(cg->xc, xc, sizeof(xc));
                 cg->n[0] = 0.f; cg->n[1] = 0.f; cg->n[2] = 1.f;
                 cg->kd = w * M->gnd_k * d;
                 cg->gn = gn;
-                float vt = sqrtf(vp[0] * vp[0] + vp[1] * vp[1]);
-                cg->ct = M->gnd_mu * fn / fmaxf(vt, M->slip_eps);
+                real vt = r_sqrt(vp[0] * vp[0] + vp[1] * vp[1]);
+                cg->ct = M->gnd_mu * fn / r_fmax(vt, M->slip_eps);
                 memcpy(cg->vrel, vp, sizeof(vp));
             }
         }
@@ -745,42 +775,42 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
     /* box (frictionless) */
     cb->active = 0;
     if (box) {
-        float rel[3] = {Ow[0] + xs[0] - box->pos[0], Ow[1] + xs[1] - box->pos[1], Ow[2] + xs[2] - box->pos[2]};
-        float xb[3], q[3];
+        real rel[3] = {Ow[0] + xs[0] - box->pos[0], Ow[1] + xs[1] - box->pos[1], Ow[2] + xs[2] - box->pos[2]};
+        real xb[3], q[3];
         matTvec3(box->R, rel, xb);
         int inside = 1;
         for (int i = 0; i < 3; i++) {
-            q[i] = clampf(xb[i], -box->half[i], box->half[i]);
+            q[i] = r_clamp(xb[i], -box->half[i], box->half[i]);
             if (q[i] != xb[i]) inside = 0;
         }
-        float nb[3] = {0.f, 0.f, 0.f}, d;
+        real nb[3] = {0.f, 0.f, 0.f}, d;
         const int inside_far = 0;
         if (!inside) {
-            float dl[3] = {xb[0] - q[0], xb[1] - q[1], xb[2] - q[2]};
-            float dist = sqrtf(dot3(dl, dl));
+            real dl[3] = {xb[0] - q[0], xb[1] - q[1], xb[2] - q[2]};
+            real dist = r_sqrt(dot3(dl, dl));
             d = rad - dist;
             if (d > -CONTACT_MARGIN) { nb[0] = dl[0] / dist; nb[1] = dl[1] / dist; nb[2] = dl[2] / dist; }
         } else {
             int ax = 0;
-            float best = box->half[0] - fabsf(xb[0]);
+            real best = box->half[0] - r_fabs(xb[0]);
             for (int i = 1; i < 3; i++) {
-                float m = box->half[i] - fabsf(xb[i]);
+                real m = box->half[i] - r_fabs(xb[i]);
                 if (m < best) { best = m; ax = i; }
             }
             nb[ax] = (xb[ax] >= 0.f) ? 1.f : -1.f;
             d = rad + best;
         }
         if (d > -CONTACT_MARGIN && !inside_far) {
-            float n[3];
+            real n[3];
             matvec3(box->R, nb, n);
-            float xc[3] = {xs[0] - rad * n[0], xs[1] - rad * n[1], xs[2] - rad * n[2]};
-            float vp[3], wx[3], rb[3], vbx[3];
+            real xc[3] = {xs[0] - rad * n[0], xs[1] - rad * n[1], xs[2] - rad * n[2]};
+            real vp[3], wx[3], rb[3], vbx[3];
             cross3(vb, xc, wx);
             for (int i = 0; i < 3; i++) { vp[i] = vb[3 + i] + wx[i]; rb[i] = Ow[i] + xc[i] - box->pos[i]; }
             cross3(box->w, rb, vbx);
-            float vrel[3] = {vp[0] - box->v[0] - vbx[0], vp[1] - box->v[1] - vbx[1], vp[2] - box->v[2] - vbx[2]};
-            float w = ramp01(fmaxf(d, d - h * dot3(n, vrel)), M->pen_ramp);
-            float gn = w * (h * M->antbox_k + M->antbox_c);
+            real vrel[3] = {vp[0] - box->v[0] - vbx[0], vp[1] - box->v[1] - vbx[1], vp[2] - box->v[2] - vbx[2]};
+            real w = ramp01(r_fmax(d, d - h * dot3(n, vrel)), M->pen_ramp);
+            real gn = w * (h * M->antbox_k + M->antbox_c);
             if (w > 0.f) {
                 cb->active = 1;
                 memcpy(cb->xc, xc, sizeof(xc));
@@ -801,21 +831,21 @@ static void sphere_contacts(const mms_model* M, float h, const float Ow[3], cons
  * set_actor_rigid_body_properties / set_actor_dof_properties), MMS_DR_FLOATS values or NULL for the nominal ant:
  *   [0] torso, [1..4] leg, [5..8] foot mass scale (inertia scales with the mass: recomputeInertia = True is the setter's
  *   default argument), [9..16] joint damping scale, [17..24] lower-limit offset, [25..32] upper-limit offset (rad). */
-static void ant_substep(const mms_model* M, float h, float root[13], float dof[8][2], const float tau_motor[8],
-                        const box_pose* box, float box_wrench[6], float sensors[4][6], const float* dr) {
-    float Rt[3][3];
+static void ant_substep(const mms_model* M, real h, real root[13], real dof[8][2], const real tau_motor[8],
+                        const box_pose* box, real box_wrench[6], real sensors[4][6], const float* dr) {
+    real Rt[3][3];
     quat_to_mat(root + 3, Rt);
-    const float* Ow = root;
-    float v0[6] = {root[10], root[11], root[12], root[7], root[8], root[9]};  /* (w, vO) */
-    const float zero3[3] = {0.f, 0.f, 0.f};
+    const real* Ow = root;
+    real v0[6] = {root[10], root[11], root[12], root[7], root[8], root[9]};  /* (w, vO) */
+    const real zero3[3] = {0.f, 0.f, 0.f};
 
     /* ---- torso ---- */
     m66 IA0;
-    float pA0[6];
+    real pA0[6];
     {
-        float ez[3] = {Rt[0][2], Rt[1][2], Rt[2][2]};
-        float Ic[3][3];
-        const float mt = dr ? dr[0] : 1.f;
+        real ez[3] = {Rt[0][2], Rt[1][2], Rt[2][2]};
+        real Ic[3][3];
+        const real mt = dr ? dr[0] : 1.f;
         axisym_inertia(M->torso_izz * mt, M->torso_ixx * mt, ez, Ic);
         spatial_inertia(M->torso_mass * mt, zero3, Ic, IA0);
         bias_force(IA0, v0, M->torso_mass * mt, zero3, M->gravity, pA0);
@@ -826,47 +856,48 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
     contact_fold(&ct_b, h, IA0, pA0);
 
     /* per-leg data kept for the outward pass */
-    float s1[4][6], s2[4][6], c1[4][6], c2[4][6], U1[4][6], U2[4][6], D1[4], D2[4], u1[4], u2[4];
-    float Rf[4][3][3], J2[4][3];
+    real s1[4][6], s2[4][6], c1[4][6], c2[4][6], U1[4][6], U2[4][6], D1[4], D2[4], u1[4], u2[4];
+    real Rf[4][3][3], J2[4][3];
     contact_t chip_g[4], chip_b[4], cknee_g[4], cknee_b[4], ctip_g[4], ctip_b[4];
 
     for (int l = 0; l < 4; l++) {
-        float q1 = dof[2 * l][0], qd1 = dof[2 * l][1], q2 = dof[2 * l + 1][0], qd2 = dof[2 * l + 1][1];
+        real q1 = dof[2 * l][0], qd1 = dof[2 * l][1], q2 = dof[2 * l + 1][0], qd2 = dof[2 * l + 1][1];
         /* kinematics */
-        float J1[3], a1[3] = {Rt[0][2], Rt[1][2], Rt[2][2]};
-        matvec3(Rt, M->hip_pos[l], J1);
-        float Rz[3][3], Rl[3][3], Ra[3][3];
-        const float zax[3] = {0.f, 0.f, 1.f};
+        real J1[3], a1[3] = {Rt[0][2], Rt[1][2], Rt[2][2]};
+        R3(hip_pos, M->hip_pos[l]); R3(limb_dir, M->limb_dir[l]); R3(ankle_axis, M->ankle_axis[l]);
+        matvec3(Rt, hip_pos, J1);
+        real Rz[3][3], Rl[3][3], Ra[3][3];
+        const real zax[3] = {0.f, 0.f, 1.f};
         axis_angle_to_mat(zax, q1, Rz);
         matmul3(Rt, Rz, Rl);
-        float ul[3], a2[3], uf[3];
-        matvec3(Rl, M->limb_dir[l], ul);
-        matvec3(Rl, M->ankle_axis[l], a2);
+        real ul[3], a2[3], uf[3];
+        matvec3(Rl, limb_dir, ul);
+        matvec3(Rl, ankle_axis, a2);
         for (int i = 0; i < 3; i++) J2[l][i] = J1[i] + M->leg_len * ul[i];
-        axis_angle_to_mat(M->ankle_axis[l], q2, Ra);
+        axis_angle_to_mat(ankle_axis, q2, Ra);
         matmul3(Rl, Ra, Rf[l]);
-        matvec3(Rf[l], M->limb_dir[l], uf);
-        float cl[3], cf[3], tip[3];
+        matvec3(Rf[l], limb_dir, uf);
+        real cl[3], cf[3], tip[3];
         for (int i = 0; i < 3; i++) {
             cl[i] = J1[i] + 0.5f * M->leg_len * ul[i];
             cf[i] = J2[l][i] + 0.5f * M->foot_len * uf[i];
             tip[i] = J2[l][i] + M->foot_len * uf[i];
         }
         /* motion subspaces and velocities */
-        float t3[3];
+        real t3[3];
         cross3(J1, a1, t3);
         for (int i = 0; i < 3; i++) { s1[l][i] = a1[i]; s1[l][3 + i] = t3[i]; }
         cross3(J2[l], a2, t3);
         for (int i = 0; i < 3; i++) { s2[l][i] = a2[i]; s2[l][3 + i] = t3[i]; }
-        float vl[6], vf[6], sq[6];
+        real vl[6], vf[6], sq[6];
         for (int i = 0; i < 6; i++) { sq[i] = s1[l][i] * qd1; vl[i] = v0[i] + sq[i]; }
         cross_motion(v0, sq, c1[l]);
         for (int i = 0; i < 6; i++) { sq[i] = s2[l][i] * qd2; vf[i] = vl[i] + sq[i]; }
         cross_motion(vl, sq, c2[l]);
         /* inertias and bias forces */
         m66 IAl, IAf;
-        float pAl[6], pAf[6], Ic[3][3];
-        const float ml = dr ? dr[1 + l] : 1.f, mf = dr ? dr[5 + l] : 1.f;
+        real pAl[6], pAf[6], Ic[3][3];
+        const real ml = dr ? dr[1 + l] : 1.f, mf = dr ? dr[5 + l] : 1.f;
         axisym_inertia(M->leg_ia * ml, M->leg_it * ml, ul, Ic);
         spatial_inertia(M->leg_mass * ml, cl, Ic, IAl);
         bias_force(IAl, vl, M->leg_mass * ml, cl, M->gravity, pAl);
@@ -882,22 +913,22 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
         contact_fold(&ctip_g[l], h, IAf, pAf);  contact_fold(&ctip_b[l], h, IAf, pAf);
 
         /* joint torques with linearly-implicit damping and limits */
-        float tau[2], Dextra[2];
+        real tau[2], Dextra[2];
         for (int j = 0; j < 2; j++) {
             int d = 2 * l + j;
-            float q = dof[d][0], qd = dof[d][1];
-            const float damping = dr ? M->joint_damping * dr[9 + d] : M->joint_damping;
-            const float upper = dr ? M->dof_upper[d] + dr[25 + d] : M->dof_upper[d];
-            const float lower = dr ? M->dof_lower[d] + dr[17 + d] : M->dof_lower[d];
-            float t = tau_motor[d] - damping * qd;
-            float De = M->armature + h * damping;
-            float ehi = q - upper, elo = lower - q;
-            float whi = ramp01(fmaxf(ehi, ehi + h * qd), M->limit_ramp), wlo = ramp01(fmaxf(elo, elo - h * qd), M->limit_ramp);
+            real q = dof[d][0], qd = dof[d][1];
+            const real damping = dr ? M->joint_damping * dr[9 + d] : M->joint_damping;
+            const real upper = dr ? M->dof_upper[d] + dr[25 + d] : M->dof_upper[d];
+            const real lower = dr ? M->dof_lower[d] + dr[17 + d] : M->dof_lower[d];
+            real t = tau_motor[d] - damping * qd;
+            real De = M->armature + h * damping;
+            real ehi = q - upper, elo = lower - q;
+            real whi = ramp01(r_fmax(ehi, ehi + h * qd), M->limit_ramp), wlo = ramp01(r_fmax(elo, elo - h * qd), M->limit_ramp);
             if (whi > 0.f) {
-                float gl = whi * (h * M->limit_k + M->limit_c);
+                real gl = whi * (h * M->limit_k + M->limit_c);
                 t += -whi * M->limit_k * ehi - gl * qd; De += h * gl;
             } else if (wlo > 0.f) {
-                float gl = wlo * (h * M->limit_k + M->limit_c);
+                real gl = wlo * (h * M->limit_k + M->limit_c);
                 t += wlo * M->limit_k * elo - gl * qd; De += h * gl;
             }
             tau[j] = t; Dextra[j] = De;
@@ -909,10 +940,10 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
         u2[l] = tau[1];
         for (int i = 0; i < 6; i++) u2[l] -= s2[l][i] * pAf[i];
         {
-            float invD = 1.f / D2[l];
+            real invD = 1.f / D2[l];
             m66 Ia;
             for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Ia[i][j] = IAf[i][j] - U2[l][i] * U2[l][j] * invD;
-            float Iac[6];
+            real Iac[6];
             m66_mulv(Ia, c2[l], Iac);
             m66_add(IAl, Ia);
             for (int i = 0; i < 6; i++) pAl[i] += pAf[i] + Iac[i] + U2[l][i] * (u2[l] * invD);
@@ -924,38 +955,38 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
         u1[l] = tau[0];
         for (int i = 0; i < 6; i++) u1[l] -= s1[l][i] * pAl[i];
         {
-            float invD = 1.f / D1[l];
+            real invD = 1.f / D1[l];
             m66 Ia;
             for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Ia[i][j] = IAl[i][j] - U1[l][i] * U1[l][j] * invD;
-            float Iac[6];
+            real Iac[6];
             m66_mulv(Ia, c1[l], Iac);
             m66_add(IA0, Ia);
             for (int i = 0; i < 6; i++) pA0[i] += pAl[i] + Iac[i] + U1[l][i] * (u1[l] * invD);
         }
     }
     /* root */
-    float a0[6], rhs[6];
+    real a0[6], rhs[6];
     for (int i = 0; i < 6; i++) rhs[i] = -pA0[i];
     solve6(IA0, rhs, a0);
 
     /* outward + contact forces */
     contact_force(&ct_g, h, a0);
     contact_force(&ct_b, h, a0);
-    float fbox[3] = {0, 0, 0}, tbox[3] = {0, 0, 0};
+    real fbox[3] = {0, 0, 0}, tbox[3] = {0, 0, 0};
 #define ACC_BOX(c)                                                                          \
     if ((c).active && box) {                                                                \
-        float rb_[3] = {Ow[0] + (c).xc[0] - box->pos[0], Ow[1] + (c).xc[1] - box->pos[1],   \
+        real rb_[3] = {Ow[0] + (c).xc[0] - box->pos[0], Ow[1] + (c).xc[1] - box->pos[1],   \
                         Ow[2] + (c).xc[2] - box->pos[2]};                                   \
-        float nf_[3] = {-(c).f[0], -(c).f[1], -(c).f[2]}, tq_[3];                           \
+        real nf_[3] = {-(c).f[0], -(c).f[1], -(c).f[2]}, tq_[3];                           \
         cross3(rb_, nf_, tq_);                                                              \
         for (int i_ = 0; i_ < 3; i_++) { fbox[i_] += nf_[i_]; tbox[i_] += tq_[i_]; }         \
     }
     ACC_BOX(ct_b);
-    float qdd[8];
+    real qdd[8];
     for (int l = 0; l < 4; l++) {
-        float al[6], af[6];
+        real al[6], af[6];
         for (int i = 0; i < 6; i++) al[i] = a0[i] + c1[l][i];
-        float t = u1[l];
+        real t = u1[l];
         for (int i = 0; i < 6; i++) t -= U1[l][i] * al[i];
         qdd[2 * l] = t / D1[l];
         for (int i = 0; i < 6; i++) al[i] += s1[l][i] * qdd[2 * l];
@@ -969,11 +1000,11 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
         contact_force(&ctip_g[l], h, af);  contact_force(&ctip_b[l], h, af);
         ACC_BOX(chip_b[l]); ACC_BOX(cknee_b[l]); ACC_BOX(ctip_b[l]);
         if (sensors) {
-            float F[3] = {0, 0, 0}, T[3] = {0, 0, 0};
+            real F[3] = {0, 0, 0}, T[3] = {0, 0, 0};
             contact_t* cs[2] = {&ctip_g[l], &ctip_b[l]};
             for (int k = 0; k < 2; k++)
                 if (cs[k]->active) {
-                    float r[3] = {cs[k]->xc[0] - J2[l][0], cs[k]->xc[1] - J2[l][1], cs[k]->xc[2] - J2[l][2]}, tq[3];
+                    real r[3] = {cs[k]->xc[0] - J2[l][0], cs[k]->xc[1] - J2[l][1], cs[k]->xc[2] - J2[l][2]}, tq[3];
                     cross3(r, cs[k]->f, tq);
                     for (int i = 0; i < 3; i++) { F[i] += cs[k]->f[i]; T[i] += tq[i]; }
                 }
@@ -989,48 +1020,48 @@ static void ant_substep(const mms_model* M, float h, float root[13], float dof[8
         dof[d][1] += h * qdd[d];
         dof[d][0] += h * dof[d][1];
     }
-    float wxv[3];
+    real wxv[3];
     cross3(v0, v0 + 3, wxv);                                     /* classical accel = a_lin + w x v */
     for (int i = 0; i < 3; i++) {
         root[7 + i] += h * (a0[3 + i] + wxv[i]);
         root[10 + i] += h * a0[i];
     }
-    float wn = sqrtf(root[10] * root[10] + root[11] * root[11] + root[12] * root[12]);
-    if (wn > 64.f) { float s = 64.f / wn; root[10] *= s; root[11] *= s; root[12] *= s; }  /* PhysX default max angular velocity */
+    real wn = r_sqrt(root[10] * root[10] + root[11] * root[11] + root[12] * root[12]);
+    if (wn > 64.f) { real s = 64.f / wn; root[10] *= s; root[11] *= s; root[12] *= s; }  /* PhysX default max angular velocity */
     for (int i = 0; i < 3; i++) root[i] += h * root[7 + i];
     quat_integrate(root + 3, root + 10, h);
 }
 
 /* One substep of the free box: gravity, explicit ant reaction wrench, implicit frictionless corner contacts. */
-static void box_substep(const mms_model* M, float h, float root[13], const float wrench[6]) {
-    float R[3][3];
+static void box_substep(const mms_model* M, real h, real root[13], const real wrench[6]) {
+    real R[3][3];
     quat_to_mat(root + 3, R);
-    float Iw[3][3], RI[3][3];
+    real Iw[3][3], RI[3][3];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) RI[i][j] = R[i][j] * M->box_inertia[j];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) Iw[i][j] = RI[i][0] * R[j][0] + RI[i][1] * R[j][1] + RI[i][2] * R[j][2];
     m66 A;
     m66_zero(A);
     for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) A[i][j] = Iw[i][j]; A[3 + i][3 + i] = M->box_mass; }
-    float w[3] = {root[10], root[11], root[12]}, v[3] = {root[7], root[8], root[9]};
-    float Iww[3], gyro[3];
+    real w[3] = {root[10], root[11], root[12]}, v[3] = {root[7], root[8], root[9]};
+    real Iww[3], gyro[3];
     matvec3(Iw, w, Iww);
     cross3(w, Iww, gyro);
-    float b[6] = {wrench[0] - gyro[0], wrench[1] - gyro[1], wrench[2] - gyro[2],
+    real b[6] = {wrench[0] - gyro[0], wrench[1] - gyro[1], wrench[2] - gyro[2],
                   wrench[3], wrench[4], wrench[5] - M->box_mass * M->gravity};
-    float vb[6] = {w[0], w[1], w[2], v[0], v[1], v[2]};
+    real vb[6] = {w[0], w[1], w[2], v[0], v[1], v[2]};
     for (int c = 0; c < 8; c++) {
-        float loc[3] = {(c & 1 ? 1.f : -1.f) * M->box_half[0], (c & 2 ? 1.f : -1.f) * M->box_half[1],
+        real loc[3] = {(c & 1 ? 1.f : -1.f) * M->box_half[0], (c & 2 ? 1.f : -1.f) * M->box_half[1],
                         (c & 4 ? 1.f : -1.f) * M->box_half[2]};
-        float xc[3];
+        real xc[3];
         matvec3(R, loc, xc);
-        float d = -(root[2] + xc[2]);
+        real d = -(root[2] + xc[2]);
         if (d <= -CONTACT_MARGIN) continue;
-        float wx[3], vp[3];
+        real wx[3], vp[3];
         cross3(w, xc, wx);
         for (int i = 0; i < 3; i++) vp[i] = v[i] + wx[i];
-        float w = ramp01(fmaxf(d, d - h * vp[2]), M->pen_ramp);
-        float gn = w * (h * M->boxgnd_k + M->boxgnd_c);
+        real w = ramp01(r_fmax(d, d - h * vp[2]), M->pen_ramp);
+        real gn = w * (h * M->boxgnd_k + M->boxgnd_c);
         if (!(w > 0.f)) continue;
         contact_t ct;
         ct.active = 1;
@@ -1038,84 +1069,144 @@ static void box_substep(const mms_model* M, float h, float root[13], const float
         ct.n[0] = 0.f; ct.n[1] = 0.f; ct.n[2] = 1.f;
         ct.kd = w * M->boxgnd_k * d; ct.gn = gn; ct.ct = 0.f;
         if (M->boxgnd_mu > 0.f) {                                    /* optional Coulomb friction, regularised like the ants' */
-            float fn = fmaxf(w * M->boxgnd_k * d - gn * vp[2], 0.f);
-            float vt = sqrtf(vp[0] * vp[0] + vp[1] * vp[1]);
-            ct.ct = M->boxgnd_mu * fn / fmaxf(vt, M->slip_eps);
+            real fn = r_fmax(w * M->boxgnd_k * d - gn * vp[2], 0.f);
+            real vt = r_sqrt(vp[0] * vp[0] + vp[1] * vp[1]);
+            ct.ct = M->boxgnd_mu * fn / r_fmax(vt, M->slip_eps);
         }
         memcpy(ct.vrel, vp, sizeof(vp));
-        float p[6] = {0, 0, 0, 0, 0, 0};
+        real p[6] = {0, 0, 0, 0, 0, 0};
         contact_fold(&ct, h, A, p);
         for (int i = 0; i < 6; i++) b[i] -= p[i];
     }
     (void)vb;
-    float a[6];
+    real a[6];
     solve6(A, b, a);
     for (int i = 0; i < 3; i++) { root[10 + i] += h * a[i]; root[7 + i] += h * a[3 + i]; }
-    float wn = sqrtf(root[10] * root[10] + root[11] * root[11] + root[12] * root[12]);
-    if (wn > 64.f) { float s = 64.f / wn; root[10] *= s; root[11] *= s; root[12] *= s; }
+    real wn = r_sqrt(root[10] * root[10] + root[11] * root[11] + root[12] * root[12]);
+    if (wn > 64.f) { real s = 64.f / wn; root[10] *= s; root[11] *= s; root[12] *= s; }
     for (int i = 0; i < 3; i++) root[i] += h * root[7 + i];
     quat_integrate(root + 3, root + 10, h);
 }
 
 /* One substep of one helicopter (single rigid body).  thrust[2][3]: rotor forces in the body frame. */
-static void heli_substep(const mms_model* M, float h, float root[13], const float thrust[2][3]) {
-    float R[3][3];
+static void heli_substep(const mms_model* M, real h, real root[13], const real thrust[2][3]) {
+    real R[3][3];
     quat_to_mat(root + 3, R);
     /* reference point = body origin; COM at (0,0,com_z) in the body frame */
-    float cb[3] = {0.f, 0.f, M->heli_com_z}, c[3];
+    real cb[3] = {0.f, 0.f, M->heli_com_z}, c[3];
     matvec3(R, cb, c);
-    float Iw[3][3], RI[3][3];
+    real Iw[3][3], RI[3][3];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) RI[i][j] = R[i][j] * M->heli_inertia[j];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) Iw[i][j] = RI[i][0] * R[j][0] + RI[i][1] * R[j][1] + RI[i][2] * R[j][2];
     m66 A;
     spatial_inertia(M->heli_mass, c, Iw, A);
-    float v0[6] = {root[10], root[11], root[12], root[7], root[8], root[9]};
-    float p[6];
+    real v0[6] = {root[10], root[11], root[12], root[7], root[8], root[9]};
+    real p[6];
     bias_force(A, v0, M->heli_mass, c, M->gravity, p);
     for (int r = 0; r < 2; r++) {
-        float xb[3] = {0.f, 0.f, M->heli_rotor_z[r]}, x[3], f[3], m[3];
+        real xb[3] = {0.f, 0.f, M->heli_rotor_z[r]}, x[3], f[3], m[3];
         matvec3(R, xb, x);
         matvec3(R, thrust[r], f);
         cross3(x, f, m);
         for (int i = 0; i < 3; i++) { p[i] -= m[i]; p[3 + i] -= f[i]; }
     }
     for (int k = 0; k < 8; k++) {                      /* chassis corners against the ground */
-        float loc[3] = {(k & 1 ? 1.f : -1.f) * M->heli_half, (k & 2 ? 1.f : -1.f) * M->heli_half,
+        real loc[3] = {(k & 1 ? 1.f : -1.f) * M->heli_half, (k & 2 ? 1.f : -1.f) * M->heli_half,
                         (k & 4 ? 1.f : -1.f) * M->heli_half};
-        float xc[3];
+        real xc[3];
         matvec3(R, loc, xc);
-        float d = -(root[2] + xc[2]);
+        real d = -(root[2] + xc[2]);
         if (d <= -CONTACT_MARGIN) continue;
-        float wx[3], vp[3];
+        real wx[3], vp[3];
         cross3(v0, xc, wx);
         for (int i = 0; i < 3; i++) vp[i] = v0[3 + i] + wx[i];
-        float w = ramp01(fmaxf(d, d - h * vp[2]), M->pen_ramp);
-        float gn = w * (h * M->heli_gnd_k + M->heli_gnd_c);
-        float fn = fmaxf(w * M->heli_gnd_k * d - gn * vp[2], 0.f);
+        real w = ramp01(r_fmax(d, d - h * vp[2]), M->pen_ramp);
+        real gn = w * (h * M->heli_gnd_k + M->heli_gnd_c);
+        real fn = r_fmax(w * M->heli_gnd_k * d - gn * vp[2], 0.f);
         if (!(w > 0.f)) continue;
         contact_t ct;
         ct.active = 1;
         memcpy(ct.xc, xc, sizeof(xc));
         ct.n[0] = 0.f; ct.n[1] = 0.f; ct.n[2] = 1.f;
         ct.kd = w * M->heli_gnd_k * d; ct.gn = gn;
-        float vt = sqrtf(vp[0] * vp[0] + vp[1] * vp[1]);
-        ct.ct = M->gnd_mu * fn / fmaxf(vt, M->slip_eps);
+        real vt = r_sqrt(vp[0] * vp[0] + vp[1] * vp[1]);
+        ct.ct = M->gnd_mu * fn / r_fmax(vt, M->slip_eps);
         memcpy(ct.vrel, vp, sizeof(vp));
         contact_fold(&ct, h, A, p);
     }
-    float a[6], rhs[6];
+    real a[6], rhs[6];
     for (int i = 0; i < 6; i++) rhs[i] = -p[i];
     solve6(A, rhs, a);
-    float wxv[3];
+    real wxv[3];
     cross3(v0, v0 + 3, wxv);
     for (int i = 0; i < 3; i++) { root[7 + i] += h * (a[3 + i] + wxv[i]); root[10 + i] += h * a[i]; }
-    float wn = sqrtf(root[10] * root[10] + root[11] * root[11] + root[12] * root[12]);
-    if (wn > M->heli_max_angvel) { float s = M->heli_max_angvel / wn; root[10] *= s; root[11] *= s; root[12] *= s; }
+    real wn = r_sqrt(root[10] * root[10] + root[11] * root[11] + root[12] * root[12]);
+    if (wn > M->heli_max_angvel) { real s = M->heli_max_angvel / wn; root[10] *= s; root[11] *= s; root[12] *= s; }
     for (int i = 0; i < 3; i++) root[i] += h * root[7 + i];
     quat_integrate(root + 3, root + 10, h);
 }
 
+/* The physics of one env for one control step (all substeps), in place on `real` state: roots [actors][13] (env-local frame),
+ * dofs [dofs][2], sensors [A][24] (ant tasks; may be NULL).  act: the env's raw actions; dr: [A][MMS_DR_FLOATS] or NULL. */
+static void physics_core(const mms_config* c, int A, const float* act_in, real* roots, real* dofs, real* sensors, const float* dr) {
+    const mms_model* M = &c->model;
+    const real h = (real)c->dt / (real)c->substeps;
+    if (c->task == MMS_TASK_TEN_ANT || c->task == MMS_TASK_ONE_ANT) {
+        for (int s = 0; s < c->substeps; s++) {
+            real* br = roots + 13 * A;
+            box_pose box;
+            for (int j = 0; j < 3; j++) { box.pos[j] = br[j]; box.v[j] = br[7 + j]; box.w[j] = br[10 + j]; box.half[j] = M->box_half[j]; }
+            quat_to_mat(br + 3, box.R);
+            real wrench[6] = {0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < A; k++) {
+                real tau[8];
+                for (int j = 0; j < 8; j++) {
+                    float a = fmaxf(fminf(act_in[8 * k + j], c->clip_actions), -c->clip_actions);
+                    tau[j] = (real)a * M->gear[j] * c->power_scale;            /* ten_ant.py:889 */
+                }
+                ant_substep(M, h, roots + 13 * k, (real(*)[2])(dofs + 16 * k), tau, &box, wrench,
+                            sensors ? (real(*)[6])(sensors + (size_t)k * 24) : NULL, dr ? dr + (size_t)k * MMS_DR_FLOATS : NULL);
+            }
+            box_substep(M, h, br, wrench);
+        }
+    } else {
+        real thr[24], act[24];
+        for (int j = 0; j < 24; j++) act[j] = fmaxf(fminf(act_in[j], c->clip_actions), -c->clip_actions);
+        ingenuity_thrust_real(act, c->dt, thr);
+        for (int s = 0; s < c->substeps; s++)
+            for (int k = 0; k < A; k++) {
+                heli_substep(M, h, roots + 13 * k, (const real(*)[3])(thr + 6 * k));
+                for (int j = 0; j < 4; j++) dofs[2 * (4 * k + j)] += h * dofs[2 * (4 * k + j) + 1];  /* visual rotors: kinematic */
+            }
+    }
+}
+
+#ifdef MO_F64
+/* The double-precision yardstick: physics of n envs from fp32 state (as the fp32 engines hold it), results in double.
+ * Envs with reset[i] != 0 skip the physics, as in mo_step.  sens_in / sens_out [n][A][24] may be NULL (not an ant task). */
+MO_EXPORT void mo_physics_f64(const mms_config* c, int64_t n, const float* actions, const float* root_in, const float* dof_in,
+                              const float* sens_in, const float* dr, const int64_t* reset, double* root_out, double* dof_out,
+                              double* sens_out) {
+    int A = c->num_agents;
+    int ant = (c->task == MMS_TASK_TEN_ANT || c->task == MMS_TASK_ONE_ANT);
+    int actors = ant ? A + 1 : A, dofs = ant ? 8 * A : 4 * A, nact = ant ? 8 * A : 6 * A;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        double* r = root_out + (size_t)i * actors * 13;
+        double* d = dof_out + (size_t)i * dofs * 2;
+        double* sn = (sens_out && ant) ? sens_out + (size_t)i * A * 24 : NULL;
+        for (int j = 0; j < actors * 13; j++) r[j] = root_in[(size_t)i * actors * 13 + j];
+        for (int j = 0; j < dofs * 2; j++) d[j] = dof_in[(size_t)i * dofs * 2 + j];
+        if (sn) for (int j = 0; j < A * 24; j++) sn[j] = sens_in ? sens_in[(size_t)i * A * 24 + j] : 0.0;
+        if (reset[i] == 0) physics_core(c, A, actions + (size_t)i * nact, r, d, sn, dr ? dr + (size_t)i * A * MMS_DR_FLOATS : NULL);
+    }
+}
+MO_EXPORT int mo_abi_version(void) { return MMS_ABI_VERSION; }
+MO_EXPORT int mo_sizeof_config(void) { return (int)sizeof(mms_config); }
+#endif
+
+#ifndef MO_F64   /* engine + unit-level entry points: fp32 build only */
 /* ------------------------------------------------------------------------------------------ */
 /* engine: same buffers and step protocol as the product (include/mms.h)                       */
 /* ------------------------------------------------------------------------------------------ */
@@ -1334,44 +1425,9 @@ static void post_step_env(mo_engine* e, int i, int first_step) {
 }
 
 static void physics_env(mo_engine* e, int i) {
-    const mms_config* c = &e->cfg;
-    const mms_model* M = &c->model;
-    int A = e->A;
-    float* roots = e->root_states + (size_t)i * e->actors * 13;
-    float* dofs = e->dof_state + (size_t)i * e->dofs_per_env * 2;
-    float h = c->dt / (float)c->substeps;
-    if (is_ant_task(c->task)) {
-        for (int s = 0; s < c->substeps; s++) {
-            float* br = roots + 13 * A;
-            box_pose box;
-            memcpy(box.pos, br, 12);
-            quat_to_mat(br + 3, box.R);
-            memcpy(box.v, br + 7, 12);
-            memcpy(box.w, br + 10, 12);
-            memcpy(box.half, M->box_half, 12);
-            float wrench[6] = {0, 0, 0, 0, 0, 0};
-            for (int k = 0; k < A; k++) {
-                float tau[8];
-                for (int j = 0; j < 8; j++)
-                    tau[j] = clampf(e->actions[(size_t)i * e->num_actions + 8 * k + j], -c->clip_actions, c->clip_actions) *
-                             M->gear[j] * c->power_scale;            /* ten_ant.py:889 */
-                ant_substep(M, h, roots + 13 * k, (float(*)[2])(dofs + 16 * k), tau, &box, wrench,
-                            (float(*)[6])(e->foot_sensors + ((size_t)i * A + k) * 24),
-                            e->dr_enabled ? e->dr_params + ((size_t)i * A + k) * MMS_DR_FLOATS : NULL);
-            }
-            box_substep(M, h, br, wrench);
-        }
-    } else {
-        float thr[24];
-        float act[24];
-        for (int j = 0; j < 24; j++) act[j] = clampf(e->actions[(size_t)i * 24 + j], -c->clip_actions, c->clip_actions);
-        mo_ingenuity_thrust(act, c->dt, thr);
-        for (int s = 0; s < c->substeps; s++)
-            for (int k = 0; k < A; k++) {
-                heli_substep(M, h, roots + 13 * k, (const float(*)[3])(thr + 6 * k));
-                for (int j = 0; j < 4; j++) dofs[2 * (4 * k + j)] += h * dofs[2 * (4 * k + j) + 1];  /* visual rotors: kinematic */
-            }
-    }
+    physics_core(&e->cfg, e->A, e->actions + (size_t)i * e->num_actions, e->root_states + (size_t)i * e->actors * 13,
+                 e->dof_state + (size_t)i * e->dofs_per_env * 2, e->foot_sensors + (size_t)i * e->A * 24,
+                 e->dr_enabled ? e->dr_params + (size_t)i * e->A * MMS_DR_FLOATS : NULL);
 }
 
 /* BaseTask.step (base_task.py:129-149).  Envs flagged for reset skip the physics: their state is
@@ -1466,3 +1522,4 @@ MO_EXPORT void mo_ant_momentum(const mms_model* M, const float* root, const floa
 }
 MO_EXPORT int mo_abi_version(void) { return MMS_ABI_VERSION; }
 MO_EXPORT int mo_sizeof_config(void) { return (int)sizeof(mms_config); }
+#endif /* !MO_F64 */

@@ -7,11 +7,22 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured parity margins of this run (tests/parity.py): gpurun_out/ travels back from the GPU box."""
+    try:
+        import parity
+        parity.dump_margins(os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
+    except Exception as e:                      # never turn a green run red over the report
+        print("parity margins not written:", e)
 
 
 def load_golden(name):
