@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MMS_ABI_VERSION 1
+#define MMS_ABI_VERSION 2
 #define MMS_DR_FLOATS 33       /* per-ant physical domain-randomisation block, see mms_set_dr */
 
 enum mms_task { MMS_TASK_TEN_ANT = 0, MMS_TASK_ONE_ANT = 1, MMS_TASK_MULTI_INGENUITY = 2 };
@@ -69,8 +69,9 @@ typedef struct mms_model {
     /* contact (compliant, linearly-implicit) */
     float gnd_k, gnd_c, gnd_mu, slip_eps, pen_ramp;
     float antbox_k, antbox_c;
+    float antbox_mu;                     /* ant-box Coulomb friction (regularised like the ground's); 0 = frictionless contact */
     float boxgnd_k, boxgnd_c;
-    float boxgnd_mu;                     /* box-ground Coulomb friction; 0 = the frictionless box of this model (default) */
+    float boxgnd_mu;                     /* box-ground Coulomb friction; 0 = frictionless */
     /* box */
     float box_half[3], box_mass, box_inertia[3];
     /* helicopter (MultiIngenuity): one rigid body */

@@ -204,16 +204,21 @@ struct Contact {
 };
 MMS_HD Contact contact_none() { return Contact{0.f, V3{0, 0, 0}, V3{0, 0, 1}, V3{0, 0, 0}, 0.f, 0.f, 0.f}; }
 
-// I^A += h P^T G P, p^A -= P^T (kd n - G vrel);  G = (gn - ct) n n^T + ct 1
+// I^A += h P^T G P, p^A -= P^T (kd n - G vrel);  G = (gn - ct) n n^T + ct 1,  P = [-[xc]x | 1]:
+// a rank-1 term along wn = (xc x n, n) plus the isotropic part h ct P^T P = h ct [[(x.x) 1 - x x^T, [x]x], [[x]x^T, 1]],
+// whose 15 non-zero entries of the upper triangle are written out (three more rank-1 updates would cost 3 x 21 FMAs)
 MMS_HD void contact_fold(const Contact& c, float h, Sym6& IA, S6& pA) {
     if (c.active == 0.f) return;
     S6 wn = S6{cross(c.xc, c.n), c.n};
     sym_rank1(IA, h * (c.gn - c.ct), wn);
     if (c.ct != 0.f) {
-        float hc = h * c.ct;
-        sym_rank1(IA, hc, S6{cross(c.xc, V3{1, 0, 0}), V3{1, 0, 0}});
-        sym_rank1(IA, hc, S6{cross(c.xc, V3{0, 1, 0}), V3{0, 1, 0}});
-        sym_rank1(IA, hc, S6{cross(c.xc, V3{0, 0, 1}), V3{0, 0, 1}});
+        const float t = h * c.ct, x = c.xc.x, y = c.xc.y, z = c.xc.z;
+        IA.m[sidx(0, 0)] += t * (y * y + z * z); IA.m[sidx(0, 1)] += -t * x * y; IA.m[sidx(0, 2)] += -t * x * z;
+        IA.m[sidx(1, 1)] += t * (x * x + z * z); IA.m[sidx(1, 2)] += -t * y * z; IA.m[sidx(2, 2)] += t * (x * x + y * y);
+        IA.m[sidx(0, 4)] += -t * z; IA.m[sidx(0, 5)] += t * y;
+        IA.m[sidx(1, 3)] += t * z;  IA.m[sidx(1, 5)] += -t * x;
+        IA.m[sidx(2, 3)] += -t * y; IA.m[sidx(2, 4)] += t * x;
+        IA.m[sidx(3, 3)] += t; IA.m[sidx(4, 4)] += t; IA.m[sidx(5, 5)] += t;
     }
     float vn = dot(c.n, c.vrel);
     V3 f0 = (c.kd - (c.gn - c.ct) * vn) * c.n - c.ct * c.vrel;
@@ -253,7 +258,8 @@ MMS_HD Contact sphere_ground(float k, float cdamp, float mu, float slip_eps, flo
     }
     return c;
 }
-MMS_HD Contact sphere_box(float k, float cdamp, float pen_ramp, float h, V3 Ow, V3 xs, float rad, S6 vb, const BoxPose& box) {
+MMS_HD Contact sphere_box(float k, float cdamp, float pen_ramp, float h, V3 Ow, V3 xs, float rad, S6 vb, const BoxPose& box,
+                          float mu = 0.f, float slip_eps = 1.f) {
     Contact c = contact_none();
     V3 rel = Ow + xs - box.pos;
     V3 xb = mulT(box.R, rel);
@@ -291,6 +297,12 @@ MMS_HD Contact sphere_box(float k, float cdamp, float pen_ramp, float h, V3 Ow, 
             c.kd = w * k * d;
             c.gn = gn;
             c.ct = 0.f;
+            if (mu > 0.f) {                                        // Coulomb friction, regularised like the ground's
+                float vn = dot(n, vrel);
+                float fn = fmaxf(w * k * d - gn * vn, 0.f);
+                V3 vt = vrel - vn * n;
+                c.ct = mu * fn / fmaxf(sqrtf(dot(vt, vt)), slip_eps);
+            }
             c.vrel = vrel;
         }
     }
@@ -379,9 +391,11 @@ MMS_HD void contact_fold_ground(const Contact& c, float h, Sym6& IA, S6& pA) {
     pA.a = pA.a - cross(c.xc, f0);
     pA.l = pA.l - f0;
 }
-// frictionless box contact fold (rank 1): I^A += h gn wn wn^T, p^A -= (kd - gn vn) wn,  wn = (xc x n, n)
+// box contact fold.  Frictionless (rank 1): I^A += h gn wn wn^T, p^A -= (kd - gn vn) wn,  wn = (xc x n, n); with friction
+// (c.ct != 0, model.antbox_mu > 0) the general form.
 MMS_HD void contact_fold_box(const Contact& c, float h, Sym6& IA, S6& pA) {
     if (c.active == 0.f) return;
+    if (c.ct != 0.f) { contact_fold(c, h, IA, pA); return; }
     S6 wn = S6{cross(c.xc, c.n), c.n};
     sym_rank1(IA, h * c.gn, wn);
     pA = pA + (-(c.kd - c.gn * dot(c.n, c.vrel))) * wn;
@@ -390,6 +404,12 @@ MMS_HD void contact_fold_box(const Contact& c, float h, Sym6& IA, S6& pA) {
 // f = (kd - gn vn) - h gn (wn . a);  wrench -= f ((O + xc - box) x n, n)
 MMS_HD void box_reaction(const Contact& c, float h, V3 Ow, const BoxPose& box, S6 acc, S6& w) {
     if (c.active == 0.f) return;
+    if (c.ct != 0.f) {                                             // with friction: the full contact force, tangential part included
+        V3 f = contact_force(c, h, acc);
+        w.a = w.a - cross(Ow + c.xc - box.pos, f);
+        w.l = w.l - f;
+        return;
+    }
     S6 wn = S6{cross(c.xc, c.n), c.n};
     float f = (c.kd - c.gn * dot(c.n, c.vrel)) - (h * c.gn) * dot(wn, acc);
     w.a = w.a - f * cross(Ow + c.xc - box.pos, c.n);
@@ -524,7 +544,7 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         contact_fold_ground(g, h, IAf, pAf);
         if (SENSORS) { SP->tip_g = g; SP->tip_b = contact_none(); }
         if (P.near_box) {
-            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box);
+            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IAf, pAf);
             if (SENSORS) SP->tip_b = b;
         }
@@ -556,9 +576,9 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl);
         contact_fold_ground(g, h, IAl, pAl);
         if (P.near_box) {
-            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box);
+            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IAl, pAl);
-            b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box);
+            b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IAl, pAl);
         }
     }
@@ -597,7 +617,7 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, zero, M->torso_radius, v0);
         contact_fold_ground(g, h, IA0, pA0);
         if (P.near_box) {
-            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, zero, M->torso_radius, v0, box);
+            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, zero, M->torso_radius, v0, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IA0, pA0);
         }
     }
@@ -644,14 +664,14 @@ MMS_HD void leg_outward(const mms_model* M, const LegConst& L, float h, AntLane&
         M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);          // rare: the full kinematics again for the contact points
         LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
         S6 v0 = S6{S.ang, S.vel};
-        Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box);
+        Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
         box_reaction(b, h, Ow, box, al, wrench);
-        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box);
+        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
         box_reaction(b, h, Ow, box, al, wrench);
-        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box);
+        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box, M->antbox_mu, M->slip_eps);
         box_reaction(b, h, Ow, box, af, wrench);
         if (leg == 0) {
-            b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, V3{0, 0, 0}, M->torso_radius, v0, box);
+            b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, V3{0, 0, 0}, M->torso_radius, v0, box, M->antbox_mu, M->slip_eps);
             box_reaction(b, h, Ow, box, a0, wrench);
         }
     }

@@ -270,13 +270,21 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
         const bool box_friction = M->boxgnd_mu > 0.f;                // uniform: box-ground friction couples all six accelerations
         for (int s = 0; s < C->substeps; s++) {
             S6 wr = ant_phase();
-            // The box's own ground contacts do not depend on this substep's ant reactions: the corner lanes evaluate and reduce them
-            // BEFORE the barrier -- in the layouts whose box lanes fill waves of their own that is time in which those waves would
+            // The box's own ground contacts (with or without friction) do not depend on this substep's ant reactions: the corner
+            // lanes evaluate and reduce them BEFORE the barrier -- in the layouts whose box lanes fill waves of their own that is time in which those waves would
             // only wait for the ant lanes; after the barrier the box needs the wrench, one small solve and the integration.
             BoxCorner bc = {};
+            BoxCornerF bf;
             if (is_box && !box_friction) {
                 bc = box_corner(M, h, load_rigid(s_box), s_bp->R, corner);
                 oct_sum(bc);
+            }
+            if (is_box && box_friction) {
+                bf = box_corner_friction(M, h, load_rigid(s_box), s_bp->R, corner);
+#pragma unroll
+                for (int k = 0; k < 21; k++) bf.IA.m[k] = oct_sum(bf.IA.m[k]);
+                bf.pA.a.x = oct_sum(bf.pA.a.x); bf.pA.a.y = oct_sum(bf.pA.a.y); bf.pA.a.z = oct_sum(bf.pA.a.z);
+                bf.pA.l.x = oct_sum(bf.pA.l.x); bf.pA.l.y = oct_sum(bf.pA.l.y); bf.pA.l.z = oct_sum(bf.pA.l.z);
             }
             S6 w = S6{V3{0, 0, 0}, V3{0, 0, 0}};
             if (kOneWave) {                                          // one wave per env: the reaction wrench by DPP / permute
@@ -290,11 +298,6 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
                 RigidState B = load_rigid(s_box);                    // (again: cheaper than carrying 22 values across the barrier)
                 M3 R = s_bp->R;
                 if (box_friction) {
-                    BoxCornerF bf = box_corner_friction(M, h, B, R, corner);
-#pragma unroll
-                    for (int k = 0; k < 21; k++) bf.IA.m[k] = oct_sum(bf.IA.m[k]);
-                    bf.pA.a.x = oct_sum(bf.pA.a.x); bf.pA.a.y = oct_sum(bf.pA.a.y); bf.pA.a.z = oct_sum(bf.pA.a.z);
-                    bf.pA.l.x = oct_sum(bf.pA.l.x); bf.pA.l.y = oct_sum(bf.pA.l.y); bf.pA.l.z = oct_sum(bf.pA.l.z);
                     if (simulate) box_finish_friction(M, h, B, R, bf, w);
                 } else if (simulate) box_finish(M, h, B, R, bc, w);
                 if (corner == 0) box_store(B);

@@ -16,7 +16,7 @@ import ctypes
 import math
 import xml.etree.ElementTree as ET
 
-MMS_ABI_VERSION = 1
+MMS_ABI_VERSION = 2
 TASK_IDS = {"TenAnt": 0, "OneAnt": 1, "MultiIngenuity": 2}
 
 
@@ -36,7 +36,7 @@ class MmsModel(ctypes.Structure):
         ("limit_k", ctypes.c_float), ("limit_c", ctypes.c_float), ("limit_ramp", ctypes.c_float),
         ("gnd_k", ctypes.c_float), ("gnd_c", ctypes.c_float), ("gnd_mu", ctypes.c_float),
         ("slip_eps", ctypes.c_float), ("pen_ramp", ctypes.c_float),
-        ("antbox_k", ctypes.c_float), ("antbox_c", ctypes.c_float),
+        ("antbox_k", ctypes.c_float), ("antbox_c", ctypes.c_float), ("antbox_mu", ctypes.c_float),
         ("boxgnd_k", ctypes.c_float), ("boxgnd_c", ctypes.c_float), ("boxgnd_mu", ctypes.c_float),
         ("box_half", ctypes.c_float * 3), ("box_mass", ctypes.c_float), ("box_inertia", ctypes.c_float * 3),
         ("heli_mass", ctypes.c_float), ("heli_inertia", ctypes.c_float * 3), ("heli_com_z", ctypes.c_float),
@@ -75,6 +75,8 @@ class MmsTensor(ctypes.Structure):
 # ant description (restated from nv_ant.xml; see module docstring)
 # ----------------------------------------------------------------------------------------------
 ANT_DENSITY = 5.0
+ANT_FRICTION = 1.5        # <default><geom friction="1.5 0.1 0.1"> (nv_ant.xml:8)
+BOX_FRICTION = 0.0        # shape_props[0].friction = 0. (ten_ant.py:548, one_ant.py:282)
 ANT_DESCRIPTION = {
     "torso": {"sphere_radius": 0.25,
               "aux_capsules": [((0.0, 0.0, 0.0), (0.2, 0.2, 0.0)), ((0.0, 0.0, 0.0), (-0.2, 0.2, 0.0)),
@@ -213,7 +215,7 @@ def build_model(task, num_agents, dt, substeps, gravity):
     m.antbox_c = min(100.0, 0.25 * mass / h)
     m.boxgnd_k = 3.0e3 * mass
     m.boxgnd_c = 60.0 * mass
-    m.boxgnd_mu = 0.0                       # frictionless box; cfg["env"]["boxGroundFriction"] overrides
+    m.boxgnd_mu = m.antbox_mu = 0.0         # set by make_config from the materials and the combine rule
     # --- helicopter: chassis box 0.12^3 density 50 + two rotor discs r 0.15, half height 0.005, density 1000
     mc = 50.0 * 0.12 ** 3
     mr = 1000.0 * math.pi * 0.15 ** 2 * 0.01
@@ -326,9 +328,22 @@ def make_config(task, cfg=None, num_envs=None, num_agents=None, device=0, seed=0
         c.box_start[0], c.box_start[1], c.box_start[2] = 4.0, 0.0, 1.0
     gravity = 3.721 if task == "MultiIngenuity" else -float(sim.get("gravity", [0, 0, -9.81])[2])
     c.model = build_model(task, int(num_agents), c.dt, c.substeps, gravity)
-    # not a key of the reference YAML: opt-in Coulomb friction between the box and the ground (0.5 = what PhysX's "average"
-    # combine rule would make of the box's 0 and the plane's 1.0; default 0 = this model's frictionless box)
-    c.model.boxgnd_mu = float(env.get("boxGroundFriction", 0.0))
+    # Contact friction = combine(material a, material b).  Materials: the ant's geoms 1.5 (nv_ant.xml:8, the MJCF default geom
+    # friction), the ground plane cfg env.plane.dynamicFriction (ten_ant.py:233-238), the box 0 (ten_ant.py:547-551,
+    # one_ant.py:281-285), the helicopter 1.0.  Combine rule: PhysX's documented default is the AVERAGE of the two materials --
+    # ant-ground 1.25, box-ground 0.5, ant-box 0.75 -- and the reference's own OneAnt training log is only consistent with a box
+    # that stops when it is no longer pushed (tools/ref_logs.py).  `env.frictionCombine: "min"` (not a key
+    # of the reference YAML) gives the other reading: a box that is frictionless against everything, ant-ground 1.0.
+    # `env.boxGroundFriction` (not a reference key either) overrides the box-ground value alone.
+    rule = str(env.get("frictionCombine", "average"))
+    if rule not in ("average", "min"):
+        raise ValueError("env.frictionCombine must be 'average' or 'min', got %r" % rule)
+    comb = (lambda a, b: 0.5 * (a + b)) if rule == "average" else min
+    plane_mu = float(env.get("plane", {}).get("dynamicFriction", 1.0))
+    body_mu = 1.0 if task == "MultiIngenuity" else ANT_FRICTION
+    c.model.gnd_mu = comb(body_mu, plane_mu)
+    c.model.boxgnd_mu = float(env.get("boxGroundFriction", comb(BOX_FRICTION, plane_mu)))
+    c.model.antbox_mu = comb(ANT_FRICTION, BOX_FRICTION)
     return c
 
 

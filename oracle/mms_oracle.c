@@ -772,7 +772,7 @@ static void sphere_contacts(const mms_model* M, real h, const real Ow[3], const 
             }
         }
     }
-    /* box (frictionless) */
+    /* box (frictionless unless model.antbox_mu > 0) */
     cb->active = 0;
     if (box) {
         real rel[3] = {Ow[0] + xs[0] - box->pos[0], Ow[1] + xs[1] - box->pos[1], Ow[2] + xs[2] - box->pos[2]};
@@ -818,6 +818,12 @@ static void sphere_contacts(const mms_model* M, real h, const real Ow[3], const 
                 cb->kd = w * M->antbox_k * d;
                 cb->gn = gn;
                 cb->ct = 0.f;
+                if (M->antbox_mu > 0.f) {                            /* Coulomb friction, regularised like the ground's */
+                    real vn = dot3(n, vrel);
+                    real fn = r_fmax(w * M->antbox_k * d - gn * vn, 0.f);
+                    real vt[3] = {vrel[0] - vn * n[0], vrel[1] - vn * n[1], vrel[2] - vn * n[2]};
+                    cb->ct = M->antbox_mu * fn / r_fmax(r_sqrt(dot3(vt, vt)), M->slip_eps);
+                }
                 memcpy(cb->vrel, vrel, sizeof(vrel));
             }
         }

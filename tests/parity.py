@@ -8,9 +8,13 @@ Three independent questions, three gates:
    is that double evaluation (oracle/mms_oracle.c compiled with -DMO_F64, same model, same fp32 inputs):
        err(implementation, f64)  <=  RATIO x err(fp32 oracle, f64) + floor        on the median,
        err(implementation, f64)  <=  RATIO_TAIL x err(fp32 oracle, f64) + floor   on the 99th percentile
-   of the per-step maxima, for velocities (relative to max(1, |v|)), poses and -- OneAnt -- the foot sensors.  (The p99 of 40 ..
-   150 per-step maxima is an order statistic of a heavy-tailed sample: the lane emulation on the CPU -- a clean fp32
-   evaluation with no approximate functions -- measures 0.3 .. 2.8 x the oracle's own p99 and 0.74 .. 1.19 x its median.)  A wrong term,
+   over all (env, step) pairs of a test -- one sample per pair, the env's largest error -- for velocities (relative to
+   max(1, |v|)), poses and -- OneAnt -- the foot sensors.  (The tail is an order statistic of a heavy-tailed sample: the lane
+   emulation on the CPU -- a clean fp32 evaluation with no approximate functions -- measures 0.3 .. 2.8 x the oracle's own p99.
+   The largest single sample is only capped: the model has rare states where one ulp on an input moves the DOUBLE result by
+   2 rad/s -- a foot caught between the ground and the tilted box inside the 0.5 mm activation ramp, found on the GPU as a
+   0.5 rad/s deviation of one joint of one ant in 280 env-steps -- and whichever side of such a kink an implementation's
+   rounding lands on is not an error.)  A wrong term,
    index or sign is O(0.1 .. 10) on most steps and fails by orders of magnitude; an implementation that is merely sloppier
    than a clean fp32 evaluation (approximate reciprocals, polynomial sin / cos) fails too once it is 2x worse.
 2. EPILOGUE (reset, observations, reward, caches), decoupled from the physics' conditioning: the oracle's post-physics glue is
@@ -28,7 +32,7 @@ import numpy as np
 from oracle.oracle import OracleEngine, physics_f64
 
 RATIO = 2.0              # the implementation may be this much farther from the double result than the fp32 oracle is (median)
-RATIO_TAIL = 4.0         # ... and this much on the 99th percentile of the per-step maxima
+RATIO_TAIL = 3.0         # ... and this much on the 99th percentile (measured: <= 1.5 lane emulation, <= 1.8 MI355X)
 VEL_FLOOR = 2e-6         # additive floors: a few ulp (the helicopters in free flight sit at 5e-8 on both sides)
 POSE_FLOOR = 2e-6
 SENS_FLOOR = 2e-5
@@ -140,18 +144,22 @@ class TeacherForced:
         if live.any():
             self.live_steps += 1
             vs = np.maximum(1.0, np.abs(v64[live]))
-            gv, ov = float(np.max(np.abs(vg[live] - v64[live]) / vs)), float(np.max(np.abs(vo[live] - v64[live]) / vs))
-            gp, op = float(np.max(np.abs(pg[live] - p64[live]))), float(np.max(np.abs(po[live] - p64[live])))
-            assert gv < VEL_CAP, (what, "velocity vs f64", gv)
-            assert gp < POSE_CAP, (what, "pose vs f64", gp)
-            self.log["gv"].append(gv); self.log["ov"].append(ov); self.log["gp"].append(gp); self.log["op"].append(op)
+            # one sample per (env, step): the env's largest error.  (Statistics over per-STEP maxima would let one ill-conditioned
+            # env decide a whole step: the model has rare states -- a foot caught between the ground and the tilted box inside the
+            # 0.5 mm activation ramp -- where ONE ulp on an input moves the double result itself by 2 rad/s.)
+            gv, ov = np.max(np.abs(vg[live] - v64[live]) / vs, 1), np.max(np.abs(vo[live] - v64[live]) / vs, 1)
+            gp, op = np.max(np.abs(pg[live] - p64[live]), 1), np.max(np.abs(po[live] - p64[live]), 1)
+            assert gv.max() < VEL_CAP, (what, "velocity vs f64", float(gv.max()))
+            assert gp.max() < POSE_CAP, (what, "pose vs f64", float(gp.max()))
+            self.log["gv"].extend(gv.tolist()); self.log["ov"].extend(ov.tolist())
+            self.log["gp"].extend(gp.tolist()); self.log["op"].extend(op.tolist())
             self.log["dv"].append(float(np.max(np.abs(vg[live] - vo[live]) / vs)))
             self.log["dp"].append(float(np.max(np.abs(pg[live] - po[live]))))
             if self.task == "OneAnt":
                 sg, so = got["foot_sensors"].reshape(n, -1)[live], o.tensor("foot_sensors").reshape(n, -1)[live]
                 st = s64.reshape(n, -1)[live]
                 ss = np.maximum(1.0, np.abs(st))
-                self.log["gs"].append(float(np.max(np.abs(sg - st) / ss))); self.log["os"].append(float(np.max(np.abs(so - st) / ss)))
+                self.log["gs"].extend(np.max(np.abs(sg - st) / ss, 1).tolist()); self.log["os"].extend(np.max(np.abs(so - st) / ss, 1).tolist())
         if (~live).any():                       # reset rows: integer hashing is bit-exact, 0.4 u - 0.2 may contract into one fma
             assert np.max(np.abs(pg[~live] - po[~live])) < 3e-7 and np.max(np.abs(vg[~live] - vo[~live])) < 3e-7, (what, "reset state")
         # ---- 2. epilogue on the implementation's own post-step state ----

@@ -13,7 +13,7 @@ import pytest
 from conftest import ROOT
 
 from massive_marl_benchmark_amd import _lib
-from massive_marl_benchmark_amd.model import (ANT_DESCRIPTION, MmsConfig, default_cfg, load_mjcf_ant, make_config, task_dims)
+from massive_marl_benchmark_amd.model import (ANT_DESCRIPTION, MMS_ABI_VERSION, MmsConfig, default_cfg, load_mjcf_ant, make_config, task_dims)
 
 REF = "/root/reference"
 
@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_loads_without_gpu_and_refuses_cpu():
     L = _lib.lib()                                   # dlopen + symbol binding only; no compute
-    assert L.mms_abi_version() == 1
+    assert L.mms_abi_version() == MMS_ABI_VERSION
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present: the no-device error path is not reachable")

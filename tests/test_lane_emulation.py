@@ -90,10 +90,14 @@ def test_teacher_forced_parity(emu, task, n, steps):
     assert tf.resets > n or task != "TenAnt"
 
 
-@pytest.mark.parametrize("task,n", [("TenAnt", 5), ("OneAnt", 6)])
-def test_ant_box_contact_parity(emu, task, n):
-    """Teacher-forced parity while ants are pressed against the box; the box must feel them (its x velocity goes negative)."""
-    kw = dict(num_envs=n, seed=11, total_envs=64, env_offset=7)
+@pytest.mark.parametrize("task,n,rule", [("TenAnt", 5, "average"), ("OneAnt", 6, "average"), ("TenAnt", 4, "min"), ("OneAnt", 5, "min")])
+def test_ant_box_contact_parity(emu, task, n, rule):
+    """Teacher-forced parity while ants are pressed against the box (with ant-box friction under `average`, frictionless under
+    `min`); the box must feel them (its x velocity goes negative)."""
+    from massive_marl_benchmark_amd.model import default_cfg
+    cfg = default_cfg(task)
+    cfg["env"]["frictionCombine"] = rule
+    kw = dict(cfg=cfg, num_envs=n, seed=11, total_envs=64, env_offset=7)
     o = OracleEngine(task, **kw)
     e = EmuEngine(emu, task, **kw)
     tf = parity.TeacherForced(o, lambda k: e.buf[k])
@@ -111,7 +115,7 @@ def test_ant_box_contact_parity(emu, task, n):
         pushed = min(pushed, float(box_vx.min()))
         if t == 20:
             shove_ants_into_box(o, rng)                    # again, from a different configuration
-    tf.finish("emu/ant_box_contact/%s" % task)
+    tf.finish("emu/ant_box_contact/%s/%s" % (task, rule))
     assert pushed < -1e-3, pushed
 
 
