@@ -39,16 +39,31 @@ NSTEPS = 8                              # cfg/ppo/config.yaml:23
 GAMMA, LAM = 0.96, 0.95                 # cfg/ppo/config.yaml:30-31
 
 
+def step_kernel_source_hash():
+    """sha256 over what the step kernel is compiled from: the kernel file, the lane header, the launch-argument header and the
+    Makefile (flags).  profiles/step_kernel_traffic.json records the hash of the build its PMC passes profiled."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("step_kernels.hip", "mms_lane.h", "step_args.h", "Makefile"):
+        with open(os.path.join(ROOT, "massive_marl_benchmark_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic():
-    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/step_kernel_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of tools/profile_step.py, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself; None if the file is absent."""
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/step_kernel_traffic.json, written by
+    tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of tools/profile_step.py, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself.  None when the file is
+    absent OR was measured on another build of the kernel (its source hash differs from the sources next to this file)."""
     path = os.path.join(ROOT, "profiles", "step_kernel_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            tr = json.load(f)
     except Exception:
         return None
+    if tr.get("source_hash") != step_kernel_source_hash():
+        return None
+    return tr
 
 
 def shard_for_rank(rank, world, envs_per_gpu):
@@ -170,7 +185,8 @@ def main():
                 sim_graph.replay()
         torch.cuda.synchronize()
         sim_batches.append(time.perf_counter() - t0)
-    sim_wall = 4.0 * sorted(sim_batches)[1]
+    sim_wall = 4.0 * sorted(sim_batches)[1]            # (lower) median batch x 4; the mean and every batch are reported beside it
+    sim_wall_mean = sum(sim_batches)
     # step-kernel launch duration: back-to-back launches with nothing else on the stream, HIP events around them.
     # Measured twice -- here, after the sim-only series, and again right after the GEMM-heavy rollout series -- because the
     # kernel is VALU-issue bound and so follows the core clock, which the rollout's matrix-core bursts pull down.
@@ -260,19 +276,40 @@ def main():
             torch.cuda.current_stream(device).wait_stream(side)
             torch.cuda.synchronize()
 
+        K = max(1, K_req)                                   # timed: exactly K steps
+        tail_graph = None
+        if graph is not None and K % NSTEPS:
+            # the K mod 8 steps of the last, unfinished rollout of the timed region as a second graph, so that the figure does not
+            # depend on whether K is a multiple of 8 (round 1: 2 replays + 4 eager steps at the driver's --steps 20)
+            storage.clear()
+            with torch.cuda.stream(side):
+                tail_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(tail_graph, stream=side):
+                    for _ in range(K % NSTEPS):
+                        rollout_step()
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize()
+            storage.clear()
+
         def run_steps(k):
-            # whole rollouts (8 steps + GAE) as graph replays, the remaining k mod 8 steps of a last, unfinished rollout eagerly
-            # (after a replay the engine's clamped observation row is current, which is what the eager step 0 starts from)
+            # whole rollouts (8 steps + GAE) as graph replays, then the k mod 8 steps of an unfinished rollout (tail graph when k is
+            # the timed K, eagerly otherwise; after a replay the engine's clamped observation row is current, which is what step 0
+            # of a rollout starts from)
             if graph is not None:
                 for _ in range(k // NSTEPS):
                     graph.replay()
+                if k % NSTEPS and k == K and tail_graph is not None:
+                    tail_graph.replay()
+                    storage.step = k % NSTEPS                # (host-side cursor: a replay does not run the Python that advances it)
+                    return
                 k = k % NSTEPS
             for _ in range(k):
                 rollout_step()
 
-        K = max(1, K_req)                                   # timed: exactly K steps
         W = W_req if graph is None else ((W_req + NSTEPS - 1) // NSTEPS) * NSTEPS    # warm-up: whole rollouts, at least W steps
         storage.clear()
+        run_steps(max(64, NSTEPS))                          # always: 64 untimed steps before the W warm-up steps the caller asked for
+        storage.clear()                                     # (clocks, allocator pools, first replays), outside the timed region
         run_steps(W)
         barrier()
         t0 = time.perf_counter()
@@ -359,8 +396,12 @@ def main():
                        "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else "mms_linear2_act + mms_ppo_heads_act",
                        "critic_deferred": bool(args.defer_critic), "finite": finite, "resets_total": resets_seen},
             "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
-                         "note": "engine step with pre-drawn actions (ring of 16); four batches, median batch x 4",
-                         "batch_ms": [1e3 * b for b in sim_batches], "hipgraph": sim_graph is not None},
+                         "value_mean": world * N * sim_steps / sim_wall_mean, "ms_per_step_mean": 1e3 * sim_wall_mean / sim_steps,
+                         "note": "engine step with pre-drawn actions (ring of 16); four equal batches: `value` from the median batch, "
+                                 "`value_mean` from all four; a batch more than 1.5 x the median is listed in `outlier_batches`",
+                         "batch_ms": [1e3 * b for b in sim_batches],
+                         "outlier_batches": [i for i, b in enumerate(sim_batches) if b > 1.5 * sorted(sim_batches)[1]],
+                         "hipgraph": sim_graph is not None},
             "roofline": {"bound": "hbm", "kernel": step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (tr or {}).get("source"),

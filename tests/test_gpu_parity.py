@@ -590,6 +590,113 @@ def test_hundred_agent_swarm_parity(torch_cuda):
     eng.close()
 
 
+def test_swarm_full_size_properties(torch_cuda):
+    """BASELINE configs[4] at its per-GPU size: 100 ants per env, 16384 envs over 8 GPUs = 2048 envs on this one (the <512,1>
+    multi-wave variant of the step kernel).  Determinism, shard invariance (2 x 1024 with matching env_offset = how two GPUs
+    would hold them), finiteness, joint limits, box on the ground, resets."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.engine import Engine
+    N, A, TOTAL = 2048, 100, 16384
+    g = torch.Generator().manual_seed(99)
+    ring = [(torch.rand(N, 8 * A, generator=g) * 2 - 1).cuda() for _ in range(4)]
+
+    def run(parts, steps, offset0=4096):
+        engs = [Engine("TenAnt", num_envs=sz, num_agents=A, device=0, seed=5, env_offset=offset0 + off, total_envs=TOTAL) for off, sz in parts]
+        assert engs[0].obs_dim == 3808 and engs[0].num_actions == 800
+        for t in range(steps):
+            for e, (off, sz) in zip(engs, parts):
+                e.tensor("actions").copy_(ring[t % 4][off:off + sz])
+                e.step()
+        torch.cuda.synchronize()
+        out = {k: torch.cat([e.tensor(k) for e in engs]).clone() for k in ("obs", "rew", "reset", "progress", "root_states", "dof_state", "reset_count")}
+        for e in engs:
+            e.close()
+        return out
+
+    steps = 100
+    a = run([(0, N)], steps)
+    b = run([(0, N)], steps)
+    c = run([(0, 1024), (1024, 1024)], steps)
+    for k in a:
+        assert torch.equal(a[k], b[k]), "not deterministic: " + k
+        assert torch.equal(a[k], c[k]), "depends on sharding: " + k
+    assert torch.isfinite(a["obs"]).all() and torch.isfinite(a["rew"]).all() and torch.isfinite(a["root_states"]).all()
+    assert int(a["reset_count"].sum()) > N                                  # first-step reset + natural terminations
+    r = a["root_states"].view(N, A + 1, 13)
+    assert float(r[:, :A, 2].min()) > 0.0 and float(r[:, :A, 2].max()) < 2.5
+    settled = a["progress"] > 40
+    assert bool(settled.any()) and float((r[settled, A, 2] - 0.5).abs().max()) < 0.03     # the 280 m box rests on the ground
+    lo = torch.tensor([-0.698132, 0.523599, -0.698132, -1.745329, -0.698132, -1.745329, -0.698132, 0.523599], device="cuda")
+    hi = torch.tensor([0.698132, 1.745329, 0.698132, -0.523599, 0.698132, -0.523599, 0.698132, 1.745329], device="cuda")
+    q = a["dof_state"].view(N, A, 8, 2)[..., 0]
+    assert float((q - hi).max()) < 0.1 and float((lo - q).max()) < 0.1
+    assert float(r[:, :, 3:7].norm(dim=-1).sub(1).abs().max()) < 1e-5
+    parity.record("gpu/swarm100_full_size", envs=N, ants=A, steps=steps, resets=int(a["reset_count"].sum()),
+                  max_speed=float(r[:, :, 7:10].abs().max()))
+
+
+def test_mappo_datapath_full_size(torch_cuda):
+    """BASELINE configs[3] on one GPU's shard: 4096 TenAnt envs through the MAPPO rollout data path -- MultiVecTaskPython +
+    SharedRolloutBuffers (env step writing share_obs[t+1], mms_marl_views, one mms_gae_marl_agents launch for all ten agents)
+    -- for two rollouts of 8 steps: the per-agent views hold what the wrapper returned, returns match a float64 GAE."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.algorithms.marl.utils.shared_buffer import SharedRolloutBuffers
+    from massive_marl_benchmark_amd.model import default_cfg
+    from massive_marl_benchmark_amd.tasks.agent_base.multi_vec_task import MultiVecTaskPython
+    from massive_marl_benchmark_amd.tasks.ten_ant import TenAnt
+    n, T, A = 4096, 8, 10
+    conf = dict(episode_length=T, n_rollout_threads=n, hidden_size=16, recurrent_N=1, gamma=0.99, gae_lambda=0.95, use_gae=True,
+                use_popart=False, use_valuenorm=True, use_proper_time_limits=False)
+    cfg = default_cfg("TenAnt")
+    cfg["env"]["numEnvs"] = n
+    cfg["clip_observations"] = 7.0
+    cfg["seed"] = 4
+    env = MultiVecTaskPython(TenAnt(cfg, None, "physx", "cuda", 0, True, is_multi_agent=True), "cuda:0")
+    sh = SharedRolloutBuffers(conf, env, "cuda:0")
+    sh.warmup()
+
+    class Norm:
+        def __init__(self, k):
+            self.m, self.v = torch.tensor([0.1 * k], device="cuda"), torch.tensor([1.0 + 0.2 * k], device="cuda")
+
+        def running_mean_var(self):
+            return self.m, self.v
+
+    norms = [Norm(k) for k in range(A)]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for it in range(2):
+        vals = []
+        for t in range(T):
+            acts = [torch.rand(n, 8, generator=g, device="cuda") * 2 - 1 for _ in range(A)]
+            logp = [torch.randn(n, 8, generator=g, device="cuda") for _ in range(A)]
+            v = torch.randn(n, A, generator=g, device="cuda")
+            rew, dones = sh.env_step(acts)
+            sh.insert_step(rew, dones, v, acts, logp)
+            vals.append(v)
+            torch.cuda.synchronize()
+            assert torch.equal(sh.share_obs[t + 1], env.task.engine.tensor("obs_clipped")), (it, t)
+            assert torch.equal(sh.agents[3].obs[t + 1][:, :38], sh.share_obs[t + 1][:, 38 * 3:38 * 4])
+            assert torch.equal(sh.agents[3].obs[t + 1][:, 38:], sh.share_obs[t + 1][:, 380:])
+        nxt = torch.randn(n, A, generator=g, device="cuda")
+        sh.compute_returns(nxt, norms)
+        torch.cuda.synchronize()
+        # float64 GAE of agent 7 from the stored planes (separated_buffer.py:153-164 with ValueNorm denormalisation)
+        k = 7
+        vp = torch.cat([torch.stack(vals)[:, :, k], nxt[None, :, k]]).double() * float(norms[k].v.sqrt()) + float(norms[k].m)
+        rw, mk = sh.agents[k].rewards[..., 0].double(), sh.agents[k].masks[..., 0].double()
+        gae, want = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(T, n, dtype=torch.float64, device="cuda")
+        for t in reversed(range(T)):
+            delta = rw[t] + 0.99 * vp[t + 1] * mk[t + 1] - vp[t]
+            gae = delta + 0.99 * 0.95 * mk[t + 1] * gae
+            want[t] = gae + vp[t]
+        err = float((sh.agents[k].returns[:T, :, 0].double() - want).abs().max() / want.abs().max().clamp(min=1.0))
+        assert err < 1e-5, err
+        assert bool(torch.isfinite(sh.share_obs).all())
+        sh.after_update()
+    parity.record("gpu/mappo_datapath_full_size", envs=n, agents=A, gae_rel_err=err)
+    env.task.engine.close()
+
+
 def test_ingenuity_full_size_properties(torch_cuda):
     """BASELINE config 3 size (MultiIngenuity, 8192 envs): determinism, shard invariance, finiteness, resets."""
     torch = torch_cuda

@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--fixed-lr", action="store_true", help="no adaptive KL schedule")
     ap.add_argument("--value-coef", type=float, default=1.0)
-    ap.add_argument("--box-friction", type=float, default=0.0, help="cfg env.boxGroundFriction (0 = this model's frictionless box)")
+    ap.add_argument("--friction-combine", default="average", choices=["average", "min"],
+                    help="cfg env.frictionCombine: PhysX's average rule (default) or min = a box that is frictionless against everything")
     args = ap.parse_args()
 
     import torch
@@ -44,7 +45,7 @@ def main():
     cfg["env"]["numEnvs"] = args.num_envs
     cfg["seed"] = args.seed
     cfg["clip_observations"] = 5.0
-    cfg["env"]["boxGroundFriction"] = args.box_friction
+    cfg["env"]["frictionCombine"] = args.friction_combine
     task = {"OneAnt": OneAnt, "TenAnt": TenAnt}[args.task](cfg, None, "physx", "cuda", 0, True)
     env = VecTaskPython(task, "cuda:0", 5.0, 1.0)
     N, obs_dim, act_dim = env.num_envs, env.observation_space.shape[0], env.action_space.shape[0]
