@@ -85,7 +85,6 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout step eagerly instead of replaying a hipGraph")
     ap.add_argument("--library-gemms", action="store_true",
                     help="A/B: the policy's layers as library GEMMs + separate ELU passes (critic on a second stream) instead of mms_linear2_act / mms_ppo_heads_act")
-    ap.add_argument("--fuse-bf16", action="store_true", help="A/B (bf16-policy series): mms_linear2_act_bf16 instead of the library bf16 GEMMs + ELU")
     ap.add_argument("--one-stream", action="store_true", help="A/B: actor and critic MLPs on one stream")
     ap.add_argument("--defer-critic", action="store_true",
                     help="A/B: let the critic pass overlap the sampling kernel and the env step (joined before the GAE); faster, but "
@@ -205,7 +204,6 @@ def main():
         ac_.bind_rollout(None if args.unfused else storage, None if args.unfused else actions_buf)
         ac_.two_streams = not args.one_stream
         ac_.fuse_head = not args.library_gemms
-        ac_.fuse_layers_bf16 = args.fuse_bf16
         ac_.fuse_layers = not args.library_gemms
         ac_.defer_value = args.defer_critic and not args.one_stream
 

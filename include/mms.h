@@ -28,15 +28,20 @@
  *     105-142)
  *   apply_randomizations actor_params: set_actor_rigid_body_properties   mms_set_dr + "dr_params"
  *     / set_actor_dof_properties (base_task.py:343-395)
- *   ActorCritic.act sampling tail + RolloutStorage.add_transitions       mms_ppo_act,
+ *   ActorCritic.act sampling tail + RolloutStorage.add_transitions       mms_ppo_act, mms_ppo_heads_act,
  *     (algorithms/rl/ppo/module.py:73-87; storage.py:33-47)              mms_bind_rollout_out
+ *   ActorCritic hidden layers (module.py:27-52)                          mms_linear2_act
  *
  * Ownership: the engine owns every buffer it reports through mms_get_tensor for the lifetime of the
  * handle; callers wrap them as NON-owning views and must keep the handle alive while any view exists.
  * Threading: a handle is not thread-safe; one handle per process / GPU.  All work is enqueued on the
  * caller's HIP stream; no entry point synchronises the device except mms_create / mms_destroy.
  * Status: 0 = ok; non-zero = error, text from mms_last_error().
- * There is NO CPU fallback: mms_create fails when no HIP device is usable.
+ * There is NO CPU fallback: mms_create of libmms.so fails when no HIP device is usable.  A SEPARATE library, libmms_cpu.so, exports
+ * the same symbols for the reference's `--sim_device cpu` pipeline (base_task.py:27-32): the same lane math compiled for the host
+ * (csrc/cpu/), selected only by device = -1 / device_type = "cpu", never automatically.  Device arguments of the free functions
+ * (mms_gae_*, mms_ppo_*, mms_linear2_act, mms_marl_views) follow the same rule; streams are ignored by the CPU build.
+ * Every entry point leaves the caller's current HIP device unchanged.
  */
 #ifndef MMS_H
 #define MMS_H
@@ -85,7 +90,7 @@ typedef struct mms_config {
     int32_t task;                        /* enum mms_task */
     int32_t num_envs;                    /* envs owned by this handle (this GPU's shard) */
     int32_t num_agents;                  /* ants (10 / 1) or helicopters (4) per env */
-    int32_t device;                      /* HIP device ordinal (>= 0) */
+    int32_t device;                      /* HIP device ordinal (>= 0) for libmms.so; -1 for libmms_cpu.so, the explicit opt-in CPU build */
     int32_t substeps;                    /* physics substeps per control step (cfg sim.substeps = 2) */
     int32_t max_episode_length;          /* cfg env.episodeLength */
     int32_t external_noise;              /* 1: reset noise is read from the "reset_noise" tensor */
@@ -213,18 +218,12 @@ int mms_ppo_act(int device, const float* mean, const float* value, const float* 
                 int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot, float* logp_slot,
                 float* value_slot, float* mu_slot, float* sigma_slot, int64_t N, int32_t A, void* hip_stream);
 
-/* mms_ppo_act with the actor's last Linear layer (module.py:29-30: nn.Linear(pi_hid_sizes[-1], actions)) folded in:
- * mean = hidden @ weight^T + bias on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums), then the same
- * sampling and stores.  hidden [N,H] f32 is the output of the last activation, weight [A,H] and bias [A] are torch's Linear
- * parameters; H must be a multiple of 64, A <= 128.  Replaces a skinny GEMM that runs at < 20 TFLOP/s plus a launch. */
-int mms_ppo_head_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H, const float* value,
-                     const float* log_std, uint64_t seed, int64_t* counters, int64_t row_offset, int32_t reference_scale,
-                     float* actions_out, float* act_slot, float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot,
-                     int64_t N, int32_t A, void* hip_stream);
-
-/* mms_ppo_head_act that also evaluates the critic's last layer (module.py:49: nn.Linear(vf_hid_sizes[-1], 1)) when vhidden is
- * given: value_i = vhidden[i, :] . vweight + vbias[0] (vhidden [N,VH] f32 = output of the critic's last activation, VH a multiple
- * of 4) goes to value_slot; `value` is ignored then.  vhidden = NULL: exactly mms_ppo_head_act. */
+/* mms_ppo_act with the last Linear layers of both networks folded in.  Actor (module.py:29-30: nn.Linear(pi_hid_sizes[-1],
+ * actions)): mean = hidden @ weight^T + bias on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums), then the
+ * same sampling and stores; hidden [N,H] f32 is the output of the last activation, weight [A,H] and bias [A] are torch's Linear
+ * parameters; H must be a multiple of 64, A <= 128.  Critic (module.py:49: nn.Linear(vf_hid_sizes[-1], 1)) when vhidden is given:
+ * value_i = vhidden[i, :] . vweight + vbias[0] (vhidden [N,VH] f32 = output of the critic's last activation, VH a multiple of 4)
+ * goes to value_slot and `value` is ignored; vhidden = NULL: `value` [N] (or NULL) is stored as in mms_ppo_act. */
 int mms_ppo_heads_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H, const float* value,
                       const float* vhidden, const float* vweight, const float* vbias, int32_t VH, const float* log_std, uint64_t seed,
                       int64_t* counters, int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
@@ -238,14 +237,6 @@ int mms_ppo_heads_act(int device, const float* hidden, const float* weight, cons
  * x1 = w1 = b1 = y1 = NULL runs a single problem.  x0 and x1 may be the same buffer (first layer). */
 int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const float* x0, const float* w0, const float* b0, float* y0,
                     const float* x1, const float* w1, const float* b1, float* y1, int32_t act, void* hip_stream);
-
-/* The same layer with bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16) and bf16 output, for a bf16 copy of the
- * policy.  x [M,K]: bf16, or f32 when x_is_f32 (the first layer takes the observation row as it is and rounds it while staging);
- * w [N,ldw] bf16 with rows padded with zeros to ldw, a multiple of 64 >= K; b [N] f32; y [M,N] bf16.  K a multiple of 4 for
- * f32 x, of 64 for bf16 x. */
-int mms_linear2_act_bf16(int device, int64_t M, int32_t N, int32_t K, int32_t ldw, int32_t x_is_f32, const void* x0, const void* w0,
-                         const float* b0, void* y0, const void* x1, const void* w1, const float* b1, void* y1, int32_t act,
-                         void* hip_stream);
 
 const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
 int mms_abi_version(void);

@@ -3,20 +3,21 @@
 
 Only the path the shipped configs use is accelerated: `use_gae=True`, `use_proper_time_limits=False`, with
 PopArt / ValueNorm / no normaliser (cfg/mappo/config.yaml:26-27, cfg/happo/config.yaml:29).  The other
-branches raise (they are not reachable from the shipped configs); the minibatch generators are out of scope."""
+branches raise (they are not reachable from the shipped configs).  The minibatch generators the trainers iterate over
+(feed_forward / naive_recurrent / recurrent, separated_buffer.py:170-428) come from generators.MinibatchGenerators."""
 import ctypes
 
 import torch
 
 from .... import _lib
-from ....engine import current_stream_ptr
+from .generators import MinibatchGenerators
 
 
 def _shape_of(space):
     return tuple(space.shape) if hasattr(space, "shape") else tuple(space)
 
 
-class SeparatedReplayBuffer(object):
+class SeparatedReplayBuffer(MinibatchGenerators):
     def __init__(self, config, obs_space, share_obs_space, act_space, device):
         self.episode_length = config["episode_length"]
         self.n_rollout_threads = config["n_rollout_threads"]
@@ -78,8 +79,7 @@ class SeparatedReplayBuffer(object):
         if self._use_proper_time_limits or not self._use_gae:
             raise NotImplementedError("only use_gae=True, use_proper_time_limits=False is accelerated (the shipped configs)")
         dev = torch.device(self.device)
-        if dev.type != "cuda":
-            raise _lib.MmsError("SeparatedReplayBuffer.compute_returns runs on the HIP device only (no CPU fallback)")
+        L, idx, stream = _lib.for_device(dev)               # "cuda": the HIP build; "cpu": the CPU build (the caller's explicit choice)
         self.value_preds[-1] = next_value
         use_norm = 1 if (self._use_popart or self._use_valuenorm) else 0
         if use_norm:
@@ -89,8 +89,6 @@ class SeparatedReplayBuffer(object):
         else:
             mean = var = self.rewards          # unused
         T, N = self.episode_length, self.n_rollout_threads
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
         p = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.check(_lib.lib().mms_gae_marl(idx, p(self.rewards), p(self.value_preds), p(self.masks), p(self.returns), T, N,
-                                           float(self.gamma), float(self.gae_lambda), use_norm, p(mean), p(var),
-                                           current_stream_ptr(dev)), None, "mms_gae_marl")
+        _lib.check(L.mms_gae_marl(idx, p(self.rewards), p(self.value_preds), p(self.masks), p(self.returns), T, N,
+                                  float(self.gamma), float(self.gae_lambda), use_norm, p(mean), p(var), stream), None, "mms_gae_marl", L)

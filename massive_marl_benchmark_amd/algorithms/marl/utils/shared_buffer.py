@@ -21,10 +21,10 @@ import ctypes
 import torch
 
 from .... import _lib
-from ....engine import current_stream_ptr
+from .generators import MinibatchGenerators
 
 
-class _AgentView:
+class _AgentView(MinibatchGenerators):
     """Per-agent facade with the SeparatedReplayBuffer attribute names (separated_buffer.py:36-60)."""
 
     def __init__(self, parent, k):
@@ -164,10 +164,9 @@ class SharedRolloutBuffers:
         self.env.task.engine.bind_obs_out(self.share_obs[slot])
 
     def _views(self, slot):
-        e = self.env.task.engine
-        _lib.check(_lib.lib().mms_marl_views(e.device_index, ctypes.c_void_p(self.share_obs[slot].data_ptr()),
-                                             ctypes.c_void_p(self.obs[slot].data_ptr()), self.N, self.A, self.env.num_ant_obs,
-                                             self.env.shared_obs, current_stream_ptr(e.device)), None, "mms_marl_views")
+        L, idx, stream = _lib.for_device(self.env.task.engine.device)
+        _lib.check(L.mms_marl_views(idx, ctypes.c_void_p(self.share_obs[slot].data_ptr()), ctypes.c_void_p(self.obs[slot].data_ptr()),
+                                    self.N, self.A, self.env.num_ant_obs, self.env.shared_obs, stream), None, "mms_marl_views", L)
 
     def insert_step(self, rewards, dones, values, actions, action_log_probs):
         """Runner.insert for all agents (runner.py:222-255) without the per-agent copies of shared data.
@@ -211,8 +210,8 @@ class SharedRolloutBuffers:
             var = torch.stack([v.reshape(()) for _, v in mv]).to(dev).float().contiguous()
         else:
             mean = var = self.rewards
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        L, idx, stream = _lib.for_device(dev)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.check(_lib.lib().mms_gae_marl_agents(idx, p(self.rewards), p(self.value_preds), p(self.masks), p(self.returns), self.T,
-                                                  self.N, self.A, float(self.gamma), float(self.gae_lambda), 1 if self._use_norm else 0,
-                                                  p(mean), p(var), current_stream_ptr(dev)), None, "mms_gae_marl_agents")
+        _lib.check(L.mms_gae_marl_agents(idx, p(self.rewards), p(self.value_preds), p(self.masks), p(self.returns), self.T, self.N, self.A,
+                                         float(self.gamma), float(self.gae_lambda), 1 if self._use_norm else 0, p(mean), p(var), stream),
+                   None, "mms_gae_marl_agents", L)

@@ -40,15 +40,14 @@ def fused_mlp_forward(seq, x):
             return None
         if isinstance(act, nn.ELU) and act.alpha != 1.0:
             return None
-    L = _lib.lib()
     dev = x.device
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    L, idx, stream = _lib.for_device(dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     h = x.contiguous()
     for lin, act in pairs:
         y = torch.empty(h.shape[0], lin.out_features, device=dev)
         _lib.check(L.mms_linear2_act(idx, h.shape[0], lin.out_features, lin.in_features, p(h), p(lin.weight.detach()), p(lin.bias.detach()), p(y),
-                                     None, None, None, None, _ACT_CODES[type(act)], current_stream_ptr(dev)), None, "mms_linear2_act")
+                                     None, None, None, None, _ACT_CODES[type(act)], stream), None, "mms_linear2_act", L)
         h = y
     return h
 

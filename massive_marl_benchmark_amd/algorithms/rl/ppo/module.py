@@ -18,7 +18,6 @@ import torch
 import torch.nn as nn
 
 from .... import _lib
-from ....engine import current_stream_ptr
 
 
 def get_activation(act_name):
@@ -58,7 +57,7 @@ class ActorCritic(nn.Module):
         self._bound = None
         self._side = None       # second HIP stream: the critic MLP runs beside the actor MLP (see act)
         self._trunk = None
-        self._bf16_pack = None
+        self._act_bufs = None
 
     @staticmethod
     def init_weights(sequential, scales):
@@ -73,10 +72,6 @@ class ActorCritic(nn.Module):
     # the sampling kernel (no gain next to the critic's GEMMs: 371.8 us against 365.5 us, profiles/r01_v8_rollout_ab.txt).
     fuse_layers = True
     fuse_head = True
-    # the same for a bf16 copy of the module (mms_linear2_act_bf16).  Opt-in: 102 us for the three hidden layers of both networks
-    # (~480 TFLOP/s on the 1024-wide layer) against ~85 us of library bf16 GEMMs + the ELU / cast passes; inside the rollout the
-    # bf16-policy series measured 22.1 M env-steps/s with it and 23.1 M without (profiles/r01_v11_linear_probe.txt)
-    fuse_layers_bf16 = False
     two_streams = True      # critic beside the actor on a second stream
     defer_value = False     # opt-in: `act` returns before the critic has finished; the owner calls join() before reading values
 
@@ -108,52 +103,18 @@ class ActorCritic(nn.Module):
             return None
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         dev = x.device
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        L, idx, stream = _lib.for_device(dev)
         ha, hc = x.contiguous(), critic_in.contiguous()
         M = ha.shape[0]
-        for la, lc in zip(a_lin[:-1], c_lin[:-1]):
-            ya, yc = torch.empty(M, la.out_features, device=dev), torch.empty(M, la.out_features, device=dev)
-            _lib.check(_lib.lib().mms_linear2_act(idx, M, la.out_features, la.in_features, p(ha), p(la.weight.detach()), p(la.bias.detach()), p(ya),
-                                                  p(hc), p(lc.weight.detach()), p(lc.bias.detach()), p(yc), 1, current_stream_ptr(dev)),
-                       None, "mms_linear2_act")
-            ha, hc = ya, yc
-        return ha, hc
-
-    def _fused_hidden_bf16(self, obs_f32, critic_in_f32):
-        """bf16 copy of the module: hidden layers of both networks through mms_linear2_act_bf16 (bf16 MFMA, fp32 accumulation,
-        bias + ELU fused, bf16 out).  The first layer reads the fp32 observation rows directly; its weight is padded once to a
-        multiple of 64 columns.  Returns (actor hidden, critic hidden) in bf16, or None when the shapes do not qualify."""
-        a_lin = [m for m in self.actor if isinstance(m, nn.Linear)]
-        c_lin = [m for m in self.critic if isinstance(m, nn.Linear)]
-        acts = [m for m in list(self.actor) + list(self.critic) if not isinstance(m, nn.Linear)]
-        if (len(a_lin) != len(c_lin) or len(a_lin) < 2 or not all(isinstance(m, nn.ELU) and m.alpha == 1.0 for m in acts)
-                or any(la.weight.shape != lc.weight.shape for la, lc in zip(a_lin[:-1], c_lin[:-1]))
-                or a_lin[0].in_features % 4 or any(l.in_features % 64 for l in a_lin[1:-1])):
-            return None
-        dev = obs_f32.device
-        key = tuple(l.weight._version for l in a_lin[:-1] + c_lin[:-1])
-        if self._bf16_pack is None or self._bf16_pack[0] != key:
-            packed = []
-            for lin in a_lin[:-1] + c_lin[:-1]:
-                K = lin.in_features
-                ldw = (K + 63) // 64 * 64
-                w = torch.zeros(lin.out_features, ldw, device=dev, dtype=torch.bfloat16)
-                w[:, :K] = lin.weight.detach().to(torch.bfloat16)
-                packed.append((w, lin.bias.detach().float().contiguous(), ldw))
-            self._bf16_pack = (key, packed)
-        packed = self._bf16_pack[1]
-        n = len(a_lin) - 1
-        p = lambda t: ctypes.c_void_p(t.data_ptr())
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        ha, hc = obs_f32.contiguous(), critic_in_f32.contiguous()
-        M = ha.shape[0]
-        for i in range(n):
-            (wa, ba, ldw), (wc, bc, _) = packed[i], packed[n + i]
-            N, K = wa.shape[0], a_lin[i].in_features
-            ya = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-            yc = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-            _lib.check(_lib.lib().mms_linear2_act_bf16(idx, M, N, K, ldw, 1 if i == 0 else 0, p(ha), p(wa), p(ba), p(ya), p(hc), p(wc), p(bc),
-                                                       p(yc), 1, current_stream_ptr(dev)), None, "mms_linear2_act_bf16")
+        # activations of the hidden layers: allocated once per (batch, device) and reused -- the eager path would otherwise take an
+        # allocator round trip per layer and call
+        key = (M, str(dev))
+        if self._act_bufs is None or self._act_bufs[0] != key:
+            self._act_bufs = (key, [(torch.empty(M, la.out_features, device=dev), torch.empty(M, la.out_features, device=dev))
+                                    for la in a_lin[:-1]])
+        for (la, lc), (ya, yc) in zip(zip(a_lin[:-1], c_lin[:-1]), self._act_bufs[1]):
+            _lib.check(L.mms_linear2_act(idx, M, la.out_features, la.in_features, p(ha), p(la.weight.detach()), p(la.bias.detach()), p(ya),
+                                         p(hc), p(lc.weight.detach()), p(lc.bias.detach()), p(yc), 1, stream), None, "mms_linear2_act", L)
             ha, hc = ya, yc
         return ha, hc
 
@@ -175,8 +136,7 @@ class ActorCritic(nn.Module):
         src = mean if mean is not None else hidden
         N, A = src.shape[0], self.log_std.shape[0]
         dev = src.device
-        if dev.type != "cuda":
-            raise _lib.MmsError("ActorCritic.act samples on the HIP device only (no CPU fallback)")
+        L, idx, stream = _lib.for_device(dev)              # "cuda": the HIP build; "cpu": the CPU build (the module lives where its owner put it)
         if self._counters is None or self._counters.numel() != N or self._counters.device != dev:
             self._counters = torch.zeros(N, dtype=torch.int64, device=dev)
         storage, actions_out = self._bound if self._bound is not None else (None, None)
@@ -189,14 +149,12 @@ class ActorCritic(nn.Module):
             logp, val = torch.empty(N, 1, device=dev), torch.empty(N, 1, device=dev)
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         value = None if value is None else value.contiguous().float()
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
         log_std = self.log_std.detach().float().contiguous()
-        L = _lib.lib()
         if mean is not None:
             mean = mean.contiguous().float()
             _lib.check(L.mms_ppo_act(idx, p(mean), p(value), p(log_std), self.seed, p(self._counters), self.row_offset, 1,
-                                     p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A, current_stream_ptr(dev)),
-                       None, "mms_ppo_act")
+                                     p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A, stream),
+                       None, "mms_ppo_act", L)
         else:
             last = self.actor[-1]
             hidden = hidden.contiguous()
@@ -205,19 +163,14 @@ class ActorCritic(nn.Module):
             _lib.check(L.mms_ppo_heads_act(idx, p(hidden), p(last.weight.detach()), p(last.bias.detach()), last.in_features, p(value), p(vh),
                                            None if vh is None else p(vlast.weight.detach()), None if vh is None else p(vlast.bias.detach()),
                                            0 if vh is None else vlast.in_features, p(log_std), self.seed, p(self._counters), self.row_offset, 1,
-                                           p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A, current_stream_ptr(dev)),
-                       None, "mms_ppo_heads_act")
+                                           p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A, stream),
+                       None, "mms_ppo_heads_act", L)
         return act, logp.view(-1), val, mu, sigma
 
     def act(self, observations, states):
         with torch.no_grad():
             dtype = self.log_std.dtype                              # a bf16 copy of the module takes fp32 observations
             critic_in = (states if self.asymmetric else observations).to(dtype)
-            if self.fuse_layers_bf16 and observations.is_cuda and dtype == torch.bfloat16 and observations.dtype == torch.float32:
-                hidden = self._fused_hidden_bf16(observations, states if self.asymmetric else observations)
-                if hidden is not None:
-                    ha, hc = hidden
-                    return self._sample(self.actor[-1](ha), self.critic[-1](hc))
             if self.fuse_layers and observations.is_cuda and dtype == torch.float32 and not self.defer_value:
                 hidden = self._fused_hidden(observations, critic_in)
                 if hidden is not None:

@@ -11,7 +11,6 @@ import torch
 from torch.utils.data.sampler import BatchSampler, SequentialSampler, SubsetRandomSampler
 
 from .... import _lib
-from ....engine import current_stream_ptr
 
 
 class RolloutStorage:
@@ -67,19 +66,15 @@ class RolloutStorage:
     def compute_returns(self, last_values, gamma, lam):
         """storage.py:51-65: reverse GAE scan, then advantages = (ret - V - mean) / (std + 1e-8)."""
         dev = torch.device(self.device)
-        if dev.type != "cuda":
-            raise _lib.MmsError("RolloutStorage.compute_returns runs on the HIP device only (no CPU fallback)")
+        L, idx, stream = _lib.for_device(dev)               # "cuda": the HIP build; "cpu": the CPU build (the caller's explicit choice)
         T, N = self.num_transitions_per_env, self.num_envs
-        L = _lib.lib()
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        stream = current_stream_ptr(dev)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         last_values = last_values.contiguous().view(-1).float()
         _lib.check(L.mms_gae_ppo(idx, p(self.rewards), p(self.dones), p(self.values), p(last_values), p(self.returns),
-                                 p(self.advantages), p(self._stats), T, N, float(gamma), float(lam), stream), None, "mms_gae_ppo")
+                                 p(self.advantages), p(self._stats), T, N, float(gamma), float(lam), stream), None, "mms_gae_ppo", L)
         if self.process_group is not None:
             torch.distributed.all_reduce(self._stats, group=self.process_group)   # sum, sum of squares, count
-        _lib.check(L.mms_adv_normalize(idx, p(self.advantages), p(self._stats), T * N, stream), None, "mms_adv_normalize")
+        _lib.check(L.mms_adv_normalize(idx, p(self.advantages), p(self._stats), T * N, stream), None, "mms_adv_normalize", L)
 
     def get_statistics(self):
         """(mean trajectory length, mean reward) of the stored rollout, storage.py:67-72: trajectories are cut at every done

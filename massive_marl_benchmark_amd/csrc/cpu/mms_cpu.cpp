@@ -1,0 +1,393 @@
+// mms_cpu.cpp -- the CPU build of the engine behind the SAME C ABI (include/mms.h): lib/libmms_cpu.so.
+//
+// What it is for: the reference selects a CPU pipeline with `--sim_device cpu` (agents/tasks/agent_base/base_task.py:27-32,
+// vec_task.py:126-139; BASELINE configs[0] "OneAnt num_envs=64 ... sim_device=cpu -- plumbing, no GPU").  This library is that
+// pipeline: explicit and opt-in (mms_config.device = -1, `device_type="cpu"` in the task constructors), NEVER a fallback -- the
+// HIP library still fails without a GPU and nothing selects this one automatically.
+// What it is built from: the per-lane functions of the HIP step kernels (../mms_lane.h through lane_step.h) and the per-column
+// functions of the rollout kernels (../rollout_lane.h) -- the product's own math, compiled for the host, OpenMP over envs.
+// It shares no source with the oracle (oracle/mms_oracle.c), which stays the checker.
+// Streams: the `hip_stream` arguments are ignored; every call has completed when it returns.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../../include/mms.h"
+#include "../rollout_lane.h"
+#include "lane_step.h"
+
+#define MMS_API extern "C" __attribute__((visibility("default")))
+
+struct mms_buffer {
+    const char* name;
+    void* ptr;
+    int64_t shape[4];
+    int ndim;
+    int dtype;
+    size_t bytes;
+    int64_t row_bytes;
+};
+
+struct mms_engine {
+    mms_config cfg;
+    int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
+    float* obs_out = nullptr;
+    int write_raw_obs = 1, write_clipped_obs = 1, dr_enabled = 0;
+    float* rew_out = nullptr;
+    uint8_t* done_out = nullptr;
+    std::vector<mms_buffer> bufs;
+    std::string err;
+};
+
+static std::string g_error;
+static size_t dtype_size(int dt) { return dt == MMS_F32 ? 4 : dt == MMS_I64 ? 8 : dt == MMS_I32 ? 4 : 1; }
+static int fail(mms_engine* e, const std::string& msg) {
+    if (e) e->err = msg; else g_error = msg;
+    return 1;
+}
+static mms_buffer* find(mms_engine* e, const char* name) {
+    for (auto& b : e->bufs)
+        if (!strcmp(b.name, name)) return &b;
+    return nullptr;
+}
+static void add_buffer(mms_engine* e, const char* name, int dtype, std::initializer_list<int64_t> shape) {
+    mms_buffer b{};
+    b.name = name;
+    b.dtype = dtype;
+    b.ndim = (int)shape.size();
+    size_t n = 1;
+    int i = 0;
+    for (int64_t s : shape) { b.shape[i++] = s; n *= (size_t)s; }
+    b.bytes = n * dtype_size(dtype);
+    b.row_bytes = (int64_t)(b.bytes / (size_t)e->cfg.num_envs);
+    b.ptr = calloc(b.bytes ? b.bytes : 16, 1);
+    e->bufs.push_back(b);
+}
+template <typename T> static T* buf(mms_engine* e, const char* name) { return (T*)find(e, name)->ptr; }
+
+MMS_API int mms_abi_version(void) { return MMS_ABI_VERSION; }
+MMS_API const char* mms_last_error(mms_handle h) { return h ? h->err.c_str() : g_error.c_str(); }
+
+MMS_API int mms_destroy(mms_handle h) {
+    if (!h) return 0;
+    for (auto& b : h->bufs) free(b.ptr);
+    delete h;
+    return 0;
+}
+
+MMS_API int mms_create(const mms_config* cfg, mms_handle* out) {
+    if (!cfg || !out) return fail(nullptr, "mms_create: null argument");
+    if (cfg->abi_version != MMS_ABI_VERSION) return fail(nullptr, "mms_create: ABI version mismatch");
+    if (cfg->device != -1) return fail(nullptr, "mms_create: this is the CPU build of the engine (libmms_cpu.so); device must be -1");
+    if (cfg->num_envs <= 0 || cfg->num_agents <= 0) return fail(nullptr, "mms_create: num_envs and num_agents must be positive");
+    if (cfg->task == MMS_TASK_MULTI_INGENUITY && cfg->num_agents != 4) return fail(nullptr, "mms_create: MultiIngenuity has 4 helicopters per env");
+    if (cfg->task == MMS_TASK_ONE_ANT && cfg->num_agents != 1) return fail(nullptr, "mms_create: OneAnt has one ant per env");
+    mms_engine* e = new mms_engine();
+    e->cfg = *cfg;
+    const int N = cfg->num_envs, A = cfg->num_agents;
+    if (cfg->task == MMS_TASK_TEN_ANT) { e->actors = A + 1; e->dofs = 8 * A; e->num_actions = 8 * A; e->obs_dim = 38 * A + 8; e->prev_dim = 4 * A + 2; }
+    else if (cfg->task == MMS_TASK_ONE_ANT) { e->actors = 2; e->dofs = 8; e->num_actions = 8; e->obs_dim = 60; e->prev_dim = 6; }
+    else if (cfg->task == MMS_TASK_MULTI_INGENUITY) { e->actors = A; e->dofs = 4 * A; e->num_actions = 6 * A; e->obs_dim = 13 * A; e->prev_dim = 3 * A; }
+    else { delete e; return fail(nullptr, "mms_create: unknown task"); }
+    add_buffer(e, "actions", MMS_F32, {N, e->num_actions});
+    add_buffer(e, "obs", MMS_F32, {N, e->obs_dim});
+    add_buffer(e, "obs_clipped", MMS_F32, {N, e->obs_dim});
+    add_buffer(e, "rew", MMS_F32, {N});
+    add_buffer(e, "reset", MMS_I64, {N});
+    add_buffer(e, "progress", MMS_I64, {N});
+    add_buffer(e, "reset_count", MMS_I64, {N});
+    add_buffer(e, "root_states", MMS_F32, {(int64_t)N * e->actors, 13});
+    add_buffer(e, "initial_root_states", MMS_F32, {(int64_t)N * e->actors, 13});
+    add_buffer(e, "dof_state", MMS_F32, {(int64_t)N * e->dofs, 2});
+    add_buffer(e, "env_origin", MMS_F32, {N, 3});
+    add_buffer(e, "prev", MMS_F32, {N, e->prev_dim});
+    add_buffer(e, "reset_noise", MMS_F32, {N, 16});
+    add_buffer(e, "foot_sensors", MMS_F32, {(int64_t)N * A, 24});
+    add_buffer(e, "dr_params", MMS_F32, {(int64_t)N * A, MMS_DR_FLOATS});
+    // construction-time scene: the same as the HIP build's mms_create (ten_ant.py:339-358,494-495; one_ant.py:234;
+    // multi_ingenuity.py:157-164), env grid per SURVEY.md B.2
+    float* init = buf<float>(e, "initial_root_states");
+    float* origin = buf<float>(e, "env_origin");
+    float* prev = buf<float>(e, "prev");
+    int64_t npr = (int64_t)sqrt((double)cfg->total_envs);
+    if (npr < 1) npr = 1;
+    for (int i = 0; i < N; i++) {
+        int64_t gi = cfg->env_offset + i;
+        origin[3 * (size_t)i + 0] = (float)(gi % npr) * 2.f * cfg->env_spacing;
+        origin[3 * (size_t)i + 1] = (float)(gi / npr) * 2.f * cfg->env_spacing;
+        float* r = init + (size_t)i * e->actors * 13;
+        for (int k = 0; k < e->actors; k++) r[13 * k + 6] = 1.f;
+        if (cfg->task != MMS_TASK_MULTI_INGENUITY) {
+            for (int k = 0; k < A; k++) {
+                float off = (A == 1) ? 0.f : (1.5f + 3.f * (float)(k / 2)) * ((k % 2 == 0) ? -1.f : 1.f);
+                r[13 * k + 0] = cfg->ant_start_x; r[13 * k + 1] = off; r[13 * k + 2] = cfg->ant_start_z;
+            }
+            for (int j = 0; j < 3; j++) r[13 * A + j] = cfg->box_start[j];
+        } else {
+            static const float hy[4] = {2.f, -2.f, 6.f, -6.f};
+            for (int k = 0; k < A; k++) { r[13 * k + 0] = 0.f; r[13 * k + 1] = hy[k % 4]; r[13 * k + 2] = 1.f; }
+        }
+        // caches start as the construction-time poses in the global frame (ten_ant.py:870-882, one_ant.py:410-411)
+        const float* o = origin + 3 * (size_t)i;
+        float* pv = prev + (size_t)i * e->prev_dim;
+        if (cfg->task == MMS_TASK_TEN_ANT) {
+            const float* b = r + 13 * A;
+            float bx = b[0] + o[0], by = b[1] + o[1];
+            float ang = atanf((2.f * b[6] * b[5]) / (1.f - 2.f * b[5] * b[5]));
+            float sv = sinf(ang), cv = -cosf(ang);
+            for (int k = 0; k < A; k++) {
+                pv[2 * k] = r[13 * k] + o[0]; pv[2 * k + 1] = r[13 * k + 1] + o[1];
+                float off = 1.5f + 3.0f * (float)(k / 2);
+                pv[2 * A + 2 * k] = (k % 2 == 0) ? bx + off * sv : bx - off * sv;
+                pv[2 * A + 2 * k + 1] = (k % 2 == 0) ? by + off * cv : by - off * cv;
+            }
+            pv[4 * A] = bx; pv[4 * A + 1] = by;
+        } else if (cfg->task == MMS_TASK_ONE_ANT) {
+            pv[0] = r[0] + o[0]; pv[1] = r[1] + o[1]; pv[2] = r[13] + o[0]; pv[3] = r[14] + o[1];
+            pv[4] = -4.f / cfg->dt; pv[5] = -4.f / cfg->dt;
+        }
+    }
+    memcpy(buf<float>(e, "root_states"), init, find(e, "root_states")->bytes);
+    int64_t* reset = buf<int64_t>(e, "reset");
+    for (int i = 0; i < N; i++) reset[i] = 1;                                     // base_task.py:62-63
+    float* dr = buf<float>(e, "dr_params");
+    for (size_t k = 0; k < (size_t)N * A; k++)
+        for (int j = 0; j < 17; j++) dr[k * MMS_DR_FLOATS + j] = 1.f;            // nominal: scales 1, limit offsets 0
+    *out = e;
+    return 0;
+}
+
+MMS_API int mms_get_tensor(mms_handle h, const char* name, mms_tensor* out) {
+    if (!h || !name || !out) return fail(h, "mms_get_tensor: null argument");
+    mms_buffer* b = find(h, name);
+    if (!b) return fail(h, std::string("mms_get_tensor: unknown buffer '") + name + "'");
+    memset(out, 0, sizeof(*out));
+    out->ptr = b->ptr;
+    for (int i = 0; i < b->ndim; i++) out->shape[i] = b->shape[i];
+    out->ndim = b->ndim;
+    out->dtype = b->dtype;
+    out->device = -1;
+    return 0;
+}
+
+static int do_step(mms_handle h, int physics) {
+    if (!h) return fail(nullptr, "mms_step: null handle");
+    mms::HostBufs b{buf<float>(h, "actions"), h->write_raw_obs ? buf<float>(h, "obs") : nullptr,
+                    h->write_clipped_obs ? buf<float>(h, "obs_clipped") : nullptr, buf<float>(h, "rew"), buf<int64_t>(h, "reset"),
+                    buf<int64_t>(h, "progress"), buf<float>(h, "root_states"), buf<float>(h, "initial_root_states"),
+                    buf<float>(h, "dof_state"), buf<float>(h, "env_origin"), buf<float>(h, "prev"), buf<float>(h, "reset_noise"),
+                    buf<float>(h, "foot_sensors"), buf<int64_t>(h, "reset_count"), h->dr_enabled ? buf<float>(h, "dr_params") : nullptr};
+    b.obs_out = h->obs_out; b.rew_out = h->rew_out; b.done_out = h->done_out;
+    const mms_config* C = &h->cfg;
+#pragma omp parallel for schedule(static)
+    for (int env = 0; env < C->num_envs; env++) {
+        if (C->task == MMS_TASK_MULTI_INGENUITY) mms::host_heli_env(C, b, env, physics);
+        else mms::host_ant_env(C, b, env, physics, h->obs_dim, h->prev_dim);
+    }
+    return 0;
+}
+MMS_API int mms_step(mms_handle h, void*) { return do_step(h, 1); }
+MMS_API int mms_post_step(mms_handle h, void*) { return do_step(h, 0); }
+
+MMS_API int mms_reset_all(mms_handle h, void*) {
+    if (!h) return fail(nullptr, "mms_reset_all: null handle");
+    int64_t* r = buf<int64_t>(h, "reset");
+    for (int i = 0; i < h->cfg.num_envs; i++) r[i] = 1;
+    return 0;
+}
+
+MMS_API int mms_set_state(mms_handle h, const char* name, const void* src, int, const int64_t* env_ids, int64_t n, void*) {
+    if (!h || !name || !src) return fail(h, "mms_set_state: null argument");
+    mms_buffer* b = find(h, name);
+    if (!b) return fail(h, std::string("mms_set_state: unknown buffer '") + name + "'");
+    if (!env_ids) { memcpy(b->ptr, src, b->bytes); return 0; }
+    for (int64_t i = 0; i < n; i++) {
+        if (env_ids[i] < 0 || env_ids[i] >= h->cfg.num_envs) return fail(h, "mms_set_state: env id out of range");
+        memcpy((char*)b->ptr + env_ids[i] * b->row_bytes, (const char*)src + i * b->row_bytes, (size_t)b->row_bytes);
+    }
+    return 0;
+}
+
+MMS_API int mms_bind_obs_out(mms_handle h, void* dst) {
+    if (!h) return fail(nullptr, "mms_bind_obs_out: null handle");
+    h->obs_out = (float*)dst;
+    return 0;
+}
+MMS_API int mms_set_dr(mms_handle h, int32_t enable) {
+    if (!h) return fail(nullptr, "mms_set_dr: null handle");
+    if (enable && h->cfg.task == MMS_TASK_MULTI_INGENUITY) return fail(h, "mms_set_dr: the helicopter task has no randomised physical parameters");
+    h->dr_enabled = enable != 0;
+    return 0;
+}
+MMS_API int mms_set_obs_outputs(mms_handle h, int32_t raw, int32_t clipped) {
+    if (!h) return fail(nullptr, "mms_set_obs_outputs: null handle");
+    h->write_raw_obs = raw != 0;
+    h->write_clipped_obs = clipped != 0;
+    return 0;
+}
+MMS_API int mms_bind_rollout_out(mms_handle h, float* rew_out, uint8_t* done_out) {
+    if (!h) return fail(nullptr, "mms_bind_rollout_out: null handle");
+    h->rew_out = rew_out;
+    h->done_out = done_out;
+    return 0;
+}
+
+// ---- rollout functions (device argument: -1) ---------------------------------------------------------------------------------
+static int cpu_only(int device) {
+    if (device != -1) { g_error = "libmms_cpu.so: device must be -1"; return 1; }
+    return 0;
+}
+MMS_API int mms_marl_views(int device, const float* obs_clipped, float* obs_all, int64_t n, int32_t agents, int32_t per_agent, int32_t shared, void*) {
+    if (cpu_only(device)) return 1;
+    const int64_t total = n * agents * (per_agent + shared);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < total; i++) obs_all[i] = obs_clipped[mms::marl_view_source(i, agents, per_agent, shared)];
+    return 0;
+}
+MMS_API int mms_gae_ppo(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
+                        float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam, void*) {
+    if (cpu_only(device)) return 1;
+    double sum = 0.0, sq = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : sum, sq)
+    for (int64_t i = 0; i < N; i++) mms::gae_ppo_column(rewards, dones, values, last_values, returns, advantages, T, N, i, gamma, lam, sum, sq);
+    stats[0] = sum; stats[1] = sq; stats[2] = (double)T * (double)N;
+    return 0;
+}
+MMS_API int mms_adv_normalize(int device, float* advantages, const double* stats, int64_t count, void*) {
+    if (cpu_only(device)) return 1;
+    float fm, inv;
+    mms::adv_norm_params(stats, fm, inv);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < count; i++) advantages[i] = (advantages[i] - fm) * inv;
+    return 0;
+}
+MMS_API int mms_gae_marl(int device, const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int64_t N,
+                         float gamma, float lam, int32_t use_norm, const float* norm_mean, const float* norm_var, void*) {
+    if (cpu_only(device)) return 1;
+    const float mean = use_norm ? norm_mean[0] : 0.f, var = use_norm ? norm_var[0] : 1.f;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++) mms::gae_marl_column(rewards, value_preds, masks, returns, T, N, N, i, i, gamma, lam, use_norm, mean, var);
+    return 0;
+}
+MMS_API int mms_gae_marl_agents(int device, const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T,
+                                int64_t N, int32_t A, float gamma, float lam, int32_t use_norm, const float* norm_mean, const float* norm_var, void*) {
+    if (cpu_only(device)) return 1;
+    const int64_t cols = N * A;
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < cols; c++) {
+        const int64_t i = c / A;
+        const int k = (int)(c - i * A);
+        mms::gae_marl_column(rewards, value_preds, masks, returns, T, N, cols, c, i, gamma, lam, use_norm, use_norm ? norm_mean[k] : 0.f,
+                             use_norm ? norm_var[k] : 1.f);
+    }
+    return 0;
+}
+
+// one row of ActorCritic.act's sampling tail + the add_transitions stores (module.py:73-87, storage.py:33-47)
+static void sample_row(const float* mean_row, float value_now, bool have_value, const float* log_std, uint64_t seed, int64_t* counters,
+                       int64_t row_offset, int ref_scale, float* actions_out, float* act_slot, float* logp_slot, float* value_slot,
+                       float* mu_slot, float* sigma_slot, int64_t row, int A) {
+    const int64_t c = counters[row];
+    // the wave's butterfly sum of the GPU kernel (lane j holds actions j, j + 64; xor 32, 16, ... 1), reproduced on 64 slots
+    float lane[64];
+    for (int l = 0; l < 64; l++) lane[l] = 0.f;
+    for (int j = 0; j < A; j++) {
+        float term;
+        const float act = mms::ppo_sample_one(mean_row[j], log_std[j], seed, (uint64_t)(row_offset + row), (uint64_t)c, (uint32_t)j, ref_scale, term);
+        lane[j & 63] += term;
+        if (actions_out) actions_out[row * A + j] = act;
+        if (act_slot) act_slot[row * A + j] = act;
+        if (mu_slot) mu_slot[row * A + j] = mean_row[j];
+        if (sigma_slot) sigma_slot[row * A + j] = log_std[j];
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        float nxt[64];
+        for (int l = 0; l < 64; l++) nxt[l] = lane[l] + lane[l ^ m];
+        memcpy(lane, nxt, sizeof(lane));
+    }
+    if (logp_slot) logp_slot[row] = lane[0];
+    if (value_slot && have_value) value_slot[row] = value_now;
+    counters[row] = c + 1;
+}
+MMS_API int mms_ppo_act(int device, const float* mean, const float* value, const float* log_std, uint64_t seed, int64_t* counters,
+                        int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot, float* logp_slot, float* value_slot,
+                        float* mu_slot, float* sigma_slot, int64_t N, int32_t A, void*) {
+    if (cpu_only(device)) return 1;
+    if (!mean || !log_std || !counters || N < 0 || A <= 0 || A > 128) { g_error = "mms_ppo_act: bad arguments (A must be in 1..128)"; return 1; }
+#pragma omp parallel for schedule(static)
+    for (int64_t row = 0; row < N; row++)
+        sample_row(mean + row * A, value ? value[row] : 0.f, value != nullptr, log_std, seed, counters, row_offset, reference_scale, actions_out,
+                   act_slot, logp_slot, value_slot, mu_slot, sigma_slot, row, A);
+    return 0;
+}
+MMS_API int mms_ppo_heads_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H, const float* value,
+                              const float* vhidden, const float* vweight, const float* vbias, int32_t VH, const float* log_std, uint64_t seed,
+                              int64_t* counters, int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
+                              float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N, int32_t A, void*) {
+    if (cpu_only(device)) return 1;
+    if (!hidden || !weight || !bias || !log_std || !counters || N < 0 || A <= 0 || A > 128 || H <= 0 || (H % 64) != 0) {
+        g_error = "mms_ppo_heads_act: bad arguments (A must be in 1..128, H a positive multiple of 64)";
+        return 1;
+    }
+    if (vhidden && (!vweight || !vbias || VH <= 0 || (VH % 4) != 0)) {
+        g_error = "mms_ppo_heads_act: the value head needs weight, bias and a hidden width that is a multiple of 4";
+        return 1;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t row = 0; row < N; row++) {
+        float mean[128];
+        for (int j = 0; j < A; j++) {
+            float s = 0.f;
+            for (int k = 0; k < H; k++) s = fmaf(hidden[row * (int64_t)H + k], weight[(int64_t)j * H + k], s);
+            mean[j] = s + bias[j];
+        }
+        float v = value ? value[row] : 0.f;
+        if (vhidden) {
+            float s = 0.f;
+            for (int k = 0; k < VH; k++) s = fmaf(vhidden[row * (int64_t)VH + k], vweight[k], s);
+            v = s + vbias[0];
+        }
+        sample_row(mean, v, vhidden != nullptr || value != nullptr, log_std, seed, counters, row_offset, reference_scale, actions_out, act_slot,
+                   logp_slot, value_slot, mu_slot, sigma_slot, row, A);
+    }
+    return 0;
+}
+static float act_fn(float v, int act) {
+    if (act == 1) return (v > 0.f) ? v : (expf(v) - 1.f);
+    if (act == 2) return fmaxf(v, 0.f);
+    if (act == 3) return tanhf(v);
+    return v;
+}
+MMS_API int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const float* x0, const float* w0, const float* b0, float* y0,
+                            const float* x1, const float* w1, const float* b1, float* y1, int32_t act, void*) {
+    if (cpu_only(device)) return 1;
+    if (!x0 || !w0 || !b0 || !y0 || M < 0 || N <= 0 || K <= 0 || (K % 4) != 0 || act < 0 || act > 3) {
+        g_error = "mms_linear2_act: bad arguments (K must be a positive multiple of 4, act 0..3)";
+        return 1;
+    }
+    const bool two = x1 || w1 || b1 || y1;
+    if (two && !(x1 && w1 && b1 && y1)) { g_error = "mms_linear2_act: the second problem needs all four pointers"; return 1; }
+    const float* xs[2] = {x0, x1};
+    const float* ws[2] = {w0, w1};
+    const float* bs[2] = {b0, b1};
+    float* ys[2] = {y0, y1};
+    for (int g = 0; g < (two ? 2 : 1); g++) {
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < M; m++)
+            for (int n = 0; n < N; n++) {
+                float s = 0.f;
+                for (int k = 0; k < K; k++) s = fmaf(xs[g][m * K + k], ws[g][(int64_t)n * K + k], s);    // (the fp32 MFMA is an fmaf chain too)
+                ys[g][m * N + n] = act_fn(s + bs[g][n], act);
+            }
+    }
+    return 0;
+}
+MMS_API int mms_linear2_act_bf16(int, int64_t, int32_t, int32_t, int32_t, int32_t, const void*, const void*, const float*, void*, const void*,
+                                 const void*, const float*, void*, int32_t, void*) {
+    g_error = "mms_linear2_act_bf16: not part of the CPU build (the bf16 policy series is a GPU measurement)";
+    return 1;
+}

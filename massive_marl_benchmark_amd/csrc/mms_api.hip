@@ -30,15 +30,6 @@ struct LinearArgs {
     int act;
 };
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
-struct LinearBf16Args {
-    const void* x[2];
-    const __bf16* w[2];
-    const float* b[2];
-    __bf16* y[2];
-    int M, N, K, ldw;
-    int act;
-};
-hipError_t launch_linear_act_bf16(const LinearBf16Args& a, int groups, int x_is_f32, hipStream_t s);
 hipError_t launch_ppo_head_act(const float*, const float*, const float*, int, const float*, const float*, const float*, const float*, int, const float*, uint64_t,
                                int64_t*, int64_t, int, float*, float*, float*, float*, float*, float*, int64_t, int, hipStream_t);
 }  // namespace mms
@@ -68,6 +59,20 @@ struct mms_engine {
 };
 
 static std::string g_create_error;
+
+// Every entry point that touches the GPU runs on ITS device (the engine's, or the `device` argument) and leaves the caller's
+// current device as it found it: two engines in one process, or a torch current device other than the engine's, must not make a
+// launch pick another device's stream or caches, and torch allocations after a call must not move GPU.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) { err = hipSetDevice(device); changed = (err == hipSuccess); }
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
 
 static size_t dtype_size(int dt) { return dt == MMS_F32 ? 4 : dt == MMS_I64 ? 8 : dt == MMS_I32 ? 4 : 1; }
 
@@ -114,7 +119,7 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
     if (!cfg || !out) return fail(nullptr, "mms_create: null argument");
     if (cfg->abi_version != MMS_ABI_VERSION) return fail(nullptr, "mms_create: ABI version mismatch");
     if (cfg->num_envs <= 0 || cfg->num_agents <= 0) return fail(nullptr, "mms_create: num_envs and num_agents must be positive");
-    if (cfg->device < 0) return fail(nullptr, "mms_create: this engine has no CPU path; device must be a HIP ordinal >= 0");
+    if (cfg->device < 0) return fail(nullptr, "mms_create: this is the HIP build of the engine (no CPU fallback); device must be a HIP ordinal >= 0 -- device -1 is served by libmms_cpu.so, an explicit opt-in");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "mms_create: no HIP device available (no CPU fallback)");
     if (cfg->device >= ndev) return fail(nullptr, "mms_create: device ordinal out of range");
@@ -122,7 +127,8 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
     if (cfg->task == MMS_TASK_ONE_ANT && cfg->num_agents != 1) return fail(nullptr, "mms_create: OneAnt has one ant per env");
     if (cfg->task != MMS_TASK_MULTI_INGENUITY && ((4 * cfg->num_agents + 7) & ~7) + 8 > 512)
         return fail(nullptr, "mms_create: at most 126 ants per env");
-    MMS_HIP(nullptr, hipSetDevice(cfg->device));
+    DeviceGuard guard(cfg->device);
+    MMS_HIP(nullptr, guard.err);
     mms_engine* e = new mms_engine();
     e->cfg = *cfg;
     if (const char* pk = getenv("MMS_PACKING")) e->packing = atoi(pk);   // A/B switch for profiling
@@ -219,7 +225,7 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
 
 __attribute__((visibility("default"))) int mms_destroy(mms_handle h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->cfg.device);                 // teardown: nothing useful to do with an error here
+    DeviceGuard guard(h->cfg.device);                  // teardown: nothing useful to do with an error here
     (void)hipDeviceSynchronize();
     for (auto& b : h->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
@@ -273,6 +279,8 @@ static mms::StepArgs step_args(mms_handle h, int physics) {
 
 static int do_step(mms_handle h, void* stream, int physics) {
     if (!h) return fail(nullptr, "mms_step: null handle");
+    DeviceGuard guard(h->cfg.device);
+    MMS_HIP(h, guard.err);
     mms::StepArgs a = step_args(h, physics);
     MMS_HIP(h, mms::launch_step(a, h->cfg.task, (hipStream_t)stream));
     return 0;
@@ -282,6 +290,8 @@ __attribute__((visibility("default"))) int mms_post_step(mms_handle h, void* hip
 
 __attribute__((visibility("default"))) int mms_reset_all(mms_handle h, void* hip_stream) {
     if (!h) return fail(nullptr, "mms_reset_all: null handle");
+    DeviceGuard guard(h->cfg.device);
+    MMS_HIP(h, guard.err);
     std::vector<int64_t> ones((size_t)h->cfg.num_envs, 1);
     MMS_HIP(h, hipMemcpyAsync(find(h, "reset")->ptr, ones.data(), ones.size() * 8, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
     MMS_HIP(h, hipStreamSynchronize((hipStream_t)hip_stream));   // `ones` is a temporary
@@ -292,6 +302,8 @@ __attribute__((visibility("default"))) int mms_set_state(mms_handle h, const cha
     if (!h || !name || !src) return fail(h, "mms_set_state: null argument");
     mms_buffer* b = find(h, name);
     if (!b) return fail(h, std::string("mms_set_state: unknown buffer '") + name + "'");
+    DeviceGuard guard(h->cfg.device);
+    MMS_HIP(h, guard.err);
     hipStream_t s = (hipStream_t)hip_stream;
     hipMemcpyKind kind = src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     if (!env_ids) {
@@ -334,12 +346,10 @@ __attribute__((visibility("default"))) int mms_bind_rollout_out(mms_handle h, fl
     return 0;
 }
 
-static int dev_guard(int device) {
-    if (device < 0) { g_create_error = "no CPU path: device must be a HIP ordinal"; return 1; }
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return 1; }
-    return 0;
-}
+#define MMS_DEV(device)                                                                                \
+    if ((device) < 0) { g_create_error = "no CPU path in this library: device must be a HIP ordinal (the CPU build is libmms_cpu.so)"; return 1; } \
+    DeviceGuard guard_(device);                                                                        \
+    if (guard_.err != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err); return 1; }
 #define MMS_FREE(call)                                                                                 \
     do {                                                                                               \
         hipError_t err_ = (call);                                                                      \
@@ -347,24 +357,24 @@ static int dev_guard(int device) {
     } while (0)
 
 __attribute__((visibility("default"))) int mms_marl_views(int device, const float* obs_clipped, float* obs_all, int64_t n, int32_t agents, int32_t per_agent, int32_t shared, void* s) {
-    if (dev_guard(device)) return 1;
+    MMS_DEV(device)
     MMS_FREE(mms::launch_marl_views(obs_clipped, obs_all, n, agents, per_agent, shared, (hipStream_t)s));
     return 0;
 }
 __attribute__((visibility("default"))) int mms_gae_ppo(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
                 float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam, void* s) {
-    if (dev_guard(device)) return 1;
+    MMS_DEV(device)
     MMS_FREE(mms::launch_gae_ppo(rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam, (hipStream_t)s));
     return 0;
 }
 __attribute__((visibility("default"))) int mms_adv_normalize(int device, float* advantages, const double* stats, int64_t count, void* s) {
-    if (dev_guard(device)) return 1;
+    MMS_DEV(device)
     MMS_FREE(mms::launch_adv_normalize(advantages, stats, count, (hipStream_t)s));
     return 0;
 }
 __attribute__((visibility("default"))) int mms_gae_marl(int device, const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int64_t N,
                  float gamma, float lam, int32_t use_norm, const float* norm_mean, const float* norm_var, void* s) {
-    if (dev_guard(device)) return 1;
+    MMS_DEV(device)
     MMS_FREE(mms::launch_gae_marl(rewards, value_preds, masks, returns, T, N, gamma, lam, use_norm, norm_mean, norm_var, (hipStream_t)s));
     return 0;
 }
@@ -372,7 +382,7 @@ __attribute__((visibility("default"))) int mms_gae_marl(int device, const float*
 __attribute__((visibility("default"))) int mms_gae_marl_agents(int device, const float* rewards, const float* value_preds, const float* masks,
                                                                float* returns, int32_t T, int64_t N, int32_t A, float gamma, float lam,
                                                                int32_t use_norm, const float* norm_mean, const float* norm_var, void* s) {
-    if (dev_guard(device)) return 1;
+    MMS_DEV(device)
     MMS_FREE(mms::launch_gae_marl_agents(rewards, value_preds, masks, returns, T, N, A, gamma, lam, use_norm, norm_mean, norm_var, (hipStream_t)s));
     return 0;
 }
@@ -381,20 +391,11 @@ __attribute__((visibility("default"))) int mms_ppo_act(int device, const float* 
                                                        int64_t* counters, int64_t row_offset, int32_t reference_scale, float* actions_out,
                                                        float* act_slot, float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot,
                                                        int64_t N, int32_t A, void* s) {
-    if (dev_guard(device)) return 1;
+    MMS_DEV(device)
     if (!mean || !log_std || !counters || N < 0 || A <= 0 || A > 128) { g_create_error = "mms_ppo_act: bad arguments (A must be in 1..128)"; return 1; }
     MMS_FREE(mms::launch_ppo_act(mean, value, log_std, seed, counters, row_offset, reference_scale, actions_out, act_slot, logp_slot, value_slot,
                                  mu_slot, sigma_slot, N, A, (hipStream_t)s));
     return 0;
-}
-
-__attribute__((visibility("default"))) int mms_ppo_head_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H,
-                                                            const float* value, const float* log_std, uint64_t seed, int64_t* counters,
-                                                            int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
-                                                            float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N,
-                                                            int32_t A, void* s) {
-    return mms_ppo_heads_act(device, hidden, weight, bias, H, value, nullptr, nullptr, nullptr, 0, log_std, seed, counters, row_offset,
-                             reference_scale, actions_out, act_slot, logp_slot, value_slot, mu_slot, sigma_slot, N, A, s);
 }
 
 __attribute__((visibility("default"))) int mms_ppo_heads_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H,
@@ -403,9 +404,9 @@ __attribute__((visibility("default"))) int mms_ppo_heads_act(int device, const f
                                                              int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
                                                              float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N,
                                                              int32_t A, void* s) {
-    if (dev_guard(device)) return 1;
+    MMS_DEV(device)
     if (!hidden || !weight || !bias || !log_std || !counters || N < 0 || A <= 0 || A > 128 || H <= 0 || (H % 64) != 0) {
-        g_create_error = "mms_ppo_head_act: bad arguments (A must be in 1..128, H a positive multiple of 64)";
+        g_create_error = "mms_ppo_heads_act: bad arguments (A must be in 1..128, H a positive multiple of 64)";
         return 1;
     }
     if (vhidden && (!vweight || !vbias || VH <= 0 || (VH % 4) != 0)) {
@@ -420,7 +421,7 @@ __attribute__((visibility("default"))) int mms_ppo_heads_act(int device, const f
 __attribute__((visibility("default"))) int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const float* x0, const float* w0, const float* b0,
                                                            float* y0, const float* x1, const float* w1, const float* b1, float* y1, int32_t act,
                                                            void* s) {
-    if (dev_guard(device)) return 1;
+    MMS_DEV(device)
     if (!x0 || !w0 || !b0 || !y0 || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || (K % 4) != 0 || act < 0 || act > 3) {
         g_create_error = "mms_linear2_act: bad arguments (K must be a positive multiple of 4, act 0..3)";
         return 1;
@@ -429,22 +430,6 @@ __attribute__((visibility("default"))) int mms_linear2_act(int device, int64_t M
     if (two && !(x1 && w1 && b1 && y1)) { g_create_error = "mms_linear2_act: the second problem needs all four pointers"; return 1; }
     mms::LinearArgs a{{x0, x1}, {w0, w1}, {b0, b1}, {y0, y1}, (int)M, N, K, act};
     MMS_FREE(mms::launch_linear_act(a, two ? 2 : 1, (hipStream_t)s));
-    return 0;
-}
-
-__attribute__((visibility("default"))) int mms_linear2_act_bf16(int device, int64_t M, int32_t N, int32_t K, int32_t ldw, int32_t x_is_f32,
-                                                                const void* x0, const void* w0, const float* b0, void* y0, const void* x1,
-                                                                const void* w1, const float* b1, void* y1, int32_t act, void* s) {
-    if (dev_guard(device)) return 1;
-    if (!x0 || !w0 || !b0 || !y0 || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || ldw < K || (ldw % 64) != 0 || act < 0 || act > 3 ||
-        (x_is_f32 ? (K % 4) != 0 : (K % 64) != 0)) {
-        g_create_error = "mms_linear2_act_bf16: bad arguments (ldw a multiple of 64 >= K; K a multiple of 4 for fp32 x, of 64 for bf16 x)";
-        return 1;
-    }
-    const bool two = x1 || w1 || b1 || y1;
-    if (two && !(x1 && w1 && b1 && y1)) { g_create_error = "mms_linear2_act_bf16: the second problem needs all four pointers"; return 1; }
-    mms::LinearBf16Args a{{x0, x1}, {(const __bf16*)w0, (const __bf16*)w1}, {b0, b1}, {(__bf16*)y0, (__bf16*)y1}, (int)M, N, K, ldw, act};
-    MMS_FREE(mms::launch_linear_act_bf16(a, two ? 2 : 1, x_is_f32, (hipStream_t)s));
     return 0;
 }
 

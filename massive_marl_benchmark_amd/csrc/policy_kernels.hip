@@ -324,118 +324,6 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
 #undef MMS_MFMA4
 #undef MMS_FRAGS
 
-// ---------------------------------------------------------------------------------------------
-// bf16 variant (the informational bf16-policy rollout series): y = ELU(x W^T + b) with bf16 operands, fp32 accumulation
-// (v_mfma_f32_32x32x16_bf16) and bf16 output, both networks in one launch.  x is bf16 -- or fp32 (XF32: the first layer takes the
-// observation row as it is and rounds it to bf16 while staging it, which saves the cast pass); w is bf16 with its rows padded
-// to a multiple of 64 (ldw); K columns of x beyond a.K read as zero.  Same tiling as above: 128 x 128 per block, 64 x 64 per
-// wave, K slices of 64 through double-buffered LDS tiles (row pitch 72 bf16 = 144 B: eight consecutive rows start in eight
-// different 16-B slots).  Lane (i, h) of the MFMA supplies k = 8h .. 8h + 7 of row i: one 128-bit LDS read per fragment.
-// ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct LinearBf16Args {
-    const void* x[2];
-    const __bf16* w[2];
-    const float* b[2];
-    __bf16* y[2];
-    int M, N, K, ldw;       // K: valid columns of x (row stride of x); ldw: row stride of w, a multiple of 64 >= K
-    int act;
-};
-constexpr int kHK = 64, kHPitch = kHK + 8;
-constexpr size_t kLinearBf16Lds = (size_t)2 * 2 * 128 * kHPitch * sizeof(__bf16);      // 73.7 KB
-
-template <bool XF32>
-__global__ void __launch_bounds__(256, 2) linear_act_bf16_kernel(LinearBf16Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* As = reinterpret_cast<__bf16*>(smem_raw);           // [2][128][kHPitch]
-    __bf16* Bs = As + 2 * 128 * kHPitch;
-    const int g = blockIdx.z;
-    const float* __restrict__ Xf = reinterpret_cast<const float*>(a.x[g]);
-    const __bf16* __restrict__ Xh = reinterpret_cast<const __bf16*>(a.x[g]);
-    const __bf16* __restrict__ W = a.w[g];
-    const float* __restrict__ Bv = a.b[g];
-    __bf16* __restrict__ Y = a.y[g];
-    const int M = a.M, N = a.N, K = a.K, ldw = a.ldw;
-    const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-    const int li = lane & 31, lh = lane >> 5;
-    const int sr = t >> 3, sk = (t & 7) * 8;               // staging: rows sr + 32 j, eight k from sk
-
-    bf16x8 ra[4], rb[4];
-    auto load_slice = [&](int kt) {
-        const int k = kt * kHK + sk;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int row = min(m0 + sr + 32 * j, M - 1), col = min(n0 + sr + 32 * j, N - 1);   // clamped: extra rows are never stored
-            if (XF32) {
-                const float* src = Xf + (size_t)row * K + k;
-                const float4 lo = (k < K) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);       // K % 4 == 0
-                const float4 hi = (k + 4 < K) ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                ra[j] = bf16x8{(__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w};
-            } else {
-                ra[j] = *reinterpret_cast<const bf16x8*>(Xh + (size_t)row * K + k);          // K % 64 == 0 for bf16 inputs
-            }
-            rb[j] = *reinterpret_cast<const bf16x8*>(W + (size_t)col * ldw + k);
-        }
-    };
-    auto store_slice = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            *reinterpret_cast<bf16x8*>(As + ((size_t)buf * 128 + sr + 32 * j) * kHPitch + sk) = ra[j];
-            *reinterpret_cast<bf16x8*>(Bs + ((size_t)buf * 128 + sr + 32 * j) * kHPitch + sk) = rb[j];
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    const int nkt = ldw / kHK;
-    load_slice(0);
-    store_slice(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; kt++) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_slice(kt + 1);
-        const __bf16* a_base = As + ((size_t)buf * 128 + wr + li) * kHPitch + 8 * lh;
-        const __bf16* b_base = Bs + ((size_t)buf * 128 + wc + li) * kHPitch + 8 * lh;
-#pragma unroll
-        for (int ks = 0; ks < kHK / 16; ks++) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a_base + 16 * ks);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a_base + 32 * kHPitch + 16 * ks);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b_base + 16 * ks);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(b_base + 32 * kHPitch + 16 * ks);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (kt + 1 < nkt) store_slice(buf ^ 1);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int col = n0 + wc + 32 * j + li;
-        const float bias = (col < N) ? Bv[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[i][j][r] + bias;
-                v = apply_act(v, a.act);
-                if (row < M && col < N) Y[(size_t)row * N + col] = (__bf16)v;
-            }
-        }
-    }
-}
-
 // More than 64 KB of dynamic LDS needs an opt-in per kernel and per device; remembered so that it is asked for once.
 static hipError_t allow_large_lds(const void* kernel, int slot) {
     static bool done[12][64] = {};
@@ -448,16 +336,6 @@ static hipError_t allow_large_lds(const void* kernel, int slot) {
         if (dev >= 0 && dev < 64) done[slot][dev] = true;
     }
     return hipSuccess;
-}
-
-hipError_t launch_linear_act_bf16(const LinearBf16Args& a, int groups, int x_is_f32, hipStream_t s) {
-    if (a.M == 0 || a.N == 0) return hipSuccess;
-    dim3 grid((a.N + kTN - 1) / kTN, (a.M + kTM - 1) / kTM, groups);
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_bf16_kernel<true>), 0); e != hipSuccess) return e;
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(linear_act_bf16_kernel<false>), 1); e != hipSuccess) return e;
-    if (x_is_f32) hipLaunchKernelGGL(linear_act_bf16_kernel<true>, grid, dim3(256), kLinearBf16Lds, s, a);
-    else hipLaunchKernelGGL(linear_act_bf16_kernel<false>, grid, dim3(256), kLinearBf16Lds, s, a);
-    return hipGetLastError();
 }
 
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "mms_lane.h"
+#include "rollout_lane.h"
 
 namespace mms {
 
@@ -31,23 +32,8 @@ __global__ void __launch_bounds__(256) gae_ppo_kernel(const float* __restrict__ 
                                                       double* __restrict__ stats, int T, int64_t N, float gamma, float lam) {
     __shared__ double s_sum[4], s_sq[4];
     double lsum = 0.0, lsq = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        float adv = 0.f;
-        float next_v = last_values[i];
-        for (int t = T - 1; t >= 0; t--) {
-            float v = values[t * N + i];
-            float nt = 1.0f - (float)dones[t * N + i];
-            float delta = rewards[t * N + i] + nt * gamma * next_v - v;
-            adv = delta + nt * gamma * lam * adv;
-            float ret = adv + v;
-            returns[t * N + i] = ret;
-            float a = ret - v;                        // storage.py:64: advantages = returns - values
-            advantages[t * N + i] = a;
-            lsum += (double)a;
-            lsq += (double)a * (double)a;
-            next_v = v;
-        }
-    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        gae_ppo_column(rewards, dones, values, last_values, returns, advantages, T, N, i, gamma, lam, lsum, lsq);
     lsum = wave_sum(lsum);
     lsq = wave_sum(lsq);
     int wave = threadIdx.x >> 6;
@@ -64,11 +50,8 @@ __global__ void __launch_bounds__(256) gae_ppo_kernel(const float* __restrict__ 
 
 // advantages := (advantages - mean) / (std + 1e-8), std unbiased (torch.std default)
 __global__ void __launch_bounds__(256) adv_normalize_kernel(float* __restrict__ advantages, const double* __restrict__ stats, int64_t count) {
-    double n = stats[2];
-    double mean = stats[0] / n;
-    double var = (stats[1] - n * mean * mean) / (n - 1.0);
-    float inv = (float)(1.0 / (sqrt(var > 0.0 ? var : 0.0) + 1e-8));
-    float fm = (float)mean;
+    float fm, inv;
+    adv_norm_params(stats, fm, inv);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
         advantages[i] = (advantages[i] - fm) * inv;
 }
@@ -77,22 +60,9 @@ __global__ void __launch_bounds__(256) gae_marl_kernel(const float* __restrict__
                                                        const float* __restrict__ masks, float* __restrict__ returns, int T, int64_t N,
                                                        float gamma, float lam, int use_norm, const float* __restrict__ norm_mean,
                                                        const float* __restrict__ norm_var) {
-    float mean = 0.f, sd = 1.f;
-    if (use_norm) { mean = norm_mean[0]; sd = sqrtf(norm_var[0]); }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        float gae = 0.f;
-        float v1 = value_preds[(int64_t)T * N + i];
-        if (use_norm) v1 = v1 * sd + mean;
-        for (int t = T - 1; t >= 0; t--) {
-            float v0 = value_preds[t * N + i];
-            if (use_norm) v0 = v0 * sd + mean;
-            float m = masks[(t + 1) * N + i];
-            float delta = rewards[t * N + i] + gamma * v1 * m - v0;
-            gae = delta + gamma * lam * m * gae;
-            returns[t * N + i] = gae + v0;
-            v1 = v0;
-        }
-    }
+    const float mean = use_norm ? norm_mean[0] : 0.f, var = use_norm ? norm_var[0] : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        gae_marl_column(rewards, value_preds, masks, returns, T, N, N, i, i, gamma, lam, use_norm, mean, var);
 }
 
 // All agents of all envs in one launch: value_preds / returns are [T+1, N, A] (agent fastest), rewards and
@@ -106,35 +76,16 @@ __global__ void __launch_bounds__(256) gae_marl_agents_kernel(const float* __res
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = c / A;
         const int k = (int)(c - i * A);
-        float mean = 0.f, sd = 1.f;
-        if (use_norm) { mean = norm_mean[k]; sd = sqrtf(norm_var[k]); }
-        float gae = 0.f;
-        float v1 = value_preds[(int64_t)T * cols + c];
-        if (use_norm) v1 = v1 * sd + mean;
-        for (int t = T - 1; t >= 0; t--) {
-            float v0 = value_preds[(int64_t)t * cols + c];
-            if (use_norm) v0 = v0 * sd + mean;
-            float m = masks[(int64_t)(t + 1) * N + i];
-            float delta = rewards[(int64_t)t * N + i] + gamma * v1 * m - v0;
-            gae = delta + gamma * lam * m * gae;
-            returns[(int64_t)t * cols + c] = gae + v0;
-            v1 = v0;
-        }
+        gae_marl_column(rewards, value_preds, masks, returns, T, N, cols, c, i, gamma, lam, use_norm, use_norm ? norm_mean[k] : 0.f, use_norm ? norm_var[k] : 1.f);
     }
 }
 
 // obs_all[n][k][0:per] = obs[n][k*per : (k+1)*per], obs_all[n][k][per:] = obs[n][agents*per:]; input already clamped
 __global__ void __launch_bounds__(256) marl_views_kernel(const float* __restrict__ obs, float* __restrict__ obs_all, int64_t n,
                                                          int agents, int per, int shared) {
-    const int w = per + shared, row = agents * per + shared;
-    const int64_t total = n * agents * w;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t e = i / ((int64_t)agents * w);
-        int r = (int)(i - e * agents * w);
-        int k = r / w, j = r - k * w;
-        int src = (j < per) ? k * per + j : agents * per + (j - per);
-        obs_all[i] = obs[e * row + src];
-    }
+    const int64_t total = n * agents * (per + shared);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        obs_all[i] = obs[marl_view_source(i, agents, per, shared)];
 }
 
 // Sampling of one row by one wave: lane j draws the noise of action j (and j + 64), the row's log-probability is a wave
@@ -150,13 +101,10 @@ __device__ __forceinline__ void ppo_sample_row(const float* mean_row, const floa
     float lp = 0.f;
     for (int j = lane; j < A; j += 64) {
         const float ls = log_std[j];
-        float scale, lscale;
-        if (ref_scale) { float sd = expf(ls); scale = sd * sd; lscale = logf(scale); }   // module.py:76: diag(exp * exp) as scale_tril
-        else { scale = expf(ls); lscale = ls; }
-        const float z = rand_normal(seed, (uint64_t)(row_offset + row), (uint64_t)c, (uint32_t)j);
         const float m = mean_row[j];
-        const float act = m + scale * z;
-        lp += -0.5f * z * z - lscale - 0.9189385332046727f;
+        float term;
+        const float act = ppo_sample_one(m, ls, seed, (uint64_t)(row_offset + row), (uint64_t)c, (uint32_t)j, ref_scale, term);
+        lp += term;
         if (o.actions_out) o.actions_out[row * A + j] = act;
         if (o.act_slot) o.act_slot[row * A + j] = act;
         if (o.mu_slot) o.mu_slot[row * A + j] = m;
@@ -321,7 +269,8 @@ hipError_t launch_ppo_head_act(const float* hidden, const float* weight, const f
     if (N == 0) return hipSuccess;
     PpoActOut o{actions_out, act_slot, logp_slot, value_slot, mu_slot, sigma_slot};
     const int nct = (A + 15) / 16;
-    const int waves = (H % 512 == 0) ? 8 : (H % 256 == 0) ? 4 : (H % 128 == 0) ? 2 : 1;      // H / waves is a multiple of 64
+    int waves = (H % 512 == 0) ? 8 : (H % 256 == 0) ? 4 : (H % 128 == 0) ? 2 : 1;            // H / waves is a multiple of 64
+    if ((size_t)(waves + 1) * 16 * (nct * 16) * sizeof(float) > 64 * 1024) waves = 4;        // (8 waves x 8 column tiles: 73.7 KB) stay within the default 64 KB
     const size_t lds = (size_t)(waves + 1) * 16 * (nct * 16) * sizeof(float);
     const dim3 grid((unsigned)((N + 15) / 16));
 #define MMS_HEAD_W(NCT, W)                                                                                                                        \

@@ -21,17 +21,21 @@ class BaseTask:
         clip_obs = float(cfg.get("clip_observations", clip_obs))   # the VecTask wrapper's clamp, fused into the kernel
         self.device_type = cfg.get("device_type", "cuda")
         self.device_id = cfg.get("device_id", 0)
-        if self.device_type not in ("cuda", "GPU"):
-            # base_task.py:27-32 selects the CPU pipeline here; this build has no CPU path by design
-            raise RuntimeError("device_type=%r: the MI355X engine has no CPU pipeline (no CPU fallback)" % (self.device_type,))
-        self.device = "cuda:" + str(self.device_id)
+        if self.device_type in ("cuda", "GPU"):
+            self.device, engine_device = "cuda:" + str(self.device_id), self.device_id
+        elif self.device_type == "cpu":
+            # base_task.py:27-32: `--sim_device cpu` selects the CPU pipeline.  Here: the CPU build of the engine (lib/libmms_cpu.so,
+            # the kernels' lane math compiled for the host) -- because the caller asked for it, never as a fallback.
+            self.device, engine_device = "cpu", "cpu"
+        else:
+            raise RuntimeError("device_type=%r: expected 'cuda' / 'GPU' (the HIP engine) or 'cpu' (the CPU build)" % (self.device_type,))
         self.headless = cfg.get("headless", True)
         self.num_envs = cfg["env"]["numEnvs"]
         self.control_freq_inv = cfg["env"].get("controlFrequencyInv", 1)
         if self.control_freq_inv != 1:
             raise NotImplementedError("controlFrequencyInv != 1 (cfg/*.yaml ship 1)")
         self.engine = Engine(self.TASK_NAME, cfg, num_envs=self.num_envs, num_agents=num_agents_default,
-                             device=self.device_id, seed=max(int(cfg.get("seed", 0) or 0), 0),
+                             device=engine_device, seed=max(int(cfg.get("seed", 0) or 0), 0),
                              env_offset=int(cfg.get("env_offset", 0)), total_envs=cfg.get("total_envs", None),
                              clip_obs=clip_obs, clip_actions=float(cfg["env"].get("clipActions", 1.0)))
         e = self.engine

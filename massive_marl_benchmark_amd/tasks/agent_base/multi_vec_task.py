@@ -73,9 +73,10 @@ class MultiVecTaskPython(MultiVecTask):
 
     def _views(self):
         t, e = self.task, self.task.engine
-        _lib.check(_lib.lib().mms_marl_views(e.device_index, ctypes.c_void_p(t.obs_buf_clipped.data_ptr()),
-                                             ctypes.c_void_p(self._obs_all.data_ptr()), self.num_environments, self.num_agents,
-                                             self.num_ant_obs, self.shared_obs, current_stream_ptr(e.device)), None, "mms_marl_views")
+        L, idx, stream = _lib.for_device(e.device)
+        _lib.check(L.mms_marl_views(idx, ctypes.c_void_p(t.obs_buf_clipped.contiguous().data_ptr()),
+                                    ctypes.c_void_p(self._obs_all.data_ptr()), self.num_environments, self.num_agents,
+                                    self.num_ant_obs, self.shared_obs, stream), None, "mms_marl_views", L)
         state_all = t.obs_buf_clipped.unsqueeze(1).expand(-1, self.num_agents, -1)
         return self._obs_all.to(self.rl_device), state_all.to(self.rl_device)
 

@@ -1,235 +1,20 @@
 // emu_step.cpp -- CPU emulation of the step kernels' lane decomposition (TEST INFRASTRUCTURE).
 // Runs the SAME per-lane functions as the HIP kernels (massive_marl_benchmark_amd/csrc/mms_lane.h) over
-// the lanes of one environment in plain loops, with the DPP / LDS reductions replaced by explicit sums in
-// the same association order.  tests/test_lane_emulation.py compares it with the oracle, so that the
-// kernel math is validated on the CPU; the GPU tests then only have to confirm the launch plumbing.
-#include <string.h>
-
-#include <vector>
-
-#include "../../massive_marl_benchmark_amd/csrc/mms_lane.h"
+// the lanes of one environment in plain loops (massive_marl_benchmark_amd/csrc/cpu/lane_step.h, shared with the CPU build of
+// the engine).  tests/test_lane_emulation.py compares it with the oracle, so that the kernel math is validated on the CPU;
+// the GPU tests then only have to confirm the launch plumbing.
+#include "../../massive_marl_benchmark_amd/csrc/cpu/lane_step.h"
 
 using namespace mms;
-
-static RigidState load_rigid(const float* r) {
-    RigidState B;
-    B.pos = V3{r[0], r[1], r[2]};
-    B.qx = r[3]; B.qy = r[4]; B.qz = r[5]; B.qw = r[6];
-    B.vel = V3{r[7], r[8], r[9]};
-    B.ang = V3{r[10], r[11], r[12]};
-    return B;
-}
-static void store_rigid(float* r, const RigidState& B) {
-    r[0] = B.pos.x; r[1] = B.pos.y; r[2] = B.pos.z; r[3] = B.qx; r[4] = B.qy; r[5] = B.qz; r[6] = B.qw;
-    r[7] = B.vel.x; r[8] = B.vel.y; r[9] = B.vel.z; r[10] = B.ang.x; r[11] = B.ang.y; r[12] = B.ang.z;
-}
-static float quad4(const float x[4]) { return (x[0] + x[1]) + (x[2] + x[3]); }
-
-struct Bufs {
-    const float* actions; float* obs; float* obs_clipped; float* rew; int64_t* reset; int64_t* progress;
-    float* root_states; const float* initial_root_states; float* dof_state; const float* env_origin; float* prev;
-    const float* reset_noise; float* foot_sensors; int64_t* reset_count; const float* dr;
-};
-
-static void emu_ant_env(const mms_config* C, const Bufs& b, int env, int do_physics, int obs_dim, int prev_dim) {
-    const mms_model* M = &C->model;
-    const int A = C->num_agents, task = C->task, nl = 4 * A, actors = A + 1;
-    float* root_env = b.root_states + (size_t)env * actors * 13;
-    const float* init_env = b.initial_root_states + (size_t)env * actors * 13;
-    float* dof_env = b.dof_state + (size_t)env * A * 16;
-    const float* act_env = b.actions + (size_t)env * A * 8;
-    float* prev_env = b.prev + (size_t)env * prev_dim;
-    V3 origin = V3{b.env_origin[3 * env], b.env_origin[3 * env + 1], b.env_origin[3 * env + 2]};
-    int64_t reset_flag = b.reset[env], progress = b.progress[env];
-    uint64_t env_global = (uint64_t)(C->env_offset + env);
-    std::vector<LegConst> L(nl);
-    std::vector<AntLane> S(nl);
-    std::vector<float> act0(nl), act1(nl);
-    std::vector<float> sens(nl * 6, 0.f);
-    for (int t = 0; t < nl; t++) {
-        int ant = t >> 2, leg = t & 3;
-        L[t] = load_leg_const(M, leg);
-        const float* r = root_env + 13 * ant;
-        S[t].pos = V3{r[0], r[1], r[2]}; S[t].qx = r[3]; S[t].qy = r[4]; S[t].qz = r[5]; S[t].qw = r[6];
-        S[t].vel = V3{r[7], r[8], r[9]}; S[t].ang = V3{r[10], r[11], r[12]};
-        S[t].q[0] = dof_env[4 * t]; S[t].qd[0] = dof_env[4 * t + 1]; S[t].q[1] = dof_env[4 * t + 2]; S[t].qd[1] = dof_env[4 * t + 3];
-        act0[t] = clampf(act_env[2 * t], -C->clip_actions, C->clip_actions);
-        act1[t] = clampf(act_env[2 * t + 1], -C->clip_actions, C->clip_actions);
-        if (task == MMS_TASK_ONE_ANT)
-            for (int i = 0; i < 6; i++) sens[6 * t + i] = b.foot_sensors[((size_t)env * A + ant) * 24 + 6 * leg + i];
-    }
-    RigidState B = load_rigid(root_env + 13 * A);
-    if (do_physics && reset_flag == 0) {
-        float h = C->dt / (float)C->substeps;
-        for (int s = 0; s < C->substeps; s++) {
-            BoxPose bp;
-            bp.pos = B.pos; bp.R = quat_to_mat(B.qx, B.qy, B.qz, B.qw); bp.v = B.vel; bp.w = B.ang;
-            bp.half = V3{M->box_half[0], M->box_half[1], M->box_half[2]};
-            std::vector<Sym6> IA(nl);
-            std::vector<S6> pA(nl), wr(nl);
-            std::vector<LegPass> P(nl);
-            std::vector<SensorPass> SP(nl);
-            const KinPark no_park{nullptr, 0};
-            for (int t = 0; t < nl; t++) {
-                float t1 = act0[t] * L[t].gear[0] * C->power_scale, t2 = act1[t] * L[t].gear[1] * C->power_scale;
-                if (b.dr) {
-                    LegDR d = load_leg_dr(b.dr + ((size_t)env * A + (t >> 2)) * MMS_DR_FLOATS, t & 3);
-                    if (task == MMS_TASK_ONE_ANT) leg_inward<true, true>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t], no_park, &d);
-                    else leg_inward<false, true>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t], no_park, &d);
-                } else if (task == MMS_TASK_ONE_ANT) leg_inward<true>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t]);
-                else leg_inward<false>(M, L[t], h, S[t], t & 3, t1, t2, true, bp, P[t], &SP[t], IA[t], pA[t]);
-            }
-            for (int q = 0; q < nl; q += 4) {                      // quad all-reduce
-                Sym6 sum;
-                S6 ps;
-                for (int k = 0; k < 21; k++) { float x[4] = {IA[q].m[k], IA[q + 1].m[k], IA[q + 2].m[k], IA[q + 3].m[k]}; sum.m[k] = quad4(x); }
-                float* pp[6] = {&ps.a.x, &ps.a.y, &ps.a.z, &ps.l.x, &ps.l.y, &ps.l.z};
-                for (int k = 0; k < 6; k++) { float x[4] = {get(pA[q], k), get(pA[q + 1], k), get(pA[q + 2], k), get(pA[q + 3], k)}; *pp[k] = quad4(x); }
-                for (int j = 0; j < 4; j++) { IA[q + j] = sum; pA[q + j] = ps; }
-            }
-            for (int t = 0; t < nl; t++) {
-                if (task == MMS_TASK_ONE_ANT) leg_outward<true>(M, L[t], h, S[t], t & 3, bp, P[t], &SP[t], IA[t], pA[t], wr[t], &sens[6 * t]);
-                else leg_outward<false>(M, L[t], h, S[t], t & 3, bp, P[t], &SP[t], IA[t], pA[t], wr[t], nullptr);
-            }
-            float wt[6];
-            for (int c = 0; c < 6; c++) { float tsum = 0.f; for (int t = 0; t < nl; t++) tsum += get(wr[t], c); wt[c] = tsum; }
-            if (M->boxgnd_mu > 0.f) {
-                BoxCornerF bc[8], bt;
-                for (int c = 0; c < 8; c++) bc[c] = box_corner_friction(M, h, B, bp.R, c);
-                auto osum = [&](auto get) { return ((get(0) + get(1)) + (get(2) + get(3))) + ((get(4) + get(5)) + (get(6) + get(7))); };
-                for (int k = 0; k < 21; k++) bt.IA.m[k] = osum([&](int c) { return bc[c].IA.m[k]; });
-                float* pp[6] = {&bt.pA.a.x, &bt.pA.a.y, &bt.pA.a.z, &bt.pA.l.x, &bt.pA.l.y, &bt.pA.l.z};
-                for (int k = 0; k < 6; k++) *pp[k] = osum([&](int c) { return get(bc[c].pA, k); });
-                box_finish_friction(M, h, B, bp.R, bt, S6{V3{wt[0], wt[1], wt[2]}, V3{wt[3], wt[4], wt[5]}});
-            } else {
-            BoxCorner bc[8], bt;
-            for (int c = 0; c < 8; c++) bc[c] = box_corner(M, h, B, bp.R, c);
-            for (int k = 0; k < 9; k++) {                          // quad sums, then the half-mirror pair
-                float q0 = (bc[0].t[k] + bc[1].t[k]) + (bc[2].t[k] + bc[3].t[k]), q1 = (bc[4].t[k] + bc[5].t[k]) + (bc[6].t[k] + bc[7].t[k]);
-                bt.t[k] = q0 + q1;
-            }
-            box_finish(M, h, B, bp.R, bt, S6{V3{wt[0], wt[1], wt[2]}, V3{wt[3], wt[4], wt[5]}});
-            }
-        }
-    }
-    progress += 1;
-    if (reset_flag != 0) {
-        for (int t = 0; t < nl; t++) ant_reset_lane(C, L[t], S[t], init_env + 13 * (t >> 2), t & 3, b.reset_noise + 16 * (size_t)env, env_global, (uint64_t)b.reset_count[env]);
-        B = load_rigid(init_env + 13 * A);
-        progress = 0;
-        b.reset_count[env] += 1;
-    }
-    for (int t = 0; t < nl; t++) {
-        dof_env[4 * t] = S[t].q[0]; dof_env[4 * t + 1] = S[t].qd[0]; dof_env[4 * t + 2] = S[t].q[1]; dof_env[4 * t + 3] = S[t].qd[1];
-        if ((t & 3) == 0) {
-            RigidState R;
-            R.pos = S[t].pos; R.qx = S[t].qx; R.qy = S[t].qy; R.qz = S[t].qz; R.qw = S[t].qw; R.vel = S[t].vel; R.ang = S[t].ang;
-            store_rigid(root_env + 13 * (t >> 2), R);
-        }
-    }
-    store_rigid(root_env + 13 * A, B);
-    std::vector<float> s_obs(obs_dim, 0.f), s_red(RP_STRIDE * A, 0.f);
-    float bgx = B.pos.x + origin.x, bgy = B.pos.y + origin.y;
-    float rew;
-    int64_t rs;
-    if (task == MMS_TASK_TEN_ANT) {
-        float sv, cv;
-        box_yaw_dir(B.qz, B.qw, sv, cv);
-        std::vector<TenAntLaneOut> o(nl);
-        std::vector<float> newprev(prev_dim);
-        for (int t = 0; t < nl; t++) {
-            int ant = t >> 2;
-            float pbx = prev_env[2 * ant], pby = prev_env[2 * ant + 1], gbx = prev_env[2 * A + 2 * ant], gby = prev_env[2 * A + 2 * ant + 1];
-            o[t] = tenant_obs_reward_lane(C, L[t], S[t], ant, t & 3, origin, act0[t], act1[t], bgx, bgy, sv, cv, pbx, pby, gbx, gby, s_obs.data());
-        }
-        for (int q = 0; q < nl; q += 4) {
-            float e[4] = {o[q].ec, o[q + 1].ec, o[q + 2].ec, o[q + 3].ec}, l[4] = {o[q].lim, o[q + 1].lim, o[q + 2].lim, o[q + 3].lim},
-                  c[4] = {o[q].acost, o[q + 1].acost, o[q + 2].acost, o[q + 3].acost};
-            float* r = s_red.data() + RP_STRIDE * (q >> 2);
-            r[RP_ADR] = o[q].adr; r[RP_GDR] = o[q].gdr; r[RP_GAR] = o[q].gar; r[RP_UP] = o[q].up; r[RP_EC] = quad4(e); r[RP_LIM] = quad4(l);
-            r[RP_FALLEN] = o[q].fallen; r[RP_ACOST] = quad4(c);
-            int ant = q >> 2;
-            prev_env[2 * ant] = o[q].px; prev_env[2 * ant + 1] = o[q].py; prev_env[2 * A + 2 * ant] = o[q].gx; prev_env[2 * A + 2 * ant + 1] = o[q].gy;
-        }
-        float* tt = s_obs.data() + 38 * A;
-        tt[0] = bgx; tt[1] = bgy; tt[2] = B.qx; tt[3] = B.qy; tt[4] = B.qz; tt[5] = B.qw; tt[6] = 0.f; tt[7] = 0.f;
-        prev_env[4 * A] = bgx; prev_env[4 * A + 1] = bgy;
-        tenant_reward_finish(C, A, s_red.data(), B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
-    } else {
-        float pot_in = prev_env[4];
-        OneAntLaneOut o[4];
-        AntObsCore core;
-        V3 pg;
-        for (int t = 0; t < 4; t++) o[t] = oneant_obs_lane(C, L[t], S[t], t, origin, act0[t], act1[t], &sens[6 * t], s_obs.data(), core, pg);
-        float e[4] = {o[0].ec, o[1].ec, o[2].ec, o[3].ec}, l[4] = {o[0].lim, o[1].lim, o[2].lim, o[3].lim}, c[4] = {o[0].acost, o[1].acost, o[2].acost, o[3].acost};
-        if (do_physics && reset_flag == 0)
-            for (int t = 0; t < 4; t++) for (int i = 0; i < 6; i++) b.foot_sensors[(size_t)env * 24 + 6 * t + i] = sens[6 * t + i];
-        float pbx = prev_env[0], pby = prev_env[1], bbx = prev_env[2], bby = prev_env[3];
-        float tbx = 0.f - bgx, tby = 0.f - bgy;
-        float pot = -sqrtf(tbx * tbx + tby * tby + 0.f * 0.f) / C->dt;
-        oneant_reward(C, pg.z, core.up_proj, quad4(e), quad4(l), quad4(c), pbx, pby, bbx, bby, pg.x, pg.y, bgx, bgy, B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
-        prev_env[0] = pg.x; prev_env[1] = pg.y; prev_env[2] = bgx; prev_env[3] = bgy; prev_env[4] = pot; prev_env[5] = pot_in;
-    }
-    b.rew[env] = rew; b.reset[env] = rs; b.progress[env] = progress;
-    for (int i = 0; i < obs_dim; i++) {
-        b.obs[(size_t)env * obs_dim + i] = s_obs[i];
-        b.obs_clipped[(size_t)env * obs_dim + i] = clampf(s_obs[i], -C->clip_obs, C->clip_obs);
-    }
-}
-
-static void emu_heli_env(const mms_config* C, const Bufs& b, int env, int do_physics) {
-    const mms_model* M = &C->model;
-    const int A = 4;
-    int64_t reset_flag = b.reset[env], progress = b.progress[env];
-    float rows[4][13];
-    for (int k = 0; k < A; k++) {
-        float* root = b.root_states + ((size_t)env * A + k) * 13;
-        const float* init = b.initial_root_states + ((size_t)env * A + k) * 13;
-        float* dof = b.dof_state + ((size_t)env * A + k) * 8;
-        const float* act = b.actions + (size_t)env * 24 + 6 * k;
-        RigidState B = load_rigid(root);
-        if (do_physics && reset_flag == 0) {
-            V3 thr[2];
-            for (int r = 0; r < 2; r++) {
-                float a0 = clampf(act[3 * r], -C->clip_actions, C->clip_actions), a1 = clampf(act[3 * r + 1], -C->clip_actions, C->clip_actions),
-                      a2 = clampf(act[3 * r + 2], -C->clip_actions, C->clip_actions);
-                float tz = C->dt * clampf(a2 * 2000.f, -2000.f, 2000.f);
-                thr[r] = V3{tz * clampf(a0, -0.2f, 0.2f), tz * clampf(a1, -0.2f, 0.2f), tz};
-            }
-            float h = C->dt / (float)C->substeps;
-            for (int s = 0; s < C->substeps; s++) {
-                heli_substep(M, h, B, thr[0], thr[1]);
-                for (int j = 0; j < 4; j++) dof[2 * j] += h * dof[2 * j + 1];
-            }
-        }
-        if (reset_flag != 0) {
-            B = load_rigid(init);
-            for (int j = 0; j < 4; j++) { dof[2 * j] = 0.f; dof[2 * j + 1] = (j == 1) ? -50.f : (j == 3 ? 50.f : 0.f); }
-        }
-        store_rigid(root, B);
-        store_rigid(rows[k], B);
-        rows[k][0] += b.env_origin[3 * env]; rows[k][1] += b.env_origin[3 * env + 1]; rows[k][2] += b.env_origin[3 * env + 2];
-        for (int j = 0; j < 13; j++) {
-            b.obs[(size_t)env * 52 + 13 * k + j] = rows[k][j];
-            b.obs_clipped[(size_t)env * 52 + 13 * k + j] = clampf(rows[k][j], -C->clip_obs, C->clip_obs);
-        }
-    }
-    progress += 1;
-    if (reset_flag != 0) { progress = 0; b.reset_count[env] += 1; }
-    float rew;
-    int64_t rs;
-    ingenuity_reward(&rows[0][0], C->max_episode_length, progress, rew, rs);
-    b.rew[env] = rew; b.reset[env] = rs; b.progress[env] = progress;
-}
 
 extern "C" __attribute__((visibility("default"))) void emu_step(const mms_config* C, const float* actions, float* obs, float* obs_clipped,
                                                                  float* rew, int64_t* reset, int64_t* progress, float* root_states,
                                                                  const float* initial_root_states, float* dof_state, const float* env_origin,
                                                                  float* prev, const float* reset_noise, float* foot_sensors, int64_t* reset_count,
                                                                  int do_physics, int obs_dim, int prev_dim, const float* dr /* may be NULL */) {
-    Bufs b{actions, obs, obs_clipped, rew, reset, progress, root_states, initial_root_states, dof_state, env_origin, prev, reset_noise, foot_sensors, reset_count, dr};
+    HostBufs b{actions, obs, obs_clipped, rew, reset, progress, root_states, initial_root_states, dof_state, env_origin, prev, reset_noise, foot_sensors, reset_count, dr};
     for (int env = 0; env < C->num_envs; env++) {
-        if (C->task == MMS_TASK_MULTI_INGENUITY) emu_heli_env(C, b, env, do_physics);
-        else emu_ant_env(C, b, env, do_physics, obs_dim, prev_dim);
+        if (C->task == MMS_TASK_MULTI_INGENUITY) host_heli_env(C, b, env, do_physics);
+        else host_ant_env(C, b, env, do_physics, obs_dim, prev_dim);
     }
 }

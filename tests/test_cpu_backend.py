@@ -1,0 +1,259 @@
+"""The CPU build of the engine (massive_marl_benchmark_amd/lib/libmms_cpu.so; csrc/cpu/): the kernels' lane math compiled for the
+host behind the same C ABI, selected only by asking for it (device_type="cpu" / device=-1).  What it is for: the reference's
+`--sim_device cpu` pipeline (agents/tasks/agent_base/base_task.py:27-32; BASELINE configs[0] "OneAnt num_envs=64 PPO, sim_device=cpu
+-- plumbing, no GPU").  Checked here: the ABI, parity with the oracle under the gates of tests/parity.py, every reference fixture
+through its step path, the drop-in classes end to end on it, and that it is never a fallback."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from conftest import ROOT, load_golden
+from massive_marl_benchmark_amd import _lib
+from massive_marl_benchmark_amd.engine import Engine
+from massive_marl_benchmark_amd.model import default_cfg, make_config
+from oracle.oracle import OracleEngine
+
+
+def test_cpu_library_exports_the_whole_abi():
+    header = open(os.path.join(ROOT, "include", "mms.h")).read()
+    declared = set(re.findall(r"\b(mms_[a-z0-9_]+)\s*\(", header)) - {"mms_engine"}
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_CPU_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert declared <= exported, declared - exported
+    assert set(_lib.SYMBOLS) <= exported
+    assert b"gfx950" not in open(_lib.LIB_CPU_PATH, "rb").read()                  # host code only
+    assert _lib.lib_cpu().mms_abi_version() == _lib.lib().mms_abi_version()
+
+
+def test_never_a_fallback():
+    """The two builds refuse each other's device: the HIP library fails for device -1 (and without a GPU), the CPU library fails
+    for a HIP ordinal; Engine() without a device argument still means the GPU."""
+    h = ctypes.c_void_p()
+    cfg = make_config("OneAnt", num_envs=4, device=-1)
+    assert _lib.lib().mms_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert "libmms_cpu.so" in _lib.last_error(None)
+    cfg = make_config("OneAnt", num_envs=4, device=0)
+    assert _lib.lib_cpu().mms_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert "device must be -1" in _lib.last_error(None, _lib.lib_cpu())
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.MmsError):
+            Engine("OneAnt", num_envs=4)
+    z = torch.zeros(4)
+    assert _lib.lib_cpu().mms_marl_views(0, ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(z.data_ptr()), 0, 2, 1, 0, None) != 0
+
+
+def test_package_never_imports_the_oracle():
+    """The oracle is the checker: no file of the product package may import, load or name it."""
+    pkg = os.path.join(ROOT, "massive_marl_benchmark_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b|libmms_oracle|mms_oracle\.c\"|oracle/_build", text, re.M), os.path.join(dirpath, f)
+
+
+class CpuImpl:
+    """tests/parity.py adapter: the CPU build behind the put / get / post_step / step interface."""
+
+    def __init__(self, task, cfg=None, **kw):
+        self.eng = Engine(task, cfg, device="cpu", **kw)
+        self.config = self.eng.config
+
+    def put(self, name, arr):
+        t = self.eng.tensor(name)
+        t.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(arr).reshape(tuple(t.shape)))).to(t.dtype))
+
+    def get(self, name):
+        return self.eng.tensor(name).numpy().copy()
+
+    def post_step(self, actions):
+        self.eng.tensor("actions").copy_(torch.from_numpy(np.ascontiguousarray(actions, np.float32)))
+        self.eng.post_step()
+
+    def step(self, actions):
+        self.eng.tensor("actions").copy_(torch.from_numpy(np.ascontiguousarray(actions, np.float32)))
+        self.eng.step()
+
+    def close(self):
+        self.eng.close()
+
+
+@pytest.mark.parametrize("check", [parity.fixture_tenant_obs, parity.fixture_tenant_goals, parity.fixture_oneant, parity.fixture_ingenuity])
+def test_reference_fixtures_through_cpu_build(check):
+    check(lambda task, cfg=None, **kw: CpuImpl(task, cfg=cfg, **kw), load_golden, "cpu/")
+
+
+@pytest.mark.parametrize("task,n,steps", [("OneAnt", 64, 100), ("TenAnt", 8, 80), ("MultiIngenuity", 16, 80)])
+def test_teacher_forced_parity_vs_oracle(task, n, steps):
+    """BASELINE configs[0]'s shape (OneAnt, 64 envs) and the other tasks on the CPU build, step for step against the oracle."""
+    kw = dict(num_envs=n, seed=5, total_envs=64, env_offset=0)
+    if task == "MultiIngenuity":
+        cfg = default_cfg(task)
+        cfg["env"]["envSpacing"] = 0.0
+        kw["cfg"] = cfg
+    eng, ora = Engine(task, device="cpu", **kw), OracleEngine(task, **kw)
+    tf = parity.TeacherForced(ora, lambda k: eng.tensor(k).numpy())
+    rng = np.random.default_rng(1)
+    for t in range(steps):
+        act = rng.uniform(-1.2, 1.2, (n, ora.num_actions)).astype(np.float32)
+        if task == "MultiIngenuity":
+            act[:, 2::3] = np.abs(act[:, 2::3]) * 0.12
+        for name in parity.STATE:
+            eng.tensor(name).copy_(torch.from_numpy(ora.tensor(name).copy()))
+        tf.before(act)
+        eng.tensor("actions").copy_(torch.from_numpy(act))
+        eng.step()
+        ora.step(act)
+        tf.after("%s step %d" % (task, t))
+    tf.finish("cpu/teacher_forced/%s" % task, min_live_steps=steps // 2)
+    eng.close()
+
+
+def test_one_ant_cpu_pipeline_ppo_plumbing():
+    """BASELINE configs[0]: OneAnt, num_envs = 64, PPO, sim_device = cpu.  The drop-in classes end to end on the CPU build: task
+    constructor with device_type="cpu", VecTaskPython, ActorCritic, RolloutStorage (cfg/ppo/config.yaml: nsteps 8, gamma 0.96,
+    lam 0.95), one surrogate update -- finite, episodes reset, zero-copy slots hold what the wrapper returned."""
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.storage import RolloutStorage
+    from massive_marl_benchmark_amd.tasks.agent_base.vec_task import VecTaskPython
+    from massive_marl_benchmark_amd.tasks.one_ant import OneAnt
+    cfg = default_cfg("OneAnt")
+    cfg["env"]["numEnvs"] = 64
+    cfg["seed"] = 2
+    task = OneAnt(cfg, None, "physx", "cpu", 0, True)
+    env = VecTaskPython(task, "cpu", 5.0, 1.0)
+    assert env.num_envs == 64 and env.observation_space.shape == (60,) and env.action_space.shape == (8,)
+    torch.manual_seed(0)
+    ac = ActorCritic((60,), (0,), (8,), 0.8, {"pi_hid_sizes": [64, 64], "vf_hid_sizes": [64, 64], "activation": "elu"}, seed=3)
+    st = RolloutStorage(64, 8, (60,), (0,), (8,), device="cpu")
+    opt = torch.optim.Adam(ac.parameters(), lr=3e-4)
+    obs = env.reset()
+    states = env.get_state()
+    resets = 0
+    for it in range(3):
+        for _ in range(8):
+            a, logp, v, mu, sigma = ac.act(obs, states)
+            nxt, rew, done, info = env.step(a)
+            st.add_transitions(obs, states, a, rew, done, v, logp, mu, sigma)
+            obs = nxt.clone()
+            resets += int(done.sum())
+        _, _, last, _, _ = ac.act(obs, states)
+        st.compute_returns(last, 0.96, 0.95)
+        assert bool(torch.isfinite(st.returns).all()) and abs(float(st.advantages.mean())) < 1e-5
+        assert abs(float(st.advantages.std()) - 1.0) < 1e-3
+        for idx in st.mini_batch_generator(4):
+            o = st.observations.view(-1, 60)[idx]
+            lp, ent, val, _, _ = ac.evaluate(o, states[:0], st.actions.view(-1, 8)[idx])
+            ratio = torch.exp(lp - st.actions_log_prob.view(-1)[idx])
+            adv = st.advantages.view(-1)[idx]
+            loss = -torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv).mean() + ((st.returns.view(-1)[idx] - val.view(-1)) ** 2).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        assert bool(torch.isfinite(loss))
+        st.clear()
+    assert bool(torch.isfinite(obs).all()) and float(obs.abs().max()) <= 5.0
+    task.engine.close()
+
+
+def test_marl_wrappers_and_generators_on_cpu_build():
+    """MultiVecTaskPython + SharedRolloutBuffers + the per-agent views' minibatch generators (what mappo_trainer.py:216 iterates
+    over) on the CPU build; the shared views and ten SeparatedReplayBuffers driven the reference's way hold the same data, and the
+    generators of both yield the reference's 12 / 13-tuples with matching contents under the same torch seed."""
+    from massive_marl_benchmark_amd.algorithms.marl.utils.separated_buffer import SeparatedReplayBuffer
+    from massive_marl_benchmark_amd.algorithms.marl.utils.shared_buffer import SharedRolloutBuffers
+    from massive_marl_benchmark_amd.tasks.agent_base.multi_vec_task import MultiVecTaskPython
+    from massive_marl_benchmark_amd.tasks.ten_ant import TenAnt
+    n, T, A = 12, 8, 10
+    conf = dict(episode_length=T, n_rollout_threads=n, hidden_size=16, recurrent_N=1, gamma=0.99, gae_lambda=0.95, use_gae=True,
+                use_popart=False, use_valuenorm=False, use_proper_time_limits=False)
+
+    def make_env():
+        cfg = default_cfg("TenAnt")
+        cfg["env"]["numEnvs"] = n
+        cfg["clip_observations"] = 7.0
+        cfg["seed"] = 3
+        return MultiVecTaskPython(TenAnt(cfg, None, "physx", "cpu", 0, True, is_multi_agent=True), "cpu")
+
+    g = torch.Generator().manual_seed(0)
+    acts = [[torch.rand(n, 8, generator=g) * 2 - 1 for _ in range(A)] for _ in range(T)]
+    vals = [torch.randn(n, A, generator=g) for _ in range(T + 1)]
+    logp = [[torch.randn(n, 8, generator=g) for _ in range(A)] for _ in range(T)]
+    env = make_env()
+    bufs = [SeparatedReplayBuffer(conf, env.observation_space[k], env.share_observation_space[k], env.action_space[k], "cpu") for k in range(A)]
+    obs, share, _ = env.reset()
+    for k in range(A):
+        bufs[k].share_obs[0].copy_(share[:, k]); bufs[k].obs[0].copy_(obs[:, k])
+    for t in range(T):
+        obs, share, rew, dones, _, _ = env.step(acts[t])
+        masks = torch.ones(n, A, 1)
+        masks[torch.all(dones != 0, dim=1)] = 0
+        for k in range(A):
+            bufs[k].insert(share[:, k], obs[:, k], torch.zeros(n, 1, 16), torch.zeros(n, 1, 16), acts[t][k], logp[t][k], vals[t][:, k:k + 1],
+                           rew[:, k], masks[:, k])
+    for k in range(A):
+        bufs[k].compute_returns(vals[T][:, k:k + 1], None)
+    env.task.engine.close()
+    env = make_env()
+    sh = SharedRolloutBuffers(conf, env, "cpu")
+    sh.warmup()
+    for t in range(T):
+        rew, dones = sh.env_step(acts[t])
+        sh.insert_step(rew, dones, vals[t], acts[t], logp[t])
+    sh.compute_returns(vals[T], None)
+    for k in (0, 7):
+        v, b = sh.agents[k], bufs[k]
+        assert torch.equal(v.share_obs, b.share_obs) and torch.equal(v.obs, b.obs) and torch.equal(v.rewards, b.rewards)
+        assert torch.allclose(v.returns[:T], b.returns[:T], atol=1e-5)
+        adv = b.returns[:-1] - b.value_preds[:-1]
+        for gen, args in (("feed_forward_generator", (adv, 4)), ("naive_recurrent_generator", (adv, 3)), ("recurrent_generator", (adv, 2, 4))):
+            torch.manual_seed(5)
+            one = list(getattr(v, gen)(*args))
+            torch.manual_seed(5)
+            two = list(getattr(b, gen)(*args))
+            assert len(one) == len(two) == args[1]
+            for x, y in zip(one, two):
+                assert len(x) == len(y) == 13                                         # factor is present in both buffer kinds
+                for i, (p, q) in enumerate(zip(x, y)):
+                    assert (p is None and q is None) or (p.shape == q.shape and torch.allclose(p, q, atol=1e-5)), (gen, i)
+        # shapes of one feed-forward batch: [batch, dim] rows in the reference's order
+        x = one_ff = next(iter(v.feed_forward_generator(adv, 4)))
+        mb = T * n // 4
+        assert x[0].shape == (mb, 388) and x[1].shape == (mb, 46) and x[4].shape == (mb, 8) and x[5].shape == (mb, 1) and x[10].shape == (mb, 1)
+        assert x[11] is None and x[12].shape == (mb, 1)
+    env.task.engine.close()
+
+
+def test_make_entry_glue():
+    """`make(task, algo)` = the reference's `agents.make` (agents/utils/package_utils.py:20-56) without isaacgym."""
+    from massive_marl_benchmark_amd.utils.package_utils import make
+    cpu = ["--sim_device", "cpu", "--pipeline", "cpu", "--rl_device", "cpu", "--seed", "1"]
+    env = make("OneAnt", "ppo", cpu + ["--num_envs", "8"])
+    assert type(env).__name__ == "VecTaskPython" and env.reset().shape == (8, 60)
+    env.task.engine.close()
+    env = make("TenAnt", "mappo", cpu + ["--num_envs", "4"])
+    assert type(env).__name__ == "MultiVecTaskPython" and env.num_agents == 10 and env.reset()[0].shape == (4, 10, 46)
+    env.task.engine.close()
+    with pytest.raises(ValueError):
+        make("OneAnt", "mtppo", cpu)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("MMS_REFERENCE", "/root/reference")), reason="reference tree not present")
+def test_reference_learners_drop_in_unchanged(tmp_path):
+    """The reference's real PPO.run (agents/algorithms/rl/ppo/ppo.py:99-175) and Runner.run (agents/algorithms/marl/runner.py:114-151,
+    mappo), imported in place and unmodified, over this build's VecTaskPython / MultiVecTaskPython on the CPU build -- with the
+    reference's own storage / module / buffer classes and with this build's drop-in ones.  The committed log of the same script:
+    tests/golden/reference_learners_dropin.log."""
+    log = tmp_path / "dropin.log"
+    env = dict(os.environ, MMS_DROPIN_LOG=str(log), OMP_NUM_THREADS="4")
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tests", "golden", "run_reference_learners.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    text = log.read_text()
+    assert text.count(": ok") == 4 and "Runner.run" in text and "PPO.run" in text

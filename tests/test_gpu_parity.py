@@ -983,9 +983,10 @@ def test_ppo_act_kernel_vs_oracle(torch_cuda):
     assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
 
 
-def test_ppo_head_act_kernel(torch_cuda):
-    """mms_ppo_head_act: the actor's last Linear layer on the matrix cores (fp32 MFMA) + the sampling.  The mean against a
-    float64 product of the same operands, everything downstream of it against the oracle fed with the kernel's own mean."""
+def test_ppo_heads_act_kernel(torch_cuda):
+    """mms_ppo_heads_act without the value head: the actor's last Linear layer on the matrix cores (fp32 MFMA) + the sampling.
+    The mean against a float64 product of the same operands, everything downstream of it against the oracle fed with the
+    kernel's own mean.  (37, 512, 128): 8 column tiles at H = 512, the shape whose 8-wave form would need 73.7 KB of LDS.)"""
     torch = torch_cuda
     from massive_marl_benchmark_amd import _lib
     from oracle.oracle import fp, ip, lib as olib_
@@ -994,7 +995,7 @@ def test_ppo_head_act_kernel(torch_cuda):
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(8)
-    for (N, H, A) in ((4096, 512, 80), (1003, 64, 8), (37, 256, 128), (16, 128, 1)):
+    for (N, H, A) in ((4096, 512, 80), (1003, 64, 8), (37, 256, 128), (37, 512, 128), (16, 128, 1)):
         hid = rng.standard_normal((N, H)).astype(np.float32)
         W = (rng.standard_normal((A, H)) / np.sqrt(H)).astype(np.float32)
         b = rng.standard_normal(A).astype(np.float32)
@@ -1004,8 +1005,8 @@ def test_ppo_head_act_kernel(torch_cuda):
         counters = torch.zeros(N, dtype=torch.int64, device="cuda")
         act, mu, sigma = (torch.zeros(N, A, device="cuda") for _ in range(3))
         logp, val = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
-        _lib.check(L.mms_ppo_head_act(0, p(th), p(tw), p(tb), H, p(tv), p(tl), 77, p(counters), 5, 1, None, p(act), p(logp), p(val),
-                                      p(mu), p(sigma), N, A, stream), None, "mms_ppo_head_act")
+        _lib.check(L.mms_ppo_heads_act(0, p(th), p(tw), p(tb), H, p(tv), None, None, None, 0, p(tl), 77, p(counters), 5, 1, None, p(act), p(logp),
+                                       p(val), p(mu), p(sigma), N, A, stream), None, "mms_ppo_heads_act")
         torch.cuda.synchronize()
         ref = hid.astype(np.float64) @ W.astype(np.float64).T + b
         scale = np.abs(hid).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b)
@@ -1018,7 +1019,7 @@ def test_ppo_head_act_kernel(torch_cuda):
         assert np.max(np.abs(to_np(logp) - ologp)) < 2e-3 * (A / 80.0 + 1.0)
         np.testing.assert_array_equal(to_np(val), value)
         np.testing.assert_array_equal(to_np(counters), oc)
-    rc = L.mms_ppo_head_act(0, p(th), p(tw), p(tb), 100, p(tv), p(tl), 77, p(counters), 5, 1, None, p(act), p(logp), p(val), p(mu), p(sigma), N, A, stream)
+    rc = L.mms_ppo_heads_act(0, p(th), p(tw), p(tb), 100, p(tv), None, None, None, 0, p(tl), 77, p(counters), 5, 1, None, p(act), p(logp), p(val), p(mu), p(sigma), N, A, stream)
     assert rc != 0 and "multiple of 64" in _lib.last_error(None)
 
 
@@ -1052,41 +1053,6 @@ def test_linear2_act_kernel(torch_cuda):
     assert L.mms_linear2_act(0, 8, 8, 6, p(x[0]), p(w[0]), p(b[0]), p(y[0]), None, None, None, None, 1, stream) != 0     # K % 4
 
 
-def test_linear2_act_bf16_kernel(torch_cuda):
-    """mms_linear2_act_bf16 (bf16 MFMA, fp32 accumulation, bias + ELU, bf16 out; fp32 or bf16 input) against a float64 product of
-    the SAME bf16-rounded operands: what is left is the rounding of the bf16 result (2^-9 relative)."""
-    torch = torch_cuda
-    from massive_marl_benchmark_amd import _lib
-    L = _lib.lib()
-    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    bf = torch.bfloat16
-    torch.manual_seed(6)
-    for (M, N, K, xf32, act, two) in ((4096, 1024, 388, True, 1, True), (300, 200, 36, True, 1, True), (129, 257, 128, False, 0, True),
-                                       (64, 512, 1024, False, 1, False), (1, 1, 4, True, 0, False)):
-        ldw = (K + 63) // 64 * 64
-        x = [torch.randn(M, K, device="cuda") for _ in range(2)]
-        if not xf32:
-            x = [t.to(bf) for t in x]
-        w = []
-        for _ in range(2):
-            q = torch.zeros(N, ldw, device="cuda", dtype=bf)
-            q[:, :K] = (torch.randn(N, K, device="cuda") / K ** 0.5).to(bf)
-            w.append(q)
-        b = [torch.randn(N, device="cuda") for _ in range(2)]
-        y = [torch.full((M, N), float("nan"), device="cuda", dtype=bf) for _ in range(2)]
-        rc = L.mms_linear2_act_bf16(0, M, N, K, ldw, 1 if xf32 else 0, p(x[0]), p(w[0]), p(b[0]), p(y[0]), p(x[1] if two else None),
-                                    p(w[1] if two else None), p(b[1] if two else None), p(y[1] if two else None), act, stream)
-        assert rc == 0, _lib.last_error(None)
-        torch.cuda.synchronize()
-        for g in range(2 if two else 1):
-            ref = torch.nn.functional.linear(x[g].to(bf).double(), w[g][:, :K].double(), b[g].double())
-            if act:
-                ref = torch.nn.functional.elu(ref)
-            assert float(((y[g].double() - ref).abs() / (1.0 + ref.abs())).max()) < 5e-3, (M, N, K, xf32, act, g)
-    assert L.mms_linear2_act_bf16(0, 8, 8, 64, 100, 0, p(x[0]), p(w[0]), p(b[0]), p(y[0]), None, None, None, None, 1, stream) != 0   # ldw % 64
-
-
 def test_fused_act_and_bound_rollout(torch_cuda):
     """ActorCritic.act (fused tail) + RolloutStorage + engine, all zero-copy: slot t of the storage holds exactly what the
     reference's act -> step -> add_transitions sequence would have copied there."""
@@ -1099,7 +1065,7 @@ def test_fused_act_and_bound_rollout(torch_cuda):
     torch.manual_seed(0)
     ac = ActorCritic((388,), (0,), (80,), 0.8, {"pi_hid_sizes": [64, 64], "vf_hid_sizes": [64, 64], "activation": "elu"},
                      seed=11).cuda()
-    ac.fuse_head = True                                            # exercise mms_ppo_head_act through the module (H = 64)
+    ac.fuse_head = True                                            # exercise mms_ppo_heads_act through the module (H = 64)
     st = RolloutStorage(n, T, (388,), (0,), (80,), device="cuda:0")
     ac.bind_rollout(st, eng.tensor("actions"))
     states = torch.zeros(n, 0, device="cuda")

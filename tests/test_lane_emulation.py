@@ -23,8 +23,8 @@ NAMES = ["actions", "obs", "obs_clipped", "rew", "reset", "progress", "root_stat
 
 @pytest.fixture(scope="module")
 def emu():
-    hdr = os.path.join(HERE, "..", "massive_marl_benchmark_amd", "csrc", "mms_lane.h")
-    if not os.path.exists(EMU_LIB) or os.path.getmtime(EMU_LIB) < max(os.path.getmtime(EMU_SRC), os.path.getmtime(hdr)):
+    hdr = os.path.join(HERE, "..", "massive_marl_benchmark_amd", "csrc", "cpu", "lane_step.h")
+    if not os.path.exists(EMU_LIB) or os.path.getmtime(EMU_LIB) < max(os.path.getmtime(EMU_SRC), os.path.getmtime(hdr), os.path.getmtime(os.path.join(os.path.dirname(hdr), "..", "mms_lane.h"))):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                                "-o", EMU_LIB, EMU_SRC])
     lib = ctypes.CDLL(EMU_LIB)
