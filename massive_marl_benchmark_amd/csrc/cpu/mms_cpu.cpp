@@ -386,8 +386,3 @@ MMS_API int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const f
     }
     return 0;
 }
-MMS_API int mms_linear2_act_bf16(int, int64_t, int32_t, int32_t, int32_t, int32_t, const void*, const void*, const float*, void*, const void*,
-                                 const void*, const float*, void*, int32_t, void*) {
-    g_error = "mms_linear2_act_bf16: not part of the CPU build (the bf16 policy series is a GPU measurement)";
-    return 1;
-}
