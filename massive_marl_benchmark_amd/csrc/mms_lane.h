@@ -158,41 +158,50 @@ MMS_HD S6 bias_force_axisym(S6 v, float m, V3 c, V3 u, float ia, float it, float
     p.l = cross(v.a, f) - fg;
     return p;
 }
-// LDL^T solve of a symmetric positive definite 6x6 system
-MMS_HD S6 solve6(const Sym6& A, S6 bv) {
-    float b[6] = {bv.a.x, bv.a.y, bv.a.z, bv.l.x, bv.l.y, bv.l.z};
-    float L[6][6], D[6], y[6], x[6];
+// LDL^T of a symmetric positive definite 6x6 system, split into the factorisation (matrix only) and the two substitutions
+// (right-hand side): the box's matrix is known before its right-hand side is (the ants' reaction arrives through a barrier), so
+// the step kernel factors before the barrier and only substitutes behind it.  solve6 = both, the same arithmetic in the same order.
+struct Ldl6 { float L[15]; float D[6]; };     // L[i][j], i > j, at lidx(i, j); D = the pivots
+constexpr int lidx(int i, int j) { return i * (i - 1) / 2 + j; }
+MMS_HD Ldl6 factor6(const Sym6& A) {
+    Ldl6 F;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         float d = A.m[sidx(j, j)];
 #pragma unroll
-        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
-        D[j] = d;
+        for (int k = 0; k < j; k++) d -= F.L[lidx(j, k)] * F.L[lidx(j, k)] * F.D[k];
+        F.D[j] = d;
         float inv = 1.f / d;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             float s = A.m[sidx(i, j)];
 #pragma unroll
-            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k] * D[k];
-            L[i][j] = s * inv;
+            for (int k = 0; k < j; k++) s -= F.L[lidx(i, k)] * F.L[lidx(j, k)] * F.D[k];
+            F.L[lidx(i, j)] = s * inv;
         }
     }
+    return F;
+}
+MMS_HD S6 substitute6(const Ldl6& F, S6 bv) {
+    float b[6] = {bv.a.x, bv.a.y, bv.a.z, bv.l.x, bv.l.y, bv.l.z};
+    float y[6], x[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         float s = b[i];
 #pragma unroll
-        for (int k = 0; k < i; k++) s -= L[i][k] * y[k];
+        for (int k = 0; k < i; k++) s -= F.L[lidx(i, k)] * y[k];
         y[i] = s;
     }
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
-        float s = y[i] / D[i];
+        float s = y[i] / F.D[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k];
+        for (int k = i + 1; k < 6; k++) s -= F.L[lidx(k, i)] * x[k];
         x[i] = s;
     }
     return S6{V3{x[0], x[1], x[2]}, V3{x[3], x[4], x[5]}};
 }
+MMS_HD S6 solve6(const Sym6& A, S6 bv) { return substitute6(factor6(A), bv); }
 
 // ---------------------------------------------------------------------------------------------
 // contacts (oracle: contact_t / sphere_contacts / contact_fold / contact_force)
@@ -794,7 +803,10 @@ MMS_HD BoxCornerF box_corner_friction(const mms_model* M, float h, const RigidSt
     contact_fold_ground(c, h, o.IA, o.pA);
     return o;
 }
-MMS_HD void box_finish_friction(const mms_model* M, float h, RigidState& B, const M3& R, const BoxCornerF& c, S6 wrench) {
+// ... in two parts: everything that does not need the ants' reaction (matrix, its factorisation, the part of the right-hand side
+// made of gravity, the gyroscopic term and the contacts) and the rest (add the reaction, substitute, integrate)
+struct BoxFactorF { Ldl6 F; S6 rhs0; };
+MMS_HD BoxFactorF box_factor_friction(const mms_model* M, const RigidState& B, const M3& R, const BoxCornerF& c) {
     Sym6 A = c.IA;
     V3 d = V3{M->box_inertia[0], M->box_inertia[1], M->box_inertia[2]};
     float ixx = d.x * R.c0.x * R.c0.x + d.y * R.c1.x * R.c1.x + d.z * R.c2.x * R.c2.x;
@@ -809,13 +821,22 @@ MMS_HD void box_finish_friction(const mms_model* M, float h, RigidState& B, cons
     V3 Iw_w = V3{ixx * B.ang.x + ixy * B.ang.y + ixz * B.ang.z, ixy * B.ang.x + iyy * B.ang.y + iyz * B.ang.z,
                  ixz * B.ang.x + iyz * B.ang.y + izz * B.ang.z};
     V3 gyro = cross(B.ang, Iw_w);
-    S6 rhs = S6{wrench.a - gyro - c.pA.a, wrench.l + V3{0.f, 0.f, -M->box_mass * M->gravity} - c.pA.l};
-    S6 acc = solve6(A, rhs);
+    BoxFactorF o;
+    o.F = factor6(A);
+    o.rhs0 = S6{V3{0.f, 0.f, 0.f} - gyro - c.pA.a, V3{0.f, 0.f, -M->box_mass * M->gravity} - c.pA.l};
+    return o;
+}
+MMS_HD void box_solve_friction(float h, RigidState& B, const BoxFactorF& f, S6 wrench) {
+    S6 rhs = S6{wrench.a + f.rhs0.a, wrench.l + f.rhs0.l};
+    S6 acc = substitute6(f.F, rhs);
     B.ang = B.ang + h * acc.a;
     B.vel = B.vel + h * acc.l;
     clamp_angvel(B.ang, kMaxAngVel);
     B.pos = B.pos + h * B.vel;
     quat_integrate(B.qx, B.qy, B.qz, B.qw, B.ang, h);
+}
+MMS_HD void box_finish_friction(const mms_model* M, float h, RigidState& B, const M3& R, const BoxCornerF& c, S6 wrench) {
+    box_solve_friction(h, B, box_factor_friction(M, B, R, c), wrench);
 }
 
 // ---------------------------------------------------------------------------------------------

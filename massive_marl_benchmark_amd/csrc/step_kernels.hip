@@ -94,7 +94,7 @@ __device__ __forceinline__ void store_rigid(float* r, const RigidState& B) {
 #define MMS_WAVES_PER_EU 2      // one-wave envs: 2 waves per SIMD; 3 and 4 need spills and measured slower (profiles/r01_v3_bench_wpe*.json)
 #endif
 __host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
-    return (size_t)((obs_dim + 3) & ~3) + 16 + (sizeof(BoxPose) + 15) / 16 * 4 + 8 + 8 + (size_t)(((RP_STRIDE + 6) * A + 3) & ~3) +
+    return (size_t)((obs_dim + 3) & ~3) + 16 + (sizeof(BoxPose) + 15) / 16 * 4 + 28 + 8 + (size_t)(((RP_STRIDE + 6) * A + 3) & ~3) +
            (size_t)((4 * A + 2 + 7 + 3) & ~3);     // + staging of the epilogue's inputs (prev_dim <= 4A+2, origin, progress, reset count)
 }
 // Residency target: TenAnt at 4096 envs is 1024 blocks x 3 waves = 3072 waves = exactly 3 per SIMD on 256 CUs, so the whole
@@ -106,8 +106,12 @@ __host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
 // DR: per-env physical domain randomisation (mass / damping scales, limit offsets) read from a.dr; a separate instantiation so
 // that the nominal kernel carries none of it.
 template <int TASK, int BLOCK, int EPB, int AT, bool DR>
+// The 512-thread layout (the runtime-sized one: the 100-ant swarm) is held to 168 VGPRs as well.  Its eight waves are two per SIMD
+// and a second block never fits beside them, so the register count looks free -- it is not: at 182-194 VGPRs (what the compiler takes
+// when allowed 256) the same instruction stream, counter for counter (SQ_INSTS_*, SQ_WAVE_CYCLES, I-cache misses), took 214-232 us
+// against 162-166 us at <= 168 for 2048 x 100 ants (profiles/r02_swarm_occupancy.txt).
 #ifndef MMS_WAVES_PER_EU_WIDE
-#define MMS_WAVES_PER_EU_WIDE 1
+#define MMS_WAVES_PER_EU_WIDE 3
 #endif
 __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOCK == 192 || BLOCK == 768) ? MMS_WAVES_PER_EU_PACKED : MMS_WAVES_PER_EU_WIDE)) ant_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -122,7 +126,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     const int A = AT > 0 ? AT : a.num_agents;
     const int LA = 4 * A;                                     // ant lanes per env
     const int ant_region = EPB * LA;
-    const int box_region = (ant_region + 7) & ~7;
+    // The box-corner lanes follow the ant lanes, 8-aligned -- in the 512-thread layout on a WAVE OF THEIR OWN (lane 448 on) whenever
+    // the ants leave the last wave free (up to 112 ants): the corner terms, their reduction and the factorisation of the box's matrix
+    // then run beside the ant waves instead of lengthening the one wave that would hold both (one block per CU: nothing else hides it).
+    const int box_region = (BLOCK == 512 && EPB == 1 && ant_region <= 448) ? 448 : ((ant_region + 7) & ~7);
     const int bt = (int)threadIdx.x - box_region;             // index among the box lanes
     const bool is_ant = (int)threadIdx.x < ant_region;
     const bool is_box = bt >= 0 && bt < 8 * EPB;
@@ -142,16 +149,25 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     // costs ~55 VGPRs per lane for values that are wave-uniform or 4-periodic
     LegConst* s_leg = reinterpret_cast<LegConst*>(lds + kCfgFloats);               // [4], shared by the block
     // per-env LDS block: the fixed-size parts first, at compile-time offsets from one lane-varying base
-    constexpr int kBoxOff = 0, kBpOff = 16, kWtotOff = kBpOff + (int)((sizeof(BoxPose) + 15) / 16 * 4), kEpiOff = kWtotOff + 8, kRedOff = kEpiOff + 8;
+    constexpr int kBoxOff = 0, kBpOff = 16, kFacOff = kBpOff + (int)((sizeof(BoxPose) + 15) / 16 * 4), kEpiOff = kFacOff + 28, kRedOff = kEpiOff + 8;
     const size_t env_stride = (ant_env_lds_floats(obs_dim, A) + 3) & ~(size_t)3;
     float* lds_envs = lds + kCfgFloats + (4 * sizeof(LegConst) + 15) / 16 * 4;
-    // behind the env blocks: six 16-B words per lane where a leg lane parks its joint axes between the two passes of a substep
-    float* lds_lanes = lds_envs + (size_t)EPB * ((ant_env_lds_floats(AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim, A) + 3) & ~(size_t)3);
+    // behind the env blocks: the block's slice of root_states, staged.  The EPB envs of a block are CONTIGUOUS in HBM (572 B per TenAnt
+    // env): the slice comes in as coalesced 16-B loads (nine 1-KB wave transactions for 16 envs) and every lane takes its torso --
+    // and the box lead its box -- from LDS, instead of 13 scalar dword loads per lane with four lanes of a quad fetching the same 52
+    // bytes (each such wave load touched ~26 cache lines).  The way back is the same: final poses into LDS, coalesced stores out.
+    float* s_root = lds_envs + (size_t)EPB * ((ant_env_lds_floats(AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim, A) + 3) & ~(size_t)3);
+    // (compile-time layouts whose slice starts and ends on 16 B only; the runtime-sized layouts load and store per lane)
+    constexpr bool kStage = AT > 0 && ((EPB * (AT + 1) * 13) % 4) == 0;
+    const int root_floats = kStage ? EPB * (A + 1) * 13 : 0;
+    // behind it: six 16-B words per lane where a leg lane parks its joint axes between the two passes of a substep
+    float* lds_lanes = s_root + ((root_floats + 3) & ~3);
     const KinPark park{lds_lanes + 4 * threadIdx.x, 4 * BLOCK};
     LegDR* s_dr = reinterpret_cast<LegDR*>(lds_lanes + 6 * 4 * BLOCK) + threadIdx.x;     // (DR kernels only) this lane's slice
     float* env_lds = lds_envs + (size_t)e_loc * env_stride;
     float* s_box = env_lds + kBoxOff;              // [16] box rigid state (home of the box between phases)
     BoxPose* s_bp = reinterpret_cast<BoxPose*>(env_lds + kBpOff);
+    float4* s_fac = reinterpret_cast<float4*>(env_lds + kFacOff);   // [7] the factored box matrix + its right-hand side, parked across the barrier
     float* s_epi = env_lds + kEpiOff;              // [8] box values the ant lanes need in the epilogue: global x, y, sin, -cos of the yaw
     float* s_red = env_lds + kRedOff;              // [A][RP_STRIDE] reward partials
     float* s_wr = s_red + RP_STRIDE * A;           // [6][A] per-ant reactions on the box
@@ -173,12 +189,26 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     // single residency round are in their prologue at the same time, so a second round trip would not be hidden by anything.
     AntLane S = {};
     float2 ac = make_float2(0.f, 0.f);
-    if (is_ant) {
+    if (kStage) {
+        const size_t g0 = (size_t)blockIdx.x * root_floats, gtot = (size_t)a.num_envs * actors * 13;
+        if (g0 + root_floats <= gtot) {
+            const float4* src = reinterpret_cast<const float4*>(a.root_states + g0);
+            for (int i = threadIdx.x; i < root_floats / 4; i += BLOCK) reinterpret_cast<float4*>(s_root)[i] = src[i];
+        } else {                                                                    // the partial last block:
+            for (int i = threadIdx.x; i < root_floats; i += BLOCK) {                // envs past the end read the last env (never stored)
+                size_t f = g0 + i;
+                if (f >= gtot) f = gtot - (size_t)actors * 13 + (f % ((size_t)actors * 13));
+                s_root[i] = a.root_states[f];
+            }
+        }
+    } else if (is_ant) {
         const float* r = a.root_states + ((size_t)env * actors + ant) * 13;
         S.pos = V3{r[0], r[1], r[2]};
         S.qx = r[3]; S.qy = r[4]; S.qz = r[5]; S.qw = r[6];
         S.vel = V3{r[7], r[8], r[9]};
         S.ang = V3{r[10], r[11], r[12]};
+    }
+    if (is_ant) {
         float4 d = reinterpret_cast<const float4*>(a.dof_state + (size_t)env * A * 16)[tid];   // (q1, qd1, q2, qd2): coalesced 16 B / lane
         S.q[0] = d.x; S.qd[0] = d.y; S.q[1] = d.z; S.qd[1] = d.w;
         ac = reinterpret_cast<const float2*>(a.actions + (size_t)env * A * 8)[tid];             // this lane's two actions
@@ -186,12 +216,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     }
     for (int i = threadIdx.x; i < (int)(sizeof(mms_config) / 4); i += BLOCK) lds[i] = reinterpret_cast<const float*>(Cg)[i];
     if (threadIdx.x < 4) s_leg[threadIdx.x] = load_leg_const(&Cg->model, threadIdx.x);
-    if (box_lead) {
-        RigidState B0 = load_rigid(a.root_states + ((size_t)env * actors + A) * 13);
-        store_rigid(s_box, B0);
-        s_bp->pos = B0.pos; s_bp->R = quat_to_mat(B0.qx, B0.qy, B0.qz, B0.qw); s_bp->v = B0.vel; s_bp->w = B0.ang;
-        s_bp->half = V3{Cg->model.box_half[0], Cg->model.box_half[1], Cg->model.box_half[2]};
-    }
+
     for (int i = threadIdx.x; i < EPB * prev_dim; i += BLOCK) {       // the caches of the block's envs are contiguous in HBM
         const int e = i / prev_dim, k = i - e * prev_dim;
         const int en = min((int)(blockIdx.x * EPB + e), a.num_envs - 1);
@@ -208,7 +233,22 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
         s_act[0] = clampf(ac.x, -Cg->clip_actions, Cg->clip_actions);     // vec_task.py:127
         s_act[1] = clampf(ac.y, -Cg->clip_actions, Cg->clip_actions);
     }
-    __syncthreads();
+    if (kStage) __syncthreads();
+    if (kStage && is_ant) {                                          // this lane's torso from the staged slice
+        const float* r = s_root + (e_loc * actors + ant) * 13;
+        S.pos = V3{r[0], r[1], r[2]};
+        S.qx = r[3]; S.qy = r[4]; S.qz = r[5]; S.qw = r[6];
+        S.vel = V3{r[7], r[8], r[9]};
+        S.ang = V3{r[10], r[11], r[12]};
+    }
+    if (box_lead) {
+        RigidState B0 = load_rigid(kStage ? s_root + (e_loc * actors + A) * 13 : a.root_states + ((size_t)env * actors + A) * 13);
+        store_rigid(s_box, B0);
+        s_bp->pos = B0.pos; s_bp->R = quat_to_mat(B0.qx, B0.qy, B0.qz, B0.qw); s_bp->v = B0.vel; s_bp->w = B0.ang;
+        const mms_model* Mb = kStage ? &C->model : &Cg->model;          // (the LDS copy is valid behind the first barrier only)
+        s_bp->half = V3{Mb->box_half[0], Mb->box_half[1], Mb->box_half[2]};
+    }
+    __syncthreads();                                                 // the box pose is read by the ant lanes of the first substep
     const LegConst& L = s_leg[leg];
     float sens[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (TASK == MMS_TASK_ONE_ANT && is_ant) {      // sensors of the last simulated substep persist across a skipped step
@@ -258,9 +298,11 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
                 const float* col = s_wr + corner * A;
                 for (int i = 0; i < A; i++) t += col[i];
             }
-            const int g0 = (int)(threadIdx.x & 63u) & ~7;
-            return S6{V3{__shfl(t, g0 + 0, 64), __shfl(t, g0 + 1, 64), __shfl(t, g0 + 2, 64)},
-                      V3{__shfl(t, g0 + 3, 64), __shfl(t, g0 + 4, 64), __shfl(t, g0 + 5, 64)}};
+            // lane c of each 8-group to the whole group: ds_swizzle in bit mode (lane' = (lane & 0x18) | c within each 32), the
+            // pattern an immediate -- six bpermute address registers hoisted out of the substep loop were being spilled
+#define MMS_FROM(c) __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(t), 0x18 | ((c) << 5)))
+            return S6{V3{MMS_FROM(0), MMS_FROM(1), MMS_FROM(2)}, V3{MMS_FROM(3), MMS_FROM(4), MMS_FROM(5)}};
+#undef MMS_FROM
         };
         auto box_store = [&](const RigidState& B) {
             store_rigid(s_box, B);
@@ -274,17 +316,27 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
             // lanes evaluate and reduce them BEFORE the barrier -- in the layouts whose box lanes fill waves of their own that is time in which those waves would
             // only wait for the ant lanes; after the barrier the box needs the wrench, one small solve and the integration.
             BoxCorner bc = {};
-            BoxCornerF bf;
             if (is_box && !box_friction) {
                 bc = box_corner(M, h, load_rigid(s_box), s_bp->R, corner);
                 oct_sum(bc);
             }
             if (is_box && box_friction) {
-                bf = box_corner_friction(M, h, load_rigid(s_box), s_bp->R, corner);
+                // with friction: the corner terms, their reduction AND the factorisation of the box's 6x6 matrix (it does not depend
+                // on the wrench) before the barrier; behind it only the two substitutions and the integration are serial
+                const RigidState B0 = load_rigid(s_box);
+                BoxCornerF bf = box_corner_friction(M, h, B0, s_bp->R, corner);
 #pragma unroll
                 for (int k = 0; k < 21; k++) bf.IA.m[k] = oct_sum(bf.IA.m[k]);
                 bf.pA.a.x = oct_sum(bf.pA.a.x); bf.pA.a.y = oct_sum(bf.pA.a.y); bf.pA.a.z = oct_sum(bf.pA.a.z);
                 bf.pA.l.x = oct_sum(bf.pA.l.x); bf.pA.l.y = oct_sum(bf.pA.l.y); bf.pA.l.z = oct_sum(bf.pA.l.z);
+                static_assert(sizeof(BoxFactorF) == 27 * 4, "parked as seven 16-B words");
+                union { BoxFactorF f; float4 q[7]; } u;              // 27 floats: parked in LDS, not carried across the barrier (on top of
+                u.q[6] = make_float4(0.f, 0.f, 0.f, 0.f);            // the ant lanes' live state they were being spilled to scratch)
+                u.f = box_factor_friction(M, B0, s_bp->R, bf);
+                if (corner == 0) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) s_fac[k] = u.q[k];
+                }
             }
             S6 w = S6{V3{0, 0, 0}, V3{0, 0, 0}};
             if (kOneWave) {                                          // one wave per env: the reaction wrench by DPP / permute
@@ -298,7 +350,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
                 RigidState B = load_rigid(s_box);                    // (again: cheaper than carrying 22 values across the barrier)
                 M3 R = s_bp->R;
                 if (box_friction) {
-                    if (simulate) box_finish_friction(M, h, B, R, bf, w);
+                    union { BoxFactorF f; float4 q[7]; } u;
+#pragma unroll
+                    for (int k = 0; k < 7; k++) u.q[k] = s_fac[k];
+                    if (simulate) box_solve_friction(h, B, u.f, w);
                 } else if (simulate) box_finish(M, h, B, R, bc, w);
                 if (corner == 0) box_store(B);
             }
@@ -309,7 +364,6 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     // ---- post_physics_step: progress, reset_idx (ten_ant.py:894-901) --------------------------
     int env_e = env;
     asm volatile("" : "+v"(env_e));                 // opaque copy: per-env addresses are re-formed here, not carried through the loop
-    float* root_env = a.root_states + (size_t)env_e * actors * 13;
     const float* init_env = a.initial_root_states + (size_t)env_e * actors * 13;
     float* dof_env = a.dof_state + (size_t)env_e * A * 16;
     float* prev_env = a.prev + (size_t)env_e * prev_dim;
@@ -325,7 +379,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     if (is_ant && live) {
         reinterpret_cast<float4*>(dof_env)[tid] = make_float4(S.q[0], S.qd[0], S.q[1], S.qd[1]);
         if (leg == 0) {
-            float* r = root_env + 13 * ant;
+            // (into the staged slice, which leaves with the observation rows; the runtime-sized layouts store per lane)
+            float* r = kStage ? s_root + (e_loc * actors + ant) * 13 : a.root_states + ((size_t)env_e * actors + ant) * 13;
             r[0] = S.pos.x; r[1] = S.pos.y; r[2] = S.pos.z; r[3] = S.qx; r[4] = S.qy; r[5] = S.qz; r[6] = S.qw;
             r[7] = S.vel.x; r[8] = S.vel.y; r[9] = S.vel.z; r[10] = S.ang.x; r[11] = S.ang.y; r[12] = S.ang.z;
         }
@@ -335,7 +390,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     RigidState B = {};
     if (box_lead) {
         B = reset_now ? load_rigid(init_env + 13 * A) : load_rigid(s_box);
-        if (live) store_rigid(root_env + 13 * A, B);
+        if (live) store_rigid(kStage ? s_root + (e_loc * actors + A) * 13 : a.root_states + ((size_t)env_e * actors + A) * 13, B);
         const float bgx = B.pos.x + origin.x, bgy = B.pos.y + origin.y;      // global frame
         s_epi[0] = bgx; s_epi[1] = bgy;
         if (TASK == MMS_TASK_TEN_ANT) {
@@ -416,6 +471,17 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
         }
     }
     if (reset_now && box_lead && live) a.reset_count[env_e] = reset_count + 1;   // every lane of the env read it before the barriers above
+    // ---- the staged root slice back to HBM: coalesced 16-B stores (live envs only) ----------------------------------
+    if (kStage) {
+        const size_t g0 = (size_t)blockIdx.x * root_floats, gtot = (size_t)a.num_envs * actors * 13;
+        if (g0 + root_floats <= gtot) {
+            float4* dst = reinterpret_cast<float4*>(a.root_states + g0);
+            for (int i = threadIdx.x; i < root_floats / 4; i += BLOCK) dst[i] = reinterpret_cast<const float4*>(s_root)[i];
+        } else {
+            for (int i = threadIdx.x; i < root_floats; i += BLOCK)
+                if (g0 + i < gtot) a.root_states[g0 + i] = s_root[i];
+        }
+    }
     // ---- coalesced observation row(s): the block's EPB rows are contiguous in HBM ---------------------------------
     {
         const int e0 = blockIdx.x * EPB;
@@ -550,6 +616,7 @@ __global__ void __launch_bounds__(256) ingenuity_step_kernel(StepArgs a) {
 template <int TASK, int BLOCK, int EPB, int AT>
 static hipError_t launch_ant(const StepArgs& a, hipStream_t stream) {
     size_t lds = (sizeof(mms_config) + 15) / 16 * 16 + (4 * sizeof(LegConst) + 15) / 16 * 16 + (size_t)EPB * ((ant_env_lds_floats(a.obs_dim, a.num_agents) + 3) & ~(size_t)3) * sizeof(float) +
+                 ((AT > 0 && (EPB * (AT + 1) * 13) % 4 == 0) ? (size_t)(EPB * (AT + 1) * 13) * sizeof(float) : 0) +   // + the staged root slice (kStage)
                  (size_t)6 * 4 * BLOCK * sizeof(float);          // + the kinematics parking space
     int grid = (a.num_envs + EPB - 1) / EPB;
     if (a.dr) lds += (size_t)BLOCK * sizeof(LegDR);
