@@ -31,6 +31,8 @@
  *   ActorCritic.act sampling tail + RolloutStorage.add_transitions       mms_ppo_act, mms_ppo_heads_act,
  *     (algorithms/rl/ppo/module.py:73-87; storage.py:33-47)              mms_bind_rollout_out
  *   ActorCritic hidden layers (module.py:27-52)                          mms_linear2_act
+ *   Actor / Critic forward of every MAPPO / HAPPO agent                  mms_linear_group_act, mms_layernorm_group,
+ *     (algorithms/marl/actor_critic.py:43-69, 137-155; runner.py:186-216)  mms_marl_heads_act
  *
  * Ownership: the engine owns every buffer it reports through mms_get_tensor for the lifetime of the
  * handle; callers wrap them as NON-owning views and must keep the handle alive while any view exists.
@@ -237,6 +239,38 @@ int mms_ppo_heads_act(int device, const float* hidden, const float* weight, cons
  * x1 = w1 = b1 = y1 = NULL runs a single problem.  x0 and x1 may be the same buffer (first layer). */
 int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const float* x0, const float* w0, const float* b0, float* y0,
                     const float* x1, const float* w1, const float* b1, float* y1, int32_t act, void* hip_stream);
+
+/* ---- MAPPO / HAPPO policy inference: every layer of ALL agents' networks per launch ------------------------------------------
+ * The reference's collect step (algorithms/marl/runner.py:186-216) calls, agent by agent, policy.get_actions -> Actor.forward
+ * (algorithms/marl/actor_critic.py:43-69) and Critic.forward (:137-155): MLPBase (algorithms/utils/mlp.py:38-65) = LayerNorm of
+ * the input, then layer_N + 1 blocks of Linear + ELU + LayerNorm (:5-36); ACTLayer / DiagGaussian (utils/act.py:75-81,
+ * utils/distributions.py:94-117) = Linear mean head, std = sigmoid(log_std / std_x_coef) * std_y_coef, sample, summed
+ * log-probability; v_out = Linear(hidden, 1).  The three operators below run one such stage for up to MMS_MAX_GROUPS networks
+ * of the same shape at once (ten actors + ten critics of TenAnt's MAPPO: 20).  The pointer arguments are HOST arrays of
+ * `groups` device pointers.  Recurrent policies (use_recurrent_policy) are not covered. */
+#define MMS_MAX_GROUPS 32
+
+/* y_g = act(x_g @ w_g^T + b_g), g < groups: mms_linear2_act for any number of networks (same kernel, same shapes rules). */
+int mms_linear_group_act(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const float* const* x, const float* const* w,
+                         const float* const* b, float* const* y, int32_t act, void* hip_stream);
+
+/* nn.LayerNorm over the last dimension (biased variance, eps inside the root): y_g[r, 0:K] = LN(x_g[r, 0:K]) * gamma_g + beta_g,
+ * y_g[r, K:Kp] = 0.  x rows have pitch K, y rows pitch Kp >= K (Kp > K pads a 46-wide observation to the multiple of 4 the layer
+ * kernel wants); y_g == x_g with Kp == K is the in-place form.  K <= 1024. */
+int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, const float* const* x, const float* const* gamma,
+                        const float* const* beta, float* const* y, float eps, void* hip_stream);
+
+/* The last LayerNorm + the output layer (+ the Gaussian sample) of each network: out_g[r, j] = b_g[j] + sum_k w_g[j, k] *
+ * LN(h_g[r])[k], j < A[g] <= 16, H <= 1024.  std[g] != NULL ([A[g]] standard deviations): out_g = that mean + std z with z ~ N(0,1)
+ * from the counter-based stream keyed (seed + g, row_offset + r, counters[g][r], j) (counters[g][r] += 1; counters or counters[g]
+ * NULL: counter 0), and logp[g][r, j] = log N(out_j | mean_j, std_j), PER DIMENSION, [M, A[g]] (FixedNormal.log_probs,
+ * distributions.py:31-34, does not sum over the action dimensions).  std == NULL or
+ * std[g] == NULL: out_g is the plain output (the critic's value; a deterministic action).  The noise stream is this build's, not
+ * torch's Philox: sampled actions differ from the reference's draw for the same torch seed, their distribution does not. */
+int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H, const float* const* h, const float* const* gamma,
+                       const float* const* beta, const float* const* w, const float* const* b, const int32_t* A, const float* const* std,
+                       float* const* out, float* const* logp, int64_t* const* counters, uint64_t seed, int64_t row_offset, float eps,
+                       void* hip_stream);
 
 const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
 int mms_abi_version(void);

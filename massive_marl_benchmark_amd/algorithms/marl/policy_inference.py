@@ -1,0 +1,203 @@
+"""All agents' `get_actions` of a MAPPO / HAPPO / IPPO collect step in a few grouped launches.
+
+The reference's Runner.collect (agents/algorithms/marl/runner.py:186-216) walks the agents and calls, per agent,
+`trainer.policy.get_actions(share_obs, obs, rnn_states, rnn_states_critic, masks)` -> Actor.forward
+(agents/algorithms/marl/actor_critic.py:43-69) + Critic.forward (:137-155): about thirty small launches per agent, ten agents per
+step for TenAnt.  The networks are independent and of the same shape, so here every stage runs ONCE for all of them:
+
+    feature LayerNorm (utils/mlp.py:52-53, 59-60)     mms_layernorm_group   actors (obs, padded to a multiple of 4) | critics (share_obs)
+    fc1: Linear + ELU (mlp.py:19-20)                  mms_linear_group_act  actors (K = obs) | critics (K = share_obs)
+    its LayerNorm                                     mms_layernorm_group   all networks, in place
+    fc2[i]: Linear + ELU + LayerNorm (mlp.py:26-27)   one mms_linear_group_act + one mms_layernorm_group (in place) each, all networks
+    last LayerNorm + fc_mean + sample + log-probs     mms_marl_heads_act    all networks (critics: v_out, no sampling)
+      (utils/act.py:75-81, distributions.py:94-117;
+       actor_critic.py:153)
+
+`GroupedPolicyInference` takes the agents' Actor / Critic modules AS THEY ARE (the reference's classes, or anything with the same
+attributes: `.base.feature_norm`, `.base.mlp.fc1`, `.base.mlp.fc2`, `.act.action_out.{fc_mean, log_std, std_x_coef, std_y_coef}`,
+`.v_out`) and reads their parameters in place: an optimizer step needs no copy back, only `refresh()` for the zero-padded copy of
+the actors' first weight matrix (46 -> 48 columns).  Recurrent policies (use_recurrent_policy / use_naive_recurrent_policy) and
+non-Box action spaces are not covered: the constructor raises, nothing falls back silently.
+
+The noise stream is this build's counter-based generator (seed + agent, global env row, per-row draw counter), as in
+rl/ppo/module.py: the sampled actions differ from torch's draw for the same torch seed, their distribution and the returned
+log-probabilities do not.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+
+
+def _blocks(base):
+    """[(Linear, LayerNorm)] of an MLPBase: fc1, then fc2[0 .. layer_N)."""
+    mlp = base.mlp
+    seqs = [mlp.fc1] + list(mlp.fc2)[:getattr(mlp, "_layer_N", len(mlp.fc2))]
+    out = []
+    for s in seqs:
+        lin, act, ln = s[0], s[1], s[2]
+        if not (isinstance(lin, nn.Linear) and isinstance(act, nn.ELU) and act.alpha == 1.0 and isinstance(ln, nn.LayerNorm) and len(s) == 3):
+            raise NotImplementedError("GroupedPolicyInference: blocks must be Linear + ELU(alpha 1) + LayerNorm (utils/mlp.py:19-27), got %r" % (s,))
+        if lin.bias is None or ln.weight is None or ln.bias is None:
+            raise NotImplementedError("GroupedPolicyInference: Linear bias and LayerNorm affine parameters are required")
+        out.append((lin, ln))
+    return out
+
+
+def _ptrs(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        if t is not None:
+            if t.dtype not in (torch.float32, torch.int64) or not t.is_contiguous():
+                raise ValueError("GroupedPolicyInference: operands must be contiguous float32")
+            arr[i] = t.data_ptr()
+    return arr
+
+
+class GroupedPolicyInference:
+    def __init__(self, actors, critics, seed=0, row_offset=0):
+        if len(actors) != len(critics) or not actors:
+            raise ValueError("one actor and one critic per agent")
+        if 2 * len(actors) > 32:
+            raise ValueError("at most 16 agents per GroupedPolicyInference (MMS_MAX_GROUPS = 32 networks per launch)")
+        for m in list(actors) + list(critics):
+            if getattr(m, "_use_recurrent_policy", False) or getattr(m, "_use_naive_recurrent_policy", False):
+                raise NotImplementedError("GroupedPolicyInference: recurrent policies are not covered (actor_critic.py:64-65)")
+            if not getattr(m.base, "_use_feature_normalization", hasattr(m.base, "feature_norm")):
+                raise NotImplementedError("GroupedPolicyInference: use_feature_normalization = False is not covered")
+        self.actors, self.critics = list(actors), list(critics)
+        self.n = len(actors)
+        self.seed, self.row_offset = int(seed), int(row_offset)
+        self.a_blocks = [_blocks(a.base) for a in self.actors]
+        self.c_blocks = [_blocks(c.base) for c in self.critics]
+        depth = {len(b) for b in self.a_blocks + self.c_blocks}
+        hidden = {lin.out_features for b in self.a_blocks + self.c_blocks for (lin, _) in b}
+        if len(depth) != 1 or len(hidden) != 1:
+            raise NotImplementedError("GroupedPolicyInference: all networks must have the same depth and hidden size")
+        self.depth, self.hidden = depth.pop(), hidden.pop()
+        heads = [a.act.action_out for a in self.actors]
+        for hd in heads:
+            if not (hasattr(hd, "fc_mean") and hasattr(hd, "log_std")):
+                raise NotImplementedError("GroupedPolicyInference: only the DiagGaussian head (Box action spaces) is covered (utils/act.py:21-23)")
+        self.obs_dim = {b[0][0].in_features for b in self.a_blocks}
+        self.sobs_dim = {b[0][0].in_features for b in self.c_blocks}
+        self.act_dim = {hd.fc_mean.out_features for hd in heads}
+        if len(self.obs_dim) != 1 or len(self.sobs_dim) != 1 or len(self.act_dim) != 1:
+            raise NotImplementedError("GroupedPolicyInference: agents must share observation / action widths")
+        self.obs_dim, self.sobs_dim, self.act_dim = self.obs_dim.pop(), self.sobs_dim.pop(), self.act_dim.pop()
+        if self.act_dim > 16 or self.hidden > 1024 or self.hidden % 4:
+            raise NotImplementedError("GroupedPolicyInference: at most 16 actions, hidden size a multiple of 4 up to 1024")
+        self.eps = float(self.actors[0].base.feature_norm.eps)
+        self.device = self.actors[0].act.action_out.fc_mean.weight.device
+        self._M = None
+        self.refresh()
+
+    # -- parameters ---------------------------------------------------------------------------------------------------------------
+    def refresh(self):
+        """Call after the parameters changed (an optimizer step): rebuilds the zero-padded first actor weights and the std vectors;
+        everything else is read from the modules' own storage."""
+        dev, n = self.device, self.n
+        d = lambda t: t.detach()
+        self.kp_a = (self.obs_dim + 3) & ~3
+        self.kp_c = (self.sobs_dim + 3) & ~3
+
+        def padded(blocks, k, kp):
+            ws = [d(b[0][0].weight) for b in blocks]
+            if kp == k:
+                return ws
+            w = torch.zeros(len(blocks), self.hidden, kp, device=dev)
+            w[:, :, :k] = torch.stack(ws)
+            return list(w.unbind(0))
+        self._w1_a = padded(self.a_blocks, self.obs_dim, self.kp_a)
+        self._w1_c = padded(self.c_blocks, self.sobs_dim, self.kp_c)
+        heads = [a.act.action_out for a in self.actors]
+        self._std = [(torch.sigmoid(d(hd.log_std) / hd.std_x_coef) * hd.std_y_coef).float().contiguous() for hd in heads]   # distributions.py:116
+        self._bind()
+
+    def _bind(self):
+        d = lambda t: t.detach()
+        A, C = self.a_blocks, self.c_blocks
+        fa = [a.base.feature_norm for a in self.actors]
+        fc = [c.base.feature_norm for c in self.critics]
+        self._keep = []                                           # (tensors whose addresses sit in the pointer arrays)
+
+        def arr(ts):
+            ts = [None if t is None else t for t in ts]
+            self._keep.append(ts)
+            return _ptrs(ts)
+        self.p = {
+            "fn_a_g": arr([d(m.weight) for m in fa]), "fn_a_b": arr([d(m.bias) for m in fa]),
+            "fn_c_g": arr([d(m.weight) for m in fc]), "fn_c_b": arr([d(m.bias) for m in fc]),
+            "w1_a": arr(self._w1_a), "b1_a": arr([d(b[0][0].bias) for b in A]),
+            "w1_c": arr(self._w1_c), "b1_c": arr([d(b[0][0].bias) for b in C]),
+        }
+        both = A + C
+        for l in range(self.depth):
+            self.p["ln%d_g" % l] = arr([d(b[l][1].weight) for b in both])
+            self.p["ln%d_b" % l] = arr([d(b[l][1].bias) for b in both])
+            if l > 0:
+                self.p["w%d" % l] = arr([d(b[l][0].weight) for b in both])
+                self.p["b%d" % l] = arr([d(b[l][0].bias) for b in both])
+        heads = [a.act.action_out.fc_mean for a in self.actors]
+        vouts = [c.v_out for c in self.critics]
+        self.p["hw"] = arr([d(m.weight) for m in heads] + [d(m.weight) for m in vouts])
+        self.p["hb"] = arr([d(m.bias) for m in heads] + [d(m.bias) for m in vouts])
+        self.p["std"] = arr(self._std + [None] * self.n)
+        self.p["std_none"] = arr([None] * (2 * self.n))
+        self._A = (ctypes.c_int32 * (2 * self.n))(*([self.act_dim] * self.n + [1] * self.n))
+
+    def _buffers(self, M):
+        if self._M == M:
+            return
+        dev, n, H = self.device, self.n, self.hidden
+        z = lambda *s, **k: torch.empty(*s, device=dev, **k)
+        self.x_a, self.x_c = z(n, M, self.kp_a), z(n, M, self.kp_c)                    # normalised (and padded) inputs
+        self.h = [z(2 * n, M, H), z(2 * n, M, H)]                                     # hidden activations, ping-pong
+        self.actions, self.logp, self.values = z(n, M, self.act_dim), z(n, M, self.act_dim), z(n, M, 1)
+        self.counters = torch.zeros(n, M, dtype=torch.int64, device=dev)
+        ub = lambda t: list(t.unbind(0))
+        self.q = {
+            "x_a": _ptrs(ub(self.x_a)), "x_c": _ptrs(ub(self.x_c)),
+            "h0": _ptrs(ub(self.h[0])), "h1": _ptrs(ub(self.h[1])),
+            "h0_a": _ptrs(ub(self.h[0][:n])), "h0_c": _ptrs(ub(self.h[0][n:])),
+            "out": _ptrs(ub(self.actions) + ub(self.values)), "logp": _ptrs(ub(self.logp) + [None] * n),
+            "cnt": _ptrs(ub(self.counters) + [None] * n),
+        }
+        self._M = M
+
+    # -- inference ----------------------------------------------------------------------------------------------------------------
+    def get_actions(self, share_obs, obs, deterministic=False):
+        """share_obs, obs: per-agent lists of [M, share_obs_dim] / [M, obs_dim] float32 tensors (what the Runner hands agent i:
+        buffer[i].share_obs[step], buffer[i].obs[step]).  Returns (values, actions, action_log_probs): per-agent lists of
+        [M, 1], [M, act_dim], [M, act_dim] views of buffers that the next call overwrites (the reference's
+        FixedNormal.log_probs keeps the per-dimension log-densities, utils/distributions.py:31-34)."""
+        n = self.n
+        if len(share_obs) != n or len(obs) != n:
+            raise ValueError("one observation tensor per agent")
+        M = obs[0].shape[0]
+        self._buffers(M)
+        L, idx, stream = _lib.for_device(self.device)
+        p, q = self.p, self.q
+        chk = lambda rc, what: _lib.check(rc, None, what, L)
+        f32 = lambda t: t.detach().float().contiguous()
+        obs, share_obs = [f32(t) for t in obs], [f32(t) for t in share_obs]
+        chk(L.mms_layernorm_group(idx, n, M, self.obs_dim, self.kp_a, _ptrs(obs), p["fn_a_g"], p["fn_a_b"], q["x_a"], self.eps, stream), "mms_layernorm_group")
+        chk(L.mms_layernorm_group(idx, n, M, self.sobs_dim, self.kp_c, _ptrs(share_obs), p["fn_c_g"], p["fn_c_b"], q["x_c"], self.eps, stream), "mms_layernorm_group")
+        H = self.hidden
+        chk(L.mms_linear_group_act(idx, n, M, H, self.kp_a, q["x_a"], p["w1_a"], p["b1_a"], q["h0_a"], 1, stream), "mms_linear_group_act")
+        chk(L.mms_linear_group_act(idx, n, M, H, self.kp_c, q["x_c"], p["w1_c"], p["b1_c"], q["h0_c"], 1, stream), "mms_linear_group_act")
+        cur = 0
+        for l in range(self.depth):
+            if l > 0:
+                chk(L.mms_linear_group_act(idx, 2 * n, M, H, H, q["h%d" % cur], p["w%d" % l], p["b%d" % l], q["h%d" % (1 - cur)], 1, stream), "mms_linear_group_act")
+                cur = 1 - cur
+            if l + 1 < self.depth:                                  # (the last LayerNorm runs inside the heads kernel)
+                chk(L.mms_layernorm_group(idx, 2 * n, M, H, H, q["h%d" % cur], p["ln%d_g" % l], p["ln%d_b" % l], q["h%d" % cur], self.eps, stream), "mms_layernorm_group")
+        last = self.depth - 1
+        chk(L.mms_marl_heads_act(idx, 2 * n, M, H, q["h%d" % cur], p["ln%d_g" % last], p["ln%d_b" % last], p["hw"], p["hb"], self._A,
+                                 p["std_none"] if deterministic else p["std"], q["out"], q["logp"], q["cnt"], self.seed, self.row_offset, self.eps, stream),
+            "mms_marl_heads_act")
+        values, actions, logp = list(self.values.unbind(0)), list(self.actions.unbind(0)), list(self.logp.unbind(0))
+        return values, actions, (None if deterministic else logp)

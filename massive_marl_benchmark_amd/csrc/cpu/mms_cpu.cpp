@@ -386,3 +386,99 @@ MMS_API int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const f
     }
     return 0;
 }
+
+// ---- grouped policy inference (the same three operators as the HIP build; plain loops) -------------------------------------------
+static bool bad_groups(int32_t groups, const char* what) {
+    if (groups >= 1 && groups <= MMS_MAX_GROUPS) return false;
+    g_error = std::string(what) + ": groups must be 1.." + std::to_string(MMS_MAX_GROUPS);
+    return true;
+}
+MMS_API int mms_linear_group_act(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const float* const* x, const float* const* w,
+                                 const float* const* b, float* const* y, int32_t act, void*) {
+    if (cpu_only(device)) return 1;
+    if (bad_groups(groups, "mms_linear_group_act")) return 1;
+    if (!x || !w || !b || !y || M < 0 || N <= 0 || K <= 0 || (K % 4) != 0 || act < 0 || act > 3) {
+        g_error = "mms_linear_group_act: bad arguments (K must be a positive multiple of 4, act 0..3)";
+        return 1;
+    }
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !w[g] || !b[g] || !y[g]) { g_error = "mms_linear_group_act: null pointer in a group"; return 1; }
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < M; m++)
+            for (int n = 0; n < N; n++) {
+                float s = 0.f;
+                for (int k = 0; k < K; k++) s = fmaf(x[g][m * K + k], w[g][(int64_t)n * K + k], s);
+                y[g][m * N + n] = act_fn(s + b[g][n], act);
+            }
+    }
+    return 0;
+}
+static void ln_row(const float* x, int K, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+    for (int k = 0; k < K; k++) s += x[k];
+    mean = s / (float)K;
+    float q = 0.f;
+    for (int k = 0; k < K; k++) q += (x[k] - mean) * (x[k] - mean);
+    rstd = 1.0f / sqrtf(q / (float)K + eps);
+}
+MMS_API int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, const float* const* x, const float* const* gamma,
+                                const float* const* beta, float* const* y, float eps, void*) {
+    if (cpu_only(device)) return 1;
+    if (bad_groups(groups, "mms_layernorm_group")) return 1;
+    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 1024 || Kp < K) {
+        g_error = "mms_layernorm_group: bad arguments (1 <= K <= 1024, Kp >= K)";
+        return 1;
+    }
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !gamma[g] || !beta[g] || !y[g]) { g_error = "mms_layernorm_group: null pointer in a group"; return 1; }
+        if (Kp != K && x[g] == y[g]) { g_error = "mms_layernorm_group: in place needs Kp == K"; return 1; }
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < M; m++) {
+            float mean, rstd;
+            ln_row(x[g] + m * K, K, eps, mean, rstd);
+            for (int k = 0; k < K; k++) y[g][m * Kp + k] = (x[g][m * K + k] - mean) * rstd * gamma[g][k] + beta[g][k];
+            for (int k = K; k < Kp; k++) y[g][m * Kp + k] = 0.f;
+        }
+    }
+    return 0;
+}
+MMS_API int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H, const float* const* h, const float* const* gamma,
+                               const float* const* beta, const float* const* w, const float* const* b, const int32_t* A, const float* const* std,
+                               float* const* out, float* const* logp, int64_t* const* counters, uint64_t seed, int64_t row_offset, float eps,
+                               void*) {
+    if (cpu_only(device)) return 1;
+    if (bad_groups(groups, "mms_marl_heads_act")) return 1;
+    if (!h || !gamma || !beta || !w || !b || !A || !out || M < 0 || H <= 0 || H > 1024) {
+        g_error = "mms_marl_heads_act: bad arguments (1 <= H <= 1024)";
+        return 1;
+    }
+    for (int g = 0; g < groups; g++) {
+        if (!h[g] || !gamma[g] || !beta[g] || !w[g] || !b[g] || !out[g] || A[g] < 1 || A[g] > 16) {
+            g_error = "mms_marl_heads_act: null pointer in a group, or outputs outside 1..16";
+            return 1;
+        }
+        const float* sd = std ? std[g] : nullptr;
+        float* lp = logp ? logp[g] : nullptr;
+        int64_t* cnt = counters ? counters[g] : nullptr;
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < M; m++) {
+            float mean, rstd, xh[1024];
+            ln_row(h[g] + m * H, H, eps, mean, rstd);
+            for (int k = 0; k < H; k++) xh[k] = (h[g][m * H + k] - mean) * rstd * gamma[g][k] + beta[g][k];
+            const int64_t c = cnt ? cnt[m] : 0;
+            for (int j = 0; j < A[g]; j++) {
+                float p = 0.f;
+                for (int k = 0; k < H; k++) p += xh[k] * w[g][(int64_t)j * H + k];
+                p += b[g][j];
+                if (sd) {
+                    const float z = mms::rand_normal(seed + (uint64_t)g, (uint64_t)(row_offset + m), (uint64_t)c, (uint32_t)j);
+                    p += sd[j] * z;
+                    if (lp) lp[m * A[g] + j] = -0.5f * z * z - logf(sd[j]) - 0.9189385332046727f;
+                }
+                out[g][m * A[g] + j] = p;
+            }
+            if (sd && cnt) cnt[m] = c + 1;
+        }
+    }
+    return 0;
+}

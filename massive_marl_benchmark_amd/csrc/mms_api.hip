@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/mms.h"
+#include "policy_args.h"
 #include "step_args.h"
 
 namespace mms {
@@ -21,15 +22,6 @@ hipError_t launch_gae_marl(const float*, const float*, const float*, float*, int
 hipError_t launch_marl_views(const float*, float*, int64_t, int, int, int, hipStream_t);
 hipError_t launch_gae_marl_agents(const float*, const float*, const float*, float*, int, int64_t, int, float, float, int, const float*, const float*, hipStream_t);
 hipError_t launch_ppo_act(const float*, const float*, const float*, uint64_t, int64_t*, int64_t, int, float*, float*, float*, float*, float*, float*, int64_t, int, hipStream_t);
-struct LinearArgs {
-    const float* x[2];
-    const float* w[2];
-    const float* b[2];
-    float* y[2];
-    int M, N, K;
-    int act;
-};
-hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
 hipError_t launch_ppo_head_act(const float*, const float*, const float*, int, const float*, const float*, const float*, const float*, int, const float*, uint64_t,
                                int64_t*, int64_t, int, float*, float*, float*, float*, float*, float*, int64_t, int, hipStream_t);
 }  // namespace mms
@@ -428,8 +420,81 @@ __attribute__((visibility("default"))) int mms_linear2_act(int device, int64_t M
     }
     const bool two = x1 || w1 || b1 || y1;
     if (two && !(x1 && w1 && b1 && y1)) { g_create_error = "mms_linear2_act: the second problem needs all four pointers"; return 1; }
-    mms::LinearArgs a{{x0, x1}, {w0, w1}, {b0, b1}, {y0, y1}, (int)M, N, K, act};
+    mms::LinearArgs a = {};
+    a.x[0] = x0; a.x[1] = x1; a.w[0] = w0; a.w[1] = w1; a.b[0] = b0; a.b[1] = b1; a.y[0] = y0; a.y[1] = y1;
+    a.M = (int)M; a.N = N; a.K = K; a.act = act;
     MMS_FREE(mms::launch_linear_act(a, two ? 2 : 1, (hipStream_t)s));
+    return 0;
+}
+
+// ---- grouped policy inference (MAPPO / HAPPO: all agents' networks per launch) -----------------------------------------------
+static bool bad_group_count(int32_t groups, const char* what) {
+    if (groups >= 1 && groups <= mms::kMaxGroups) return false;
+    g_create_error = std::string(what) + ": groups must be 1.." + std::to_string(mms::kMaxGroups);
+    return true;
+}
+
+__attribute__((visibility("default"))) int mms_linear_group_act(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const float* const* x,
+                                                                const float* const* w, const float* const* b, float* const* y, int32_t act, void* s) {
+    MMS_DEV(device)
+    if (bad_group_count(groups, "mms_linear_group_act")) return 1;
+    if (!x || !w || !b || !y || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || (K % 4) != 0 || act < 0 || act > 3) {
+        g_create_error = "mms_linear_group_act: bad arguments (K must be a positive multiple of 4, act 0..3)";
+        return 1;
+    }
+    mms::LinearArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !w[g] || !b[g] || !y[g]) { g_create_error = "mms_linear_group_act: null pointer in a group"; return 1; }
+        a.x[g] = x[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.y[g] = y[g];
+    }
+    a.M = (int)M; a.N = N; a.K = K; a.act = act;
+    MMS_FREE(mms::launch_linear_act(a, groups, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, const float* const* x,
+                                                               const float* const* gamma, const float* const* beta, float* const* y, float eps, void* s) {
+    MMS_DEV(device)
+    if (bad_group_count(groups, "mms_layernorm_group")) return 1;
+    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 1024 || Kp < K) {
+        g_create_error = "mms_layernorm_group: bad arguments (1 <= K <= 1024, Kp >= K)";
+        return 1;
+    }
+    mms::LayerNormArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !gamma[g] || !beta[g] || !y[g]) { g_create_error = "mms_layernorm_group: null pointer in a group"; return 1; }
+        if (Kp != K && x[g] == y[g]) { g_create_error = "mms_layernorm_group: in place needs Kp == K"; return 1; }
+        a.x[g] = x[g]; a.gamma[g] = gamma[g]; a.beta[g] = beta[g]; a.y[g] = y[g];
+    }
+    a.M = M; a.K = K; a.Kp = Kp; a.eps = eps;
+    MMS_FREE(mms::launch_layernorm(a, groups, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H, const float* const* h,
+                                                              const float* const* gamma, const float* const* beta, const float* const* w,
+                                                              const float* const* b, const int32_t* A, const float* const* std, float* const* out,
+                                                              float* const* logp, int64_t* const* counters, uint64_t seed, int64_t row_offset,
+                                                              float eps, void* s) {
+    MMS_DEV(device)
+    if (bad_group_count(groups, "mms_marl_heads_act")) return 1;
+    if (!h || !gamma || !beta || !w || !b || !A || !out || M < 0 || H <= 0 || H > 1024) {
+        g_create_error = "mms_marl_heads_act: bad arguments (1 <= H <= 1024)";
+        return 1;
+    }
+    mms::HeadsArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!h[g] || !gamma[g] || !beta[g] || !w[g] || !b[g] || !out[g] || A[g] < 1 || A[g] > 16) {
+            g_create_error = "mms_marl_heads_act: null pointer in a group, or outputs outside 1..16";
+            return 1;
+        }
+        a.h[g] = h[g]; a.gamma[g] = gamma[g]; a.beta[g] = beta[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.A[g] = A[g]; a.out[g] = out[g];
+        a.std[g] = std ? std[g] : nullptr;
+        a.logp[g] = logp ? logp[g] : nullptr;
+        a.counters[g] = counters ? counters[g] : nullptr;
+    }
+    a.seed = seed; a.M = M; a.row_offset = row_offset; a.H = H; a.eps = eps;
+    MMS_FREE(mms::launch_marl_heads(a, groups, (hipStream_t)s));
     return 0;
 }
 

@@ -1,0 +1,56 @@
+// policy_args.h -- argument blocks of the policy kernels (policy_kernels.hip), shared with the C ABI file (mms_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mms {
+
+constexpr int kMaxGroups = 32;      // networks per grouped launch (MMS_MAX_GROUPS in include/mms.h)
+
+// y_g = act(x_g w_g^T + b_g) for g < groups: one launch for all of them (same M, N, K)
+struct LinearArgs {
+    const float* x[kMaxGroups];
+    const float* w[kMaxGroups];
+    const float* b[kMaxGroups];
+    float* y[kMaxGroups];
+    int M, N, K;
+    int act;        // 0: identity, 1: ELU (alpha = 1), 2: ReLU, 3: tanh
+};
+
+// y_g[r, 0:K] = LayerNorm(x_g[r, 0:K]) * gamma_g + beta_g, y_g[r, K:Kp] = 0 (row pitch Kp >= K): nn.LayerNorm over the last
+// dimension, biased variance, eps inside the square root.  x_g == y_g with Kp == K is the in-place form.
+struct LayerNormArgs {
+    const float* x[kMaxGroups];
+    const float* gamma[kMaxGroups];
+    const float* beta[kMaxGroups];
+    float* y[kMaxGroups];
+    int64_t M;
+    int K, Kp;
+    float eps;
+};
+
+// The output layer of each network on LayerNorm(h_g): out_g[r, j] = b_g[j] + sum_k w_g[j, k] LN(h_g[r])[k], j < A_g <= 16.
+// std_g != NULL: a diagonal Gaussian is sampled around it (action = out + std z, z from the counter-based stream keyed by
+// (seed + g, row_offset + r, counters_g[r]++, j)) and the per-dimension log-densities go to logp_g [M, A_g]; std_g == NULL: out_g is stored as is.
+struct HeadsArgs {
+    const float* h[kMaxGroups];
+    const float* gamma[kMaxGroups];
+    const float* beta[kMaxGroups];
+    const float* w[kMaxGroups];
+    const float* b[kMaxGroups];
+    const float* std[kMaxGroups];
+    float* out[kMaxGroups];
+    float* logp[kMaxGroups];
+    int64_t* counters[kMaxGroups];
+    int A[kMaxGroups];
+    uint64_t seed;
+    int64_t M, row_offset;
+    int H;
+    float eps;
+};
+
+hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
+hipError_t launch_layernorm(const LayerNormArgs& a, int groups, hipStream_t s);
+hipError_t launch_marl_heads(const HeadsArgs& a, int groups, hipStream_t s);
+
+}  // namespace mms

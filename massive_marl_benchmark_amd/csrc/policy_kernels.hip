@@ -11,6 +11,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "mms_lane.h"
+#include "policy_args.h"
+
 namespace mms {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,14 +28,6 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-struct LinearArgs {
-    const float* x[2];
-    const float* w[2];
-    const float* b[2];
-    float* y[2];
-    int M, N, K;
-    int act;        // 0: identity, 1: ELU (alpha = 1), 2: ReLU, 3: tanh
-};
 
 // LDS layout: both operand tiles row-major, [128 rows][32 k + 4 pad] -- exactly how they arrive from HBM, so staging is a plain
 // 16-B store per 16-B load.  The MFMA wants lane (i, h) to supply A[i][k] for ONE k per instruction; which k it supplies in
@@ -369,6 +364,131 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     } else if (small) hipLaunchKernelGGL(linear_act_kernel<1>, grid, dim3(256), kLinearLds, s, a);
     else hipLaunchKernelGGL(linear_act_kernel<2>, grid, dim3(256), kLinearLds, s, a);
 #undef MMS_LAUNCH_FAST
+    return hipGetLastError();
+}
+
+// ---- MAPPO / HAPPO policy inference for all agents' networks --------------------------------------
+// The reference's collect step (agents/algorithms/marl/runner.py:186-216) walks the agents and, per agent, an Actor and a Critic
+// (actor_critic.py:43-69, 137-155): feature LayerNorm, then layer_N + 1 blocks of Linear + ELU + LayerNorm (utils/mlp.py:5-65),
+// then the DiagGaussian head (utils/distributions.py:94-117) / v_out -- ~30 small launches per agent.  Here: every layer of ALL
+// networks is one grouped launch of the matrix-core layer kernel above (bias + ELU in its epilogue), the LayerNorms are one
+// grouped pass over rows each (HBM / Infinity-Cache bound), and the last LayerNorm, the output layers and the Gaussian sampling
+// are one kernel.
+
+__device__ __forceinline__ float wave_all_sum(float x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+
+constexpr int kLnPerLane = 16;            // row widths up to 1024: element k of a row sits in lane k % 64, slot k / 64
+
+// mean and 1 / sqrt(var + eps) of one row held lane-strided in v[0 : n) (two passes in registers: torch's LayerNorm statistics)
+__device__ __forceinline__ void row_stats(const float (&v)[kLnPerLane], int K, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnPerLane; i++) if (lane + 64 * i < K) s += v[i];
+    mean = wave_all_sum(s) / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnPerLane; i++) if (lane + 64 * i < K) { const float d = v[i] - mean; q += d * d; }
+    rstd = 1.0f / sqrtf(wave_all_sum(q) / (float)K + eps);
+}
+
+// one wave per row, four rows per block, blockIdx.y = network
+__global__ void __launch_bounds__(256) layernorm_rows_kernel(LayerNormArgs a) {
+    const int g = blockIdx.y, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const int K = a.K, Kp = a.Kp;
+    const float* __restrict__ x = a.x[g] + row * K;
+    const float* __restrict__ gamma = a.gamma[g];
+    const float* __restrict__ beta = a.beta[g];
+    float* y = a.y[g] + row * Kp;
+    float v[kLnPerLane];
+#pragma unroll
+    for (int i = 0; i < kLnPerLane; i++) v[i] = (lane + 64 * i < K) ? x[lane + 64 * i] : 0.f;
+    float mean, rstd;
+    row_stats(v, K, lane, a.eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < kLnPerLane; i++) {
+        const int k = lane + 64 * i;
+        if (k < K) y[k] = (v[i] - mean) * rstd * gamma[k] + beta[k];
+        else if (k < Kp) y[k] = 0.f;
+    }
+}
+
+// kHeadRows rows per wave: the output layer's weights ([A, H], at most 64 KB) are staged in LDS once per block and reused by its
+// 4 x kHeadRows rows (read per row straight from L2 they cost 18 KB per row: 202 us per launch against 60 us now, twenty networks).
+constexpr int kHeadRows = 8;
+__global__ void __launch_bounds__(256) marl_heads_kernel(HeadsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];          // [A][H]
+    const int g = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = a.H, A = a.A[g];
+    const float* __restrict__ gamma = a.gamma[g];
+    const float* __restrict__ beta = a.beta[g];
+    for (int k = threadIdx.x; k < A * H; k += 256) s_w[k] = a.w[g][k];
+    __syncthreads();
+    float gm[kLnPerLane], bt[kLnPerLane];
+#pragma unroll
+    for (int i = 0; i < kLnPerLane; i++) {
+        const int k = lane + 64 * i;
+        gm[i] = (k < H) ? gamma[k] : 0.f;
+        bt[i] = (k < H) ? beta[k] : 0.f;
+    }
+    const float bias = (lane < A) ? a.b[g][lane] : 0.f;
+    const float sd = (a.std[g] && lane < A) ? a.std[g][lane] : 0.f;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * kHeadRows;
+    for (int r = 0; r < kHeadRows; r++) {
+        const int64_t row = row0 + r;
+        if (row >= a.M) return;
+        const float* __restrict__ h = a.h[g] + row * H;
+        float v[kLnPerLane];
+#pragma unroll
+        for (int i = 0; i < kLnPerLane; i++) v[i] = (lane + 64 * i < H) ? h[lane + 64 * i] : 0.f;
+        float mean, rstd;
+        row_stats(v, H, lane, a.eps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < kLnPerLane; i++) v[i] = (v[i] - mean) * rstd * gm[i] + bt[i];      // (slots past H: gm = bt = 0)
+        float mine = 0.f;                               // lane j keeps output j
+        for (int j = 0; j < A; j++) {
+            const float* wj = s_w + j * H;
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < kLnPerLane; i++) if (lane + 64 * i < H) p += v[i] * wj[lane + 64 * i];
+            p = wave_all_sum(p);
+            if (lane == j) mine = p;
+        }
+        mine += bias;
+        float* out = a.out[g] + row * A;
+        if (a.std[g] == nullptr) {                      // a value head (or a deterministic action): stored as is
+            if (lane < A) out[lane] = mine;
+            continue;
+        }
+        const int64_t c = a.counters[g] ? a.counters[g][row] : 0;
+        if (lane < A) {
+            const float z = rand_normal(a.seed + (uint64_t)g, (uint64_t)(a.row_offset + row), (uint64_t)c, (uint32_t)lane);
+            out[lane] = mine + sd * z;                  // Normal.sample
+            // FixedNormal.log_probs (distributions.py:31-34) is the PER-DIMENSION log-density: the reference keeps [M, A], no sum
+            if (a.logp[g]) a.logp[g][row * A + lane] = -0.5f * z * z - logf(sd) - 0.9189385332046727f;
+        }
+        if (lane == 0 && a.counters[g]) a.counters[g][row] = c + 1;
+    }
+}
+
+hipError_t launch_layernorm(const LayerNormArgs& a, int groups, hipStream_t s) {
+    if (a.M == 0 || groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((a.M + 3) / 4), groups), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_marl_heads(const HeadsArgs& a, int groups, hipStream_t s) {
+    if (a.M == 0 || groups == 0) return hipSuccess;
+    int amax = 1;
+    for (int g = 0; g < groups; g++) amax = a.A[g] > amax ? a.A[g] : amax;
+    const size_t lds = (size_t)amax * a.H * sizeof(float);                       // <= 16 x 1024 x 4 = 64 KB
+    const int64_t per_block = 4 * kHeadRows;
+    hipLaunchKernelGGL(marl_heads_kernel, dim3((unsigned)((a.M + per_block - 1) / per_block), groups), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
