@@ -201,3 +201,22 @@ class GroupedPolicyInference:
             "mms_marl_heads_act")
         values, actions, logp = list(self.values.unbind(0)), list(self.actions.unbind(0)), list(self.logp.unbind(0))
         return values, actions, (None if deterministic else logp)
+
+    # -- the Runner's collect step --------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_trainers(cls, trainers, seed=0, row_offset=0):
+        """One object for a Runner's agents: `trainers[i].policy.actor` / `.critic` (runner.py:69-101)."""
+        return cls([t.policy.actor for t in trainers], [t.policy.critic for t in trainers], seed=seed, row_offset=row_offset)
+
+    @torch.no_grad()
+    def collect(self, buffers, step):
+        """The body of Runner.collect (agents/algorithms/marl/runner.py:198-227) for non-recurrent policies: same five return values
+        -- values [M, agents, 1], the per-agent action and log-prob lists, and the (untouched) rnn states [M, agents, ...] -- from one
+        grouped pass instead of a loop over agents.  `buffers` = the Runner's per-agent SeparatedReplayBuffers.  The padded first
+        actor weights and the std vectors are refreshed at step 0 of every episode (the trainers update the parameters in between)."""
+        if step == 0:
+            self.refresh()
+        values, actions, logp = self.get_actions([b.share_obs[step] for b in buffers], [b.obs[step] for b in buffers])
+        rnn_states = torch.transpose(torch.stack([b.rnn_states[step] for b in buffers]), 1, 0)
+        rnn_states_critic = torch.transpose(torch.stack([b.rnn_states_critic[step] for b in buffers]), 1, 0)
+        return self.values.transpose(0, 1), actions, logp, rnn_states, rnn_states_critic

@@ -7,7 +7,8 @@ pipeline, agents/tasks/agent_base/base_task.py:27-32; there is no GPU in the bui
      (BASELINE configs[0]) -- with the reference's own RolloutStorage / ActorCritic, then again with this build's drop-in classes
      (massive_marl_benchmark_amd.algorithms.rl.ppo) patched into the reference module: same loop, zero edits.
   2. agents/algorithms/marl/runner.py `Runner.run` (:114-151) with algorithm_name = mappo for 2 episodes on TenAnt, 16 envs, ten
-     agents -- the reference's policies, trainers and SeparatedReplayBuffers; then with this build's SeparatedReplayBuffer patched in.
+     agents -- the reference's policies, trainers and SeparatedReplayBuffers; then with this build's SeparatedReplayBuffer patched in;
+     then with GroupedPolicyInference (algorithms/marl/policy_inference.py) as the Runner's collect step on top of that.
 
 Runs only where the reference tree exists.  Nothing of the reference is copied: modules are imported from where they lie, with the
 name-only stand-ins of tests/golden/_isaacgym_stub for `gym` / `isaacgym` and a name-only `torch.utils.tensorboard.SummaryWriter`
@@ -121,7 +122,9 @@ def run_mappo(tmp):
     n = 16
     conf.update(n_rollout_threads=n, num_env_steps=2 * conf["episode_length"] * n, hidden_size=64, run_dir=os.path.join(tmp, "marl"),
                 log_interval=1, save_interval=1000)
-    for label, buf_cls in (("reference SeparatedReplayBuffer", ref_buffer), ("this build's SeparatedReplayBuffer", OurBuffer)):
+    from massive_marl_benchmark_amd.algorithms.marl.policy_inference import GroupedPolicyInference
+    for label, buf_cls, grouped in (("reference SeparatedReplayBuffer", ref_buffer, False), ("this build's SeparatedReplayBuffer", OurBuffer, False),
+                                    ("this build's SeparatedReplayBuffer + GroupedPolicyInference as Runner.collect", OurBuffer, True)):
         runner.SeparatedReplayBuffer = buf_cls
         cfg = default_cfg("TenAnt")
         cfg["env"]["numEnvs"] = n
@@ -131,6 +134,9 @@ def run_mappo(tmp):
         env = MultiVecTaskPython(task, "cpu")
         torch.manual_seed(1)
         r = runner.Runner(vec_env=env, config=dict(conf), model_dir="")
+        if grouped:       # all twenty networks of a collect step in grouped launches, reading the reference's own Actor / Critic modules in place
+            inf = GroupedPolicyInference.from_trainers(r.trainer, seed=1)
+            r.collect = lambda step, inf=inf, r=r: inf.collect(r.buffer, step)
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             r.run()

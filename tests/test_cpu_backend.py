@@ -248,7 +248,8 @@ def test_make_entry_glue():
 def test_reference_learners_drop_in_unchanged(tmp_path):
     """The reference's real PPO.run (agents/algorithms/rl/ppo/ppo.py:99-175) and Runner.run (agents/algorithms/marl/runner.py:114-151,
     mappo), imported in place and unmodified, over this build's VecTaskPython / MultiVecTaskPython on the CPU build -- with the
-    reference's own storage / module / buffer classes and with this build's drop-in ones.  The committed log of the same script:
+    reference's own storage / module / buffer classes, with this build's drop-in ones, and with the grouped policy inference as the
+    Runner's collect step.  The committed log of the same script:
     tests/golden/reference_learners_dropin.log."""
     log = tmp_path / "dropin.log"
     env = dict(os.environ, MMS_DROPIN_LOG=str(log), OMP_NUM_THREADS="4")
@@ -256,4 +257,4 @@ def test_reference_learners_drop_in_unchanged(tmp_path):
                        stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
     text = log.read_text()
-    assert text.count(": ok") == 4 and "Runner.run" in text and "PPO.run" in text
+    assert text.count(": ok") == 5 and "Runner.run" in text and "PPO.run" in text and "GroupedPolicyInference as Runner.collect: ok" in text
