@@ -1,8 +1,8 @@
 """Restatement of the isaacgym.torch_utils helpers the hot path uses.
 
 Quaternions are xyzw.  These are written from the documented behaviour of the helpers, not
-from Isaac Gym source (which is not in this container); each has a closed-form KAT in
-tests/test_oracle_helpers.py.
+from Isaac Gym source (which is not in this container); each has a closed-form known-answer test in
+tests/test_oracle_golden.py (the `helpers_kat` fixture).
 """
 import math
 
