@@ -255,22 +255,24 @@ int mms_linear_group_act(int device, int32_t groups, int64_t M, int32_t N, int32
                          const float* const* b, float* const* y, int32_t act, void* hip_stream);
 
 /* nn.LayerNorm over the last dimension (biased variance, eps inside the root): y_g[r, 0:K] = LN(x_g[r, 0:K]) * gamma_g + beta_g,
- * y_g[r, K:Kp] = 0.  x rows have pitch K, y rows pitch Kp >= K (Kp > K pads a 46-wide observation to the multiple of 4 the layer
- * kernel wants); y_g == x_g with Kp == K is the in-place form.  K <= 1024. */
-int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, const float* const* x, const float* const* gamma,
-                        const float* const* beta, float* const* y, float eps, void* hip_stream);
+ * y_g[r, K:Kp] = 0.  x rows have pitch x_pitch floats (0 = K; A * K reads one agent's rows of an [N, A, K] block where they lie),
+ * y rows pitch Kp >= K (Kp > K pads a 46-wide observation to the multiple of 4 the layer kernel wants); y_g == x_g with
+ * Kp == x_pitch == K is the in-place form.  K <= 1024. */
+int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, int32_t x_pitch, const float* const* x,
+                        const float* const* gamma, const float* const* beta, float* const* y, float eps, void* hip_stream);
 
 /* The last LayerNorm + the output layer (+ the Gaussian sample) of each network: out_g[r, j] = b_g[j] + sum_k w_g[j, k] *
  * LN(h_g[r])[k], j < A[g] <= 16, H <= 1024.  std[g] != NULL ([A[g]] standard deviations): out_g = that mean + std z with z ~ N(0,1)
  * from the counter-based stream keyed (seed + g, row_offset + r, counters[g][r], j) (counters[g][r] += 1; counters or counters[g]
  * NULL: counter 0), and logp[g][r, j] = log N(out_j | mean_j, std_j), PER DIMENSION, [M, A[g]] (FixedNormal.log_probs,
  * distributions.py:31-34, does not sum over the action dimensions).  std == NULL or
- * std[g] == NULL: out_g is the plain output (the critic's value; a deterministic action).  The noise stream is this build's, not
+ * std[g] == NULL: out_g is the plain output (the critic's value; a deterministic action).  out_pitch[g] (NULL: A[g]) = floats
+ * between consecutive rows of out_g and logp_g, so that agent k's actions land in an [N, agents, A] rollout slot directly.  The noise stream is this build's, not
  * torch's Philox: sampled actions differ from the reference's draw for the same torch seed, their distribution does not. */
 int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H, const float* const* h, const float* const* gamma,
                        const float* const* beta, const float* const* w, const float* const* b, const int32_t* A, const float* const* std,
-                       float* const* out, float* const* logp, int64_t* const* counters, uint64_t seed, int64_t row_offset, float eps,
-                       void* hip_stream);
+                       float* const* out, float* const* logp, const int32_t* out_pitch, int64_t* const* counters, uint64_t seed,
+                       int64_t row_offset, float eps, void* hip_stream);
 
 const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
 int mms_abi_version(void);

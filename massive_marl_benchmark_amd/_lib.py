@@ -44,8 +44,8 @@ def _bind(path):
                                     vp, vp, c64, ctypes.c_int32, vp]
     L.mms_linear2_act.argtypes = [ci, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp]
     L.mms_linear_group_act.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int32, vp]
-    L.mms_layernorm_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, cf, vp]
-    L.mms_marl_heads_act.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, c64, cf, vp]
+    L.mms_layernorm_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, cf, vp]
+    L.mms_marl_heads_act.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, c64, cf, vp]
     L.mms_marl_views.argtypes = [ci, vp, vp, c64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     L.mms_gae_ppo.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, c64, cf, cf, vp]
     L.mms_adv_normalize.argtypes = [ci, vp, vp, c64, vp]

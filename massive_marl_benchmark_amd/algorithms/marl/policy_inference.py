@@ -56,6 +56,18 @@ def _ptrs(tensors):
     return arr
 
 
+def _row_ptrs(tensors):
+    """Pointer array + common row pitch (floats) of 2-D float32 views whose rows are dense (stride 1 inside a row): a contiguous
+    [M, K] matrix, or agent k's rows `block[:, k]` of an [M, agents, K] block."""
+    pitch = {t.stride(0) for t in tensors}
+    if len(pitch) != 1 or any(t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32 for t in tensors):
+        raise ValueError("GroupedPolicyInference: operands must be float32 [M, K] views with dense rows and one common row pitch")
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr, pitch.pop()
+
+
 class GroupedPolicyInference:
     def __init__(self, actors, critics, seed=0, row_offset=0):
         if len(actors) != len(critics) or not actors:
@@ -168,9 +180,12 @@ class GroupedPolicyInference:
         self._M = M
 
     # -- inference ----------------------------------------------------------------------------------------------------------------
-    def get_actions(self, share_obs, obs, deterministic=False):
+    def get_actions(self, share_obs, obs, deterministic=False, out=None):
         """share_obs, obs: per-agent lists of [M, share_obs_dim] / [M, obs_dim] float32 tensors (what the Runner hands agent i:
-        buffer[i].share_obs[step], buffer[i].obs[step]).  Returns (values, actions, action_log_probs): per-agent lists of
+        buffer[i].share_obs[step], buffer[i].obs[step]); rows may be strided (agent i's rows of an [M, agents, K] block are read
+        where they lie).  out = (values, actions, action_log_probs): optional per-agent lists of [M, 1] / [M, act_dim] /
+        [M, act_dim] destination views with dense rows (e.g. slices of [M, agents, ...] rollout slots), written in place.
+        Returns (values, actions, action_log_probs): per-agent lists of
         [M, 1], [M, act_dim], [M, act_dim] views of buffers that the next call overwrites (the reference's
         FixedNormal.log_probs keeps the per-dimension log-densities, utils/distributions.py:31-34)."""
         n = self.n
@@ -181,10 +196,11 @@ class GroupedPolicyInference:
         L, idx, stream = _lib.for_device(self.device)
         p, q = self.p, self.q
         chk = lambda rc, what: _lib.check(rc, None, what, L)
-        f32 = lambda t: t.detach().float().contiguous()
-        obs, share_obs = [f32(t) for t in obs], [f32(t) for t in share_obs]
-        chk(L.mms_layernorm_group(idx, n, M, self.obs_dim, self.kp_a, _ptrs(obs), p["fn_a_g"], p["fn_a_b"], q["x_a"], self.eps, stream), "mms_layernorm_group")
-        chk(L.mms_layernorm_group(idx, n, M, self.sobs_dim, self.kp_c, _ptrs(share_obs), p["fn_c_g"], p["fn_c_b"], q["x_c"], self.eps, stream), "mms_layernorm_group")
+        f32 = lambda t: t.detach() if t.dtype == torch.float32 else t.detach().float()
+        obs_p, obs_pitch = _row_ptrs([f32(t) for t in obs])
+        sobs_p, sobs_pitch = _row_ptrs([f32(t) for t in share_obs])
+        chk(L.mms_layernorm_group(idx, n, M, self.obs_dim, self.kp_a, obs_pitch, obs_p, p["fn_a_g"], p["fn_a_b"], q["x_a"], self.eps, stream), "mms_layernorm_group")
+        chk(L.mms_layernorm_group(idx, n, M, self.sobs_dim, self.kp_c, sobs_pitch, sobs_p, p["fn_c_g"], p["fn_c_b"], q["x_c"], self.eps, stream), "mms_layernorm_group")
         H = self.hidden
         chk(L.mms_linear_group_act(idx, n, M, H, self.kp_a, q["x_a"], p["w1_a"], p["b1_a"], q["h0_a"], 1, stream), "mms_linear_group_act")
         chk(L.mms_linear_group_act(idx, n, M, H, self.kp_c, q["x_c"], p["w1_c"], p["b1_c"], q["h0_c"], 1, stream), "mms_linear_group_act")
@@ -194,12 +210,24 @@ class GroupedPolicyInference:
                 chk(L.mms_linear_group_act(idx, 2 * n, M, H, H, q["h%d" % cur], p["w%d" % l], p["b%d" % l], q["h%d" % (1 - cur)], 1, stream), "mms_linear_group_act")
                 cur = 1 - cur
             if l + 1 < self.depth:                                  # (the last LayerNorm runs inside the heads kernel)
-                chk(L.mms_layernorm_group(idx, 2 * n, M, H, H, q["h%d" % cur], p["ln%d_g" % l], p["ln%d_b" % l], q["h%d" % cur], self.eps, stream), "mms_layernorm_group")
+                chk(L.mms_layernorm_group(idx, 2 * n, M, H, H, H, q["h%d" % cur], p["ln%d_g" % l], p["ln%d_b" % l], q["h%d" % cur], self.eps, stream), "mms_layernorm_group")
         last = self.depth - 1
+        if out is None:
+            values, actions, logp = list(self.values.unbind(0)), list(self.actions.unbind(0)), list(self.logp.unbind(0))
+            out_p, logp_p, pitch = q["out"], q["logp"], None
+        else:
+            values, actions, logp = (list(x) for x in out)
+            ap, a_pitch = _row_ptrs(actions)
+            lp, l_pitch = _row_ptrs(logp)
+            vp, v_pitch = _row_ptrs(values)
+            if a_pitch != l_pitch:
+                raise ValueError("GroupedPolicyInference: action and log-prob destinations must share one row pitch")
+            out_p = (ctypes.c_void_p * (2 * n))(*(list(ap) + list(vp)))
+            logp_p = (ctypes.c_void_p * (2 * n))(*(list(lp) + [None] * n))
+            pitch = (ctypes.c_int32 * (2 * n))(*([a_pitch] * n + [v_pitch] * n))
         chk(L.mms_marl_heads_act(idx, 2 * n, M, H, q["h%d" % cur], p["ln%d_g" % last], p["ln%d_b" % last], p["hw"], p["hb"], self._A,
-                                 p["std_none"] if deterministic else p["std"], q["out"], q["logp"], q["cnt"], self.seed, self.row_offset, self.eps, stream),
+                                 p["std_none"] if deterministic else p["std"], out_p, logp_p, pitch, q["cnt"], self.seed, self.row_offset, self.eps, stream),
             "mms_marl_heads_act")
-        values, actions, logp = list(self.values.unbind(0)), list(self.actions.unbind(0)), list(self.logp.unbind(0))
         return values, actions, (None if deterministic else logp)
 
     # -- the Runner's collect step --------------------------------------------------------------------------------------------------
@@ -220,3 +248,26 @@ class GroupedPolicyInference:
         rnn_states = torch.transpose(torch.stack([b.rnn_states[step] for b in buffers]), 1, 0)
         rnn_states_critic = torch.transpose(torch.stack([b.rnn_states_critic[step] for b in buffers]), 1, 0)
         return self.values.transpose(0, 1), actions, logp, rnn_states, rnn_states_critic
+
+    @torch.no_grad()
+    def collect_into(self, shared, deterministic=False):
+        """The collect step over `SharedRolloutBuffers` (utils/shared_buffer.py), zero copy: every agent's observation rows are read
+        from `shared.obs[step]` / `shared.share_obs[step]` where the env step left them, and actions, log-probs and values are
+        written straight into `shared.actions[step]`, `shared.action_log_probs[step]`, `shared.value_preds[step]`.  Returns the
+        [N, agents, act_dim] action slot (what `shared.env_step` takes)."""
+        s, n = shared.step, self.n
+        obs, sobs = shared.obs[s], shared.share_obs[s]
+        out = ([shared.value_preds[s][:, k:k + 1] for k in range(n)], [shared.actions[s][:, k] for k in range(n)],
+               [shared.action_log_probs[s][:, k] for k in range(n)])
+        self.get_actions([sobs] * n, [obs[:, k] for k in range(n)], deterministic=deterministic, out=out)
+        return shared.actions[s]
+
+    @torch.no_grad()
+    def values_into(self, shared, dst, slot=-1):
+        """Critic values of observation slot `slot` (default: the last one -- the bootstrap values of Runner.compute,
+        runner.py:229-241, taken from share_obs[-1]) into dst [N, agents]; the actor outputs of the pass go to scratch."""
+        s, n = slot, self.n
+        self._buffers(shared.obs[s].shape[0])
+        out = ([dst[:, k:k + 1] for k in range(n)], list(self.actions.unbind(0)), list(self.logp.unbind(0)))
+        self.get_actions([shared.share_obs[s]] * n, [shared.obs[s][:, k] for k in range(n)], deterministic=True, out=out)
+        return dst

@@ -177,9 +177,13 @@ class SharedRolloutBuffers:
             action_log_probs = torch.stack(list(action_log_probs), 1)
         self.rewards[s].copy_(rewards.view(-1, 1))
         self.masks[s + 1].copy_((dones == 0).to(torch.float32).view(-1, 1))        # dones are per env: dones_env == dones
-        self.value_preds[s].copy_(values.reshape(self.N, self.A))
-        self.actions[s].copy_(actions)
-        self.action_log_probs[s].copy_(action_log_probs)
+        # rows that GroupedPolicyInference.collect_into already wrote in place are recognised by their address and not copied again
+        def put(dst, src):
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src.reshape(dst.shape))
+        put(self.value_preds[s], values)
+        put(self.actions[s], actions)
+        put(self.action_log_probs[s], action_log_probs)
         self.step = (s + 1) % self.T
 
     def finished_episode_rewards(self, running, reward_env, dones_env):

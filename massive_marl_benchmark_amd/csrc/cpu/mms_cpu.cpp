@@ -421,22 +421,23 @@ static void ln_row(const float* x, int K, float eps, float& mean, float& rstd) {
     for (int k = 0; k < K; k++) q += (x[k] - mean) * (x[k] - mean);
     rstd = 1.0f / sqrtf(q / (float)K + eps);
 }
-MMS_API int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, const float* const* x, const float* const* gamma,
-                                const float* const* beta, float* const* y, float eps, void*) {
+MMS_API int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, int32_t x_pitch, const float* const* x,
+                                const float* const* gamma, const float* const* beta, float* const* y, float eps, void*) {
     if (cpu_only(device)) return 1;
     if (bad_groups(groups, "mms_layernorm_group")) return 1;
-    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 1024 || Kp < K) {
-        g_error = "mms_layernorm_group: bad arguments (1 <= K <= 1024, Kp >= K)";
+    if (x_pitch == 0) x_pitch = K;
+    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 1024 || Kp < K || x_pitch < K) {
+        g_error = "mms_layernorm_group: bad arguments (1 <= K <= 1024, Kp >= K, x_pitch >= K or 0)";
         return 1;
     }
     for (int g = 0; g < groups; g++) {
         if (!x[g] || !gamma[g] || !beta[g] || !y[g]) { g_error = "mms_layernorm_group: null pointer in a group"; return 1; }
-        if (Kp != K && x[g] == y[g]) { g_error = "mms_layernorm_group: in place needs Kp == K"; return 1; }
+        if ((Kp != K || x_pitch != K) && x[g] == y[g]) { g_error = "mms_layernorm_group: in place needs Kp == x_pitch == K"; return 1; }
 #pragma omp parallel for schedule(static)
         for (int64_t m = 0; m < M; m++) {
             float mean, rstd;
-            ln_row(x[g] + m * K, K, eps, mean, rstd);
-            for (int k = 0; k < K; k++) y[g][m * Kp + k] = (x[g][m * K + k] - mean) * rstd * gamma[g][k] + beta[g][k];
+            ln_row(x[g] + m * x_pitch, K, eps, mean, rstd);
+            for (int k = 0; k < K; k++) y[g][m * Kp + k] = (x[g][m * x_pitch + k] - mean) * rstd * gamma[g][k] + beta[g][k];
             for (int k = K; k < Kp; k++) y[g][m * Kp + k] = 0.f;
         }
     }
@@ -444,8 +445,8 @@ MMS_API int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K
 }
 MMS_API int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H, const float* const* h, const float* const* gamma,
                                const float* const* beta, const float* const* w, const float* const* b, const int32_t* A, const float* const* std,
-                               float* const* out, float* const* logp, int64_t* const* counters, uint64_t seed, int64_t row_offset, float eps,
-                               void*) {
+                               float* const* out, float* const* logp, const int32_t* out_pitch, int64_t* const* counters, uint64_t seed,
+                               int64_t row_offset, float eps, void*) {
     if (cpu_only(device)) return 1;
     if (bad_groups(groups, "mms_marl_heads_act")) return 1;
     if (!h || !gamma || !beta || !w || !b || !A || !out || M < 0 || H <= 0 || H > 1024) {
@@ -457,6 +458,8 @@ MMS_API int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H,
             g_error = "mms_marl_heads_act: null pointer in a group, or outputs outside 1..16";
             return 1;
         }
+        const int op = out_pitch ? out_pitch[g] : A[g];
+        if (op < A[g]) { g_error = "mms_marl_heads_act: out_pitch below the number of outputs"; return 1; }
         const float* sd = std ? std[g] : nullptr;
         float* lp = logp ? logp[g] : nullptr;
         int64_t* cnt = counters ? counters[g] : nullptr;
@@ -473,9 +476,9 @@ MMS_API int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H,
                 if (sd) {
                     const float z = mms::rand_normal(seed + (uint64_t)g, (uint64_t)(row_offset + m), (uint64_t)c, (uint32_t)j);
                     p += sd[j] * z;
-                    if (lp) lp[m * A[g] + j] = -0.5f * z * z - logf(sd[j]) - 0.9189385332046727f;
+                    if (lp) lp[m * op + j] = -0.5f * z * z - logf(sd[j]) - 0.9189385332046727f;
                 }
-                out[g][m * A[g] + j] = p;
+                out[g][m * op + j] = p;
             }
             if (sd && cnt) cnt[m] = c + 1;
         }

@@ -452,21 +452,23 @@ __attribute__((visibility("default"))) int mms_linear_group_act(int device, int3
     return 0;
 }
 
-__attribute__((visibility("default"))) int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, const float* const* x,
-                                                               const float* const* gamma, const float* const* beta, float* const* y, float eps, void* s) {
+__attribute__((visibility("default"))) int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, int32_t x_pitch,
+                                                               const float* const* x, const float* const* gamma, const float* const* beta, float* const* y,
+                                                               float eps, void* s) {
     MMS_DEV(device)
     if (bad_group_count(groups, "mms_layernorm_group")) return 1;
-    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 1024 || Kp < K) {
-        g_create_error = "mms_layernorm_group: bad arguments (1 <= K <= 1024, Kp >= K)";
+    if (x_pitch == 0) x_pitch = K;
+    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 1024 || Kp < K || x_pitch < K) {
+        g_create_error = "mms_layernorm_group: bad arguments (1 <= K <= 1024, Kp >= K, x_pitch >= K or 0)";
         return 1;
     }
     mms::LayerNormArgs a = {};
     for (int g = 0; g < groups; g++) {
         if (!x[g] || !gamma[g] || !beta[g] || !y[g]) { g_create_error = "mms_layernorm_group: null pointer in a group"; return 1; }
-        if (Kp != K && x[g] == y[g]) { g_create_error = "mms_layernorm_group: in place needs Kp == K"; return 1; }
+        if ((Kp != K || x_pitch != K) && x[g] == y[g]) { g_create_error = "mms_layernorm_group: in place needs Kp == x_pitch == K"; return 1; }
         a.x[g] = x[g]; a.gamma[g] = gamma[g]; a.beta[g] = beta[g]; a.y[g] = y[g];
     }
-    a.M = M; a.K = K; a.Kp = Kp; a.eps = eps;
+    a.M = M; a.K = K; a.Kp = Kp; a.x_pitch = x_pitch; a.eps = eps;
     MMS_FREE(mms::launch_layernorm(a, groups, (hipStream_t)s));
     return 0;
 }
@@ -474,8 +476,8 @@ __attribute__((visibility("default"))) int mms_layernorm_group(int device, int32
 __attribute__((visibility("default"))) int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H, const float* const* h,
                                                               const float* const* gamma, const float* const* beta, const float* const* w,
                                                               const float* const* b, const int32_t* A, const float* const* std, float* const* out,
-                                                              float* const* logp, int64_t* const* counters, uint64_t seed, int64_t row_offset,
-                                                              float eps, void* s) {
+                                                              float* const* logp, const int32_t* out_pitch, int64_t* const* counters, uint64_t seed,
+                                                              int64_t row_offset, float eps, void* s) {
     MMS_DEV(device)
     if (bad_group_count(groups, "mms_marl_heads_act")) return 1;
     if (!h || !gamma || !beta || !w || !b || !A || !out || M < 0 || H <= 0 || H > 1024) {
@@ -489,6 +491,8 @@ __attribute__((visibility("default"))) int mms_marl_heads_act(int device, int32_
             return 1;
         }
         a.h[g] = h[g]; a.gamma[g] = gamma[g]; a.beta[g] = beta[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.A[g] = A[g]; a.out[g] = out[g];
+        a.out_pitch[g] = out_pitch ? out_pitch[g] : A[g];
+        if (a.out_pitch[g] < A[g]) { g_create_error = "mms_marl_heads_act: out_pitch below the number of outputs"; return 1; }
         a.std[g] = std ? std[g] : nullptr;
         a.logp[g] = logp ? logp[g] : nullptr;
         a.counters[g] = counters ? counters[g] : nullptr;

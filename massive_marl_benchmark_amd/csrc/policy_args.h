@@ -26,6 +26,7 @@ struct LayerNormArgs {
     float* y[kMaxGroups];
     int64_t M;
     int K, Kp;
+    int x_pitch;    // floats between consecutive input rows (>= K): K for a dense matrix, A * K for one agent's rows of an [N, A, K] block
     float eps;
 };
 
@@ -43,6 +44,7 @@ struct HeadsArgs {
     float* logp[kMaxGroups];
     int64_t* counters[kMaxGroups];
     int A[kMaxGroups];
+    int out_pitch[kMaxGroups];      // floats between consecutive rows of out_g (and logp_g): A_g dense, or the row width of an [N, agents, A] block
     uint64_t seed;
     int64_t M, row_offset;
     int H;

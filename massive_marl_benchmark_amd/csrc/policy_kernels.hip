@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(LayerNormArgs a) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const int K = a.K, Kp = a.Kp;
-    const float* __restrict__ x = a.x[g] + row * K;
+    const float* __restrict__ x = a.x[g] + row * a.x_pitch;
     const float* __restrict__ gamma = a.gamma[g];
     const float* __restrict__ beta = a.beta[g];
     float* y = a.y[g] + row * Kp;
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256) marl_heads_kernel(HeadsArgs a) {
             if (lane == j) mine = p;
         }
         mine += bias;
-        float* out = a.out[g] + row * A;
+        float* out = a.out[g] + row * a.out_pitch[g];
         if (a.std[g] == nullptr) {                      // a value head (or a deterministic action): stored as is
             if (lane < A) out[lane] = mine;
             continue;
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(256) marl_heads_kernel(HeadsArgs a) {
             const float z = rand_normal(a.seed + (uint64_t)g, (uint64_t)(a.row_offset + row), (uint64_t)c, (uint32_t)lane);
             out[lane] = mine + sd * z;                  // Normal.sample
             // FixedNormal.log_probs (distributions.py:31-34) is the PER-DIMENSION log-density: the reference keeps [M, A], no sum
-            if (a.logp[g]) a.logp[g][row * A + lane] = -0.5f * z * z - logf(sd) - 0.9189385332046727f;
+            if (a.logp[g]) a.logp[g][row * a.out_pitch[g] + lane] = -0.5f * z * z - logf(sd) - 0.9189385332046727f;
         }
         if (lane == 0 && a.counters[g]) a.counters[g][row] = c + 1;
     }

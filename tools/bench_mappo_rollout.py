@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""The MAPPO rollout of BASELINE configs[3] on ONE GPU's shard: TenAnt, ten agents, 4096 envs, episode_length 8
+(cfg/mappo/config.yaml: hidden 512, layer_N 2), policy inference INCLUDED -- what Runner.run does between two updates
+(agents/algorithms/marl/runner.py:128-151: collect, envs.step, insert; then compute): env-steps/s of the whole collection loop.
+
+  reference_way   per-agent torch modules (runner.py:198-227 over actor_critic.py), MultiVecTaskPython.step materialising obs_all /
+                  state_all, ten SeparatedReplayBuffer.insert, per-agent bootstrap values, ten compute_returns -- on this engine
+  fused           GroupedPolicyInference.collect_into (all twenty networks per stage, reads and writes the rollout slots in place),
+                  SharedRolloutBuffers (share_obs once, written by the step kernel), one GAE launch; eager and as ONE hipGraph
+
+    python tools/bench_mappo_rollout.py [--num-envs 4096] [--iters 16]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-envs", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=16, help="timed rollouts of T = 8 steps")
+    args = ap.parse_args()
+    import torch
+    import marl_modules as mm
+    from massive_marl_benchmark_amd.algorithms.marl.policy_inference import GroupedPolicyInference
+    from massive_marl_benchmark_amd.algorithms.marl.utils.separated_buffer import SeparatedReplayBuffer
+    from massive_marl_benchmark_amd.algorithms.marl.utils.shared_buffer import SharedRolloutBuffers
+    from massive_marl_benchmark_amd.model import default_cfg
+    from massive_marl_benchmark_amd.tasks.agent_base.multi_vec_task import MultiVecTaskPython
+    from massive_marl_benchmark_amd.tasks.ten_ant import TenAnt
+
+    n, T, A = args.num_envs, 8, 10
+    conf = dict(episode_length=T, n_rollout_threads=n, hidden_size=512, recurrent_N=1, gamma=0.99, gae_lambda=0.95, use_gae=True,
+                use_popart=False, use_valuenorm=False, use_proper_time_limits=False)
+
+    def make_env():
+        cfg = default_cfg("TenAnt")
+        cfg["env"]["numEnvs"] = n
+        cfg["clip_observations"] = 7.0
+        cfg["seed"] = 3
+        return MultiVecTaskPython(TenAnt(cfg, None, "physx", "cuda", 0, True, is_multi_agent=True), "cuda:0")
+
+    gen = torch.Generator().manual_seed(5)
+    actors, critics = [], []
+    for i in range(A):
+        torch.manual_seed(i)
+        a, c = mm.Actor(46, 8), mm.Critic(388)
+        mm.randomize(a, gen, 0.05)
+        mm.randomize(c, gen, 0.05)
+        actors.append(a.cuda())
+        critics.append(c.cuda())
+
+    def timed(rollout, iters):
+        for _ in range(3):
+            rollout()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            rollout()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / (iters * T)
+        return {"ms_per_env_step": ms, "env_steps_per_s": n / (ms * 1e-3), "agent_steps_per_s": n * A / (ms * 1e-3)}
+
+    out = {"task": "TenAnt", "algo": "mappo", "num_envs": n, "agents": A, "T": T, "hidden": 512, "layer_N": 2}
+
+    # ---- the reference's way, on this engine ------------------------------------------------------------------------------------
+    env = make_env()
+    bufs = [SeparatedReplayBuffer(conf, env.observation_space[k], env.share_observation_space[k], env.action_space[k], "cuda:0") for k in range(A)]
+    obs, share, _ = env.reset()
+    for k in range(A):
+        bufs[k].share_obs[0].copy_(share[:, k]); bufs[k].obs[0].copy_(obs[:, k])
+    rnn = torch.zeros(n, 1, 512, device="cuda")
+
+    def reference_way():
+        with torch.no_grad():
+            for t in range(T):
+                vals, acts, lps = [], [], []
+                for k in range(A):                                                    # runner.py:198-227
+                    mean, std, value = mm.torch_forward(actors[k], critics[k], bufs[k].obs[t], bufs[k].share_obs[t])
+                    dist = torch.distributions.Normal(mean, std)
+                    act = dist.sample()
+                    vals.append(value); acts.append(act); lps.append(dist.log_prob(act))
+                obs, share, rew, dones, _, _ = env.step(acts)
+                dones_env = torch.all(dones != 0, dim=1)
+                masks = torch.ones(n, A, 1, device="cuda")
+                masks[dones_env] = 0
+                for k in range(A):
+                    bufs[k].insert(share[:, k], obs[:, k], rnn, rnn, acts[k], lps[k], vals[k], rew[:, k], masks[:, k])
+            for k in range(A):                                                        # runner.py:229-241 (compute)
+                _, _, nxt = mm.torch_forward(actors[k], critics[k], bufs[k].obs[-1], bufs[k].share_obs[-1])
+                bufs[k].compute_returns(nxt, None)
+                bufs[k].after_update()
+    out["reference_way_eager"] = timed(reference_way, max(2, args.iters // 4))
+    env.task.engine.close()
+    del bufs
+
+    # ---- fused --------------------------------------------------------------------------------------------------------------------
+    env = make_env()
+    sh = SharedRolloutBuffers(conf, env, "cuda:0")
+    sh.warmup()
+    inf = GroupedPolicyInference(actors, critics, seed=3)
+    nxt = torch.zeros(n, A, device="cuda")
+
+    def fused():
+        for t in range(T):
+            s = sh.step
+            actions = inf.collect_into(sh)
+            rew, dones = sh.env_step(actions)
+            sh.insert_step(rew, dones, sh.value_preds[s], sh.actions[s], sh.action_log_probs[s])
+        inf.values_into(sh, nxt)
+        sh.compute_returns(nxt, None)
+        sh.after_update()
+    out["fused_eager"] = timed(fused, args.iters)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fused()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            fused()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    out["fused_graph"] = timed(graph.replay, args.iters)
+    out["finite"] = bool(torch.isfinite(sh.returns).all()) and bool(torch.isfinite(sh.share_obs).all())
+    out["speedup_eager"] = out["reference_way_eager"]["ms_per_env_step"] / out["fused_eager"]["ms_per_env_step"]
+    out["speedup_graph_vs_reference_eager"] = out["reference_way_eager"]["ms_per_env_step"] / out["fused_graph"]["ms_per_env_step"]
+    env.task.engine.close()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
