@@ -32,7 +32,7 @@
  *     (algorithms/rl/ppo/module.py:73-87; storage.py:33-47)              mms_bind_rollout_out
  *   ActorCritic hidden layers (module.py:27-52)                          mms_linear2_act
  *   Actor / Critic forward of every MAPPO / HAPPO agent                  mms_linear_group_act, mms_layernorm_group,
- *     (algorithms/marl/actor_critic.py:43-69, 137-155; runner.py:186-216)  mms_marl_heads_act
+ *     (algorithms/marl/actor_critic.py:43-69, 137-155; runner.py:186-216)  mms_row_stats_group, mms_marl_heads_act
  *
  * Ownership: the engine owns every buffer it reports through mms_get_tensor for the lifetime of the
  * handle; callers wrap them as NON-owning views and must keep the handle alive while any view exists.
@@ -250,9 +250,21 @@ int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const float* x0
  * `groups` device pointers.  Recurrent policies (use_recurrent_policy) are not covered. */
 #define MMS_MAX_GROUPS 32
 
-/* y_g = act(x_g @ w_g^T + b_g), g < groups: mms_linear2_act for any number of networks (same kernel, same shapes rules). */
+/* y_g = act(x_g @ w_g^T + b_g), g < groups: mms_linear2_act for any number of networks (same kernel, same shapes rules).
+ * The three ln_* arguments (all NULL: none) fold the LayerNorms on either side of the layer into it, so that the normalised
+ * activations are never written (they need act = ELU, M and N multiples of 128, and K a multiple of 32 for ln_stat_in):
+ *   ln_part_out[g] [N/64, M, 2]: the epilogue also leaves per output row and per 64-column slot the sum and the sum of squares of
+ *     the activations; mms_row_stats_group turns them into (mean, rstd) per row.  No atomics: the result does not depend on scheduling.
+ *   ln_stat_in[g] [M, 2] + ln_s[g] [N]: x_g is the PRE-LayerNorm activation h and the layer W (LN(h) gamma + beta) + b is evaluated
+ *     as rstd (W~ h - mean s) + c: the caller passes W~ = W diag(gamma) as w_g, s = W~ 1 as ln_s[g] and c = W beta + b as b_g. */
 int mms_linear_group_act(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const float* const* x, const float* const* w,
-                         const float* const* b, float* const* y, int32_t act, void* hip_stream);
+                         const float* const* b, float* const* y, int32_t act, const float* const* ln_s, const float* const* ln_stat_in,
+                         float* const* ln_part_out, void* hip_stream);
+
+/* stat_g[r] = (mean, 1 / sqrt(var + eps)) of row r from the `slots` partial (sum, sum of squares) pairs of mms_linear_group_act's
+ * ln_part_out (width = that layer's N; biased variance, as nn.LayerNorm). */
+int mms_row_stats_group(int device, int32_t groups, int64_t M, int32_t slots, int32_t width, const float* const* part, float* const* stat,
+                        float eps, void* hip_stream);
 
 /* nn.LayerNorm over the last dimension (biased variance, eps inside the root): y_g[r, 0:K] = LN(x_g[r, 0:K]) * gamma_g + beta_g,
  * y_g[r, K:Kp] = 0.  x rows have pitch x_pitch floats (0 = K; A * K reads one agent's rows of an [N, A, K] block where they lie),

@@ -9,6 +9,10 @@ step for TenAnt.  The networks are independent and of the same shape, so here ev
     fc1: Linear + ELU (mlp.py:19-20)                  mms_linear_group_act  actors (K = obs) | critics (K = share_obs)
     its LayerNorm                                     mms_layernorm_group   all networks, in place
     fc2[i]: Linear + ELU + LayerNorm (mlp.py:26-27)   one mms_linear_group_act + one mms_layernorm_group (in place) each, all networks
+                                                      -- or, for batch and hidden sizes that are multiples of 128, the LayerNorms BETWEEN
+                                                      the layers folded into the layers on either side: the producing layer's epilogue
+                                                      leaves row sums (mms_row_stats_group -> mean, rstd), the consuming layer evaluates
+                                                      rstd (W~ h - mean s) + c; the normalised activations are never written
     last LayerNorm + fc_mean + sample + log-probs     mms_marl_heads_act    all networks (critics: v_out, no sampling)
       (utils/act.py:75-81, distributions.py:94-117;
        actor_critic.py:153)
@@ -69,7 +73,7 @@ def _row_ptrs(tensors):
 
 
 class GroupedPolicyInference:
-    def __init__(self, actors, critics, seed=0, row_offset=0):
+    def __init__(self, actors, critics, seed=0, row_offset=0, fold_layernorm=True):
         if len(actors) != len(critics) or not actors:
             raise ValueError("one actor and one critic per agent")
         if 2 * len(actors) > 32:
@@ -82,6 +86,9 @@ class GroupedPolicyInference:
         self.actors, self.critics = list(actors), list(critics)
         self.n = len(actors)
         self.seed, self.row_offset = int(seed), int(row_offset)
+        # The LayerNorms BETWEEN the hidden layers folded into the layers on either side (mms.h: ln_part_out / ln_stat_in): the
+        # normalised activations are never written.  Used when the shapes allow (batch and hidden size multiples of 128).
+        self.fold_layernorm = bool(fold_layernorm)
         self.a_blocks = [_blocks(a.base) for a in self.actors]
         self.c_blocks = [_blocks(c.base) for c in self.critics]
         depth = {len(b) for b in self.a_blocks + self.c_blocks}
@@ -126,6 +133,16 @@ class GroupedPolicyInference:
         self._w1_c = padded(self.c_blocks, self.sobs_dim, self.kp_c)
         heads = [a.act.action_out for a in self.actors]
         self._std = [(torch.sigmoid(d(hd.log_std) / hd.std_x_coef) * hd.std_y_coef).float().contiguous() for hd in heads]   # distributions.py:116
+        # folded form of hidden layer l >= 1 behind LayerNorm l - 1: W (LN(h) gamma + beta) + b = rstd (W~ h - mean s) + c
+        self._fold = {}
+        both = self.a_blocks + self.c_blocks
+        for l in range(1, self.depth):
+            W = torch.stack([d(b[l][0].weight) for b in both])                         # [2n, H, H]
+            gam = torch.stack([d(b[l - 1][1].weight) for b in both])                   # [2n, H]
+            bet = torch.stack([d(b[l - 1][1].bias) for b in both])
+            bias = torch.stack([d(b[l][0].bias) for b in both])
+            Wt = (W * gam[:, None, :]).contiguous()
+            self._fold[l] = (Wt, Wt.sum(-1).contiguous(), (torch.einsum("gnk,gk->gn", W, bet) + bias).contiguous())
         self._bind()
 
     def _bind(self):
@@ -152,6 +169,8 @@ class GroupedPolicyInference:
             if l > 0:
                 self.p["w%d" % l] = arr([d(b[l][0].weight) for b in both])
                 self.p["b%d" % l] = arr([d(b[l][0].bias) for b in both])
+        for l, (Wt, sv, cv) in self._fold.items():
+            self.p["fw%d" % l], self.p["fs%d" % l], self.p["fc%d" % l] = arr(list(Wt.unbind(0))), arr(list(sv.unbind(0))), arr(list(cv.unbind(0)))
         heads = [a.act.action_out.fc_mean for a in self.actors]
         vouts = [c.v_out for c in self.critics]
         self.p["hw"] = arr([d(m.weight) for m in heads] + [d(m.weight) for m in vouts])
@@ -169,6 +188,7 @@ class GroupedPolicyInference:
         self.h = [z(2 * n, M, H), z(2 * n, M, H)]                                     # hidden activations, ping-pong
         self.actions, self.logp, self.values = z(n, M, self.act_dim), z(n, M, self.act_dim), z(n, M, 1)
         self.counters = torch.zeros(n, M, dtype=torch.int64, device=dev)
+        self.part, self.stat = z(2 * n, max(1, H // 64), M, 2), z(2 * n, M, 2)        # row statistics of the folded LayerNorms
         ub = lambda t: list(t.unbind(0))
         self.q = {
             "x_a": _ptrs(ub(self.x_a)), "x_c": _ptrs(ub(self.x_c)),
@@ -176,6 +196,7 @@ class GroupedPolicyInference:
             "h0_a": _ptrs(ub(self.h[0][:n])), "h0_c": _ptrs(ub(self.h[0][n:])),
             "out": _ptrs(ub(self.actions) + ub(self.values)), "logp": _ptrs(ub(self.logp) + [None] * n),
             "cnt": _ptrs(ub(self.counters) + [None] * n),
+            "part": _ptrs(ub(self.part)), "part_a": _ptrs(ub(self.part[:n])), "part_c": _ptrs(ub(self.part[n:])), "stat": _ptrs(ub(self.stat)),
         }
         self._M = M
 
@@ -202,14 +223,22 @@ class GroupedPolicyInference:
         chk(L.mms_layernorm_group(idx, n, M, self.obs_dim, self.kp_a, obs_pitch, obs_p, p["fn_a_g"], p["fn_a_b"], q["x_a"], self.eps, stream), "mms_layernorm_group")
         chk(L.mms_layernorm_group(idx, n, M, self.sobs_dim, self.kp_c, sobs_pitch, sobs_p, p["fn_c_g"], p["fn_c_b"], q["x_c"], self.eps, stream), "mms_layernorm_group")
         H = self.hidden
-        chk(L.mms_linear_group_act(idx, n, M, H, self.kp_a, q["x_a"], p["w1_a"], p["b1_a"], q["h0_a"], 1, stream), "mms_linear_group_act")
-        chk(L.mms_linear_group_act(idx, n, M, H, self.kp_c, q["x_c"], p["w1_c"], p["b1_c"], q["h0_c"], 1, stream), "mms_linear_group_act")
+        fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0
+        slots = H // 64
+        chk(L.mms_linear_group_act(idx, n, M, H, self.kp_a, q["x_a"], p["w1_a"], p["b1_a"], q["h0_a"], 1, None, None, q["part_a"] if fold else None, stream), "mms_linear_group_act")
+        chk(L.mms_linear_group_act(idx, n, M, H, self.kp_c, q["x_c"], p["w1_c"], p["b1_c"], q["h0_c"], 1, None, None, q["part_c"] if fold else None, stream), "mms_linear_group_act")
         cur = 0
         for l in range(self.depth):
-            if l > 0:
-                chk(L.mms_linear_group_act(idx, 2 * n, M, H, H, q["h%d" % cur], p["w%d" % l], p["b%d" % l], q["h%d" % (1 - cur)], 1, stream), "mms_linear_group_act")
+            if l > 0 and fold:                                      # LayerNorm l - 1 folded in; leaves the statistics of LayerNorm l
+                chk(L.mms_row_stats_group(idx, 2 * n, M, slots, H, q["part"], q["stat"], self.eps, stream), "mms_row_stats_group")
+                chk(L.mms_linear_group_act(idx, 2 * n, M, H, H, q["h%d" % cur], p["fw%d" % l], p["fc%d" % l], q["h%d" % (1 - cur)], 1, p["fs%d" % l], q["stat"],
+                                           q["part"] if l + 1 < self.depth else None, stream), "mms_linear_group_act")
                 cur = 1 - cur
-            if l + 1 < self.depth:                                  # (the last LayerNorm runs inside the heads kernel)
+                continue
+            if l > 0:
+                chk(L.mms_linear_group_act(idx, 2 * n, M, H, H, q["h%d" % cur], p["w%d" % l], p["b%d" % l], q["h%d" % (1 - cur)], 1, None, None, None, stream), "mms_linear_group_act")
+                cur = 1 - cur
+            if l + 1 < self.depth and not fold:                     # (the last LayerNorm runs inside the heads kernel)
                 chk(L.mms_layernorm_group(idx, 2 * n, M, H, H, H, q["h%d" % cur], p["ln%d_g" % l], p["ln%d_b" % l], q["h%d" % cur], self.eps, stream), "mms_layernorm_group")
         last = self.depth - 1
         if out is None:

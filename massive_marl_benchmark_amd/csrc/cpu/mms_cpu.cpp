@@ -394,22 +394,58 @@ static bool bad_groups(int32_t groups, const char* what) {
     return true;
 }
 MMS_API int mms_linear_group_act(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const float* const* x, const float* const* w,
-                                 const float* const* b, float* const* y, int32_t act, void*) {
+                                 const float* const* b, float* const* y, int32_t act, const float* const* ln_s, const float* const* ln_stat_in,
+                                 float* const* ln_part_out, void*) {
     if (cpu_only(device)) return 1;
     if (bad_groups(groups, "mms_linear_group_act")) return 1;
     if (!x || !w || !b || !y || M < 0 || N <= 0 || K <= 0 || (K % 4) != 0 || act < 0 || act > 3) {
         g_error = "mms_linear_group_act: bad arguments (K must be a positive multiple of 4, act 0..3)";
         return 1;
     }
+    if ((ln_stat_in != nullptr) != (ln_s != nullptr)) { g_error = "mms_linear_group_act: ln_stat_in and ln_s come together"; return 1; }
+    if ((ln_stat_in || ln_part_out) && (act != 1 || M % 128 != 0 || N % 128 != 0 || K < 8 || (ln_stat_in && K % 32 != 0))) {
+        g_error = "mms_linear_group_act: the LayerNorm folds need act = ELU, M and N multiples of 128 (K a multiple of 32 for ln_stat_in)";
+        return 1;
+    }
     for (int g = 0; g < groups; g++) {
-        if (!x[g] || !w[g] || !b[g] || !y[g]) { g_error = "mms_linear_group_act: null pointer in a group"; return 1; }
+        if (!x[g] || !w[g] || !b[g] || !y[g] || (ln_s && (!ln_s[g] || !ln_stat_in[g])) || (ln_part_out && !ln_part_out[g])) {
+            g_error = "mms_linear_group_act: null pointer in a group";
+            return 1;
+        }
 #pragma omp parallel for schedule(static)
-        for (int64_t m = 0; m < M; m++)
+        for (int64_t m = 0; m < M; m++) {
             for (int n = 0; n < N; n++) {
                 float s = 0.f;
                 for (int k = 0; k < K; k++) s = fmaf(x[g][m * K + k], w[g][(int64_t)n * K + k], s);
+                if (ln_s) s = ln_stat_in[g][2 * m + 1] * (s - ln_stat_in[g][2 * m] * ln_s[g][n]);      // rstd (W~ h - mean s)
                 y[g][m * N + n] = act_fn(s + b[g][n], act);
             }
+            if (ln_part_out)                                                                            // slot = 64 consecutive columns
+                for (int slot = 0; slot < N / 64; slot++) {
+                    float ps = 0.f, pq = 0.f;
+                    for (int n = 64 * slot; n < 64 * slot + 64; n++) { const float v = y[g][m * N + n]; ps += v; pq += v * v; }
+                    ln_part_out[g][((int64_t)slot * M + m) * 2] = ps;
+                    ln_part_out[g][((int64_t)slot * M + m) * 2 + 1] = pq;
+                }
+        }
+    }
+    return 0;
+}
+MMS_API int mms_row_stats_group(int device, int32_t groups, int64_t M, int32_t slots, int32_t width, const float* const* part, float* const* stat,
+                                float eps, void*) {
+    if (cpu_only(device)) return 1;
+    if (bad_groups(groups, "mms_row_stats_group")) return 1;
+    if (!part || !stat || M < 0 || slots < 1 || width < 1) { g_error = "mms_row_stats_group: bad arguments"; return 1; }
+    for (int g = 0; g < groups; g++) {
+        if (!part[g] || !stat[g]) { g_error = "mms_row_stats_group: null pointer in a group"; return 1; }
+        for (int64_t m = 0; m < M; m++) {
+            float sum = 0.f, sq = 0.f;
+            for (int k = 0; k < slots; k++) { sum += part[g][((int64_t)k * M + m) * 2]; sq += part[g][((int64_t)k * M + m) * 2 + 1]; }
+            const float mean = sum / (float)width;
+            const float var = fmaxf(sq / (float)width - mean * mean, 0.f);
+            stat[g][2 * m] = mean;
+            stat[g][2 * m + 1] = 1.0f / sqrtf(var + eps);
+        }
     }
     return 0;
 }

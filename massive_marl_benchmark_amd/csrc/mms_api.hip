@@ -435,20 +435,47 @@ static bool bad_group_count(int32_t groups, const char* what) {
 }
 
 __attribute__((visibility("default"))) int mms_linear_group_act(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const float* const* x,
-                                                                const float* const* w, const float* const* b, float* const* y, int32_t act, void* s) {
+                                                                const float* const* w, const float* const* b, float* const* y, int32_t act,
+                                                                const float* const* ln_s, const float* const* ln_stat_in, float* const* ln_part_out,
+                                                                void* s) {
     MMS_DEV(device)
     if (bad_group_count(groups, "mms_linear_group_act")) return 1;
     if (!x || !w || !b || !y || M < 0 || M > 0x7fffffff || N <= 0 || K <= 0 || (K % 4) != 0 || act < 0 || act > 3) {
         g_create_error = "mms_linear_group_act: bad arguments (K must be a positive multiple of 4, act 0..3)";
         return 1;
     }
+    if ((ln_stat_in != nullptr) != (ln_s != nullptr)) { g_create_error = "mms_linear_group_act: ln_stat_in and ln_s come together"; return 1; }
+    if ((ln_stat_in || ln_part_out) && (act != 1 || M % 128 != 0 || N % 128 != 0 || K < 8 || (ln_stat_in && K % 32 != 0))) {
+        g_create_error = "mms_linear_group_act: the LayerNorm folds need act = ELU, M and N multiples of 128 (K a multiple of 32 for ln_stat_in)";
+        return 1;
+    }
     mms::LinearArgs a = {};
     for (int g = 0; g < groups; g++) {
-        if (!x[g] || !w[g] || !b[g] || !y[g]) { g_create_error = "mms_linear_group_act: null pointer in a group"; return 1; }
+        if (!x[g] || !w[g] || !b[g] || !y[g] || (ln_s && (!ln_s[g] || !ln_stat_in[g])) || (ln_part_out && !ln_part_out[g])) {
+            g_create_error = "mms_linear_group_act: null pointer in a group";
+            return 1;
+        }
         a.x[g] = x[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.y[g] = y[g];
+        if (ln_s) { a.s[g] = ln_s[g]; a.stat_in[g] = ln_stat_in[g]; }
+        if (ln_part_out) a.part_out[g] = ln_part_out[g];
     }
     a.M = (int)M; a.N = N; a.K = K; a.act = act;
     MMS_FREE(mms::launch_linear_act(a, groups, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_row_stats_group(int device, int32_t groups, int64_t M, int32_t slots, int32_t width, const float* const* part,
+                                                               float* const* stat, float eps, void* s) {
+    MMS_DEV(device)
+    if (bad_group_count(groups, "mms_row_stats_group")) return 1;
+    if (!part || !stat || M < 0 || slots < 1 || width < 1) { g_create_error = "mms_row_stats_group: bad arguments"; return 1; }
+    mms::RowStatsArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!part[g] || !stat[g]) { g_create_error = "mms_row_stats_group: null pointer in a group"; return 1; }
+        a.part[g] = part[g]; a.stat[g] = stat[g];
+    }
+    a.M = M; a.slots = slots; a.width = width; a.eps = eps;
+    MMS_FREE(mms::launch_row_stats(a, groups, (hipStream_t)s));
     return 0;
 }
 

@@ -15,6 +15,25 @@ struct LinearArgs {
     float* y[kMaxGroups];
     int M, N, K;
     int act;        // 0: identity, 1: ELU (alpha = 1), 2: ReLU, 3: tanh
+    // LayerNorm folded into the layers on either side of it (grouped MARL inference; all NULL otherwise).
+    //   part_out[g] != NULL: the epilogue also leaves, per output row, the sum and the sum of squares of its 64 activations:
+    //     part_out[g][(slot * M + row) * 2 + {0, 1}], slot = 2 * column_tile + wave half, N / 64 slots -- no atomics, so the
+    //     statistics (launch_row_stats sums the slots in order) do not depend on block scheduling.
+    //   stat_in[g] != NULL: x_g is the PRE-LayerNorm activation h and the layer is W (LN(h) gamma + beta) + b, evaluated as
+    //     rstd (W~ h - mean s) + c with W~ = W diag(gamma) (passed as w_g), s = W~ 1 (s_g), c = W beta + b (passed as b_g) and
+    //     (mean, rstd) per row from stat_in[g][row * 2 + {0, 1}].
+    const float* s[kMaxGroups];
+    const float* stat_in[kMaxGroups];
+    float* part_out[kMaxGroups];
+};
+
+// (mean, 1 / sqrt(var + eps)) per row from the slot partials a layer's epilogue left (LinearArgs::part_out): stat_g[row * 2 + {0, 1}]
+struct RowStatsArgs {
+    const float* part[kMaxGroups];
+    float* stat[kMaxGroups];
+    int64_t M;
+    int slots, width;       // width = the layer's N (the number of activations per row)
+    float eps;
 };
 
 // y_g[r, 0:K] = LayerNorm(x_g[r, 0:K]) * gamma_g + beta_g, y_g[r, K:Kp] = 0 (row pitch Kp >= K): nn.LayerNorm over the last
@@ -52,6 +71,7 @@ struct HeadsArgs {
 };
 
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
+hipError_t launch_row_stats(const RowStatsArgs& a, int groups, hipStream_t s);
 hipError_t launch_layernorm(const LayerNormArgs& a, int groups, hipStream_t s);
 hipError_t launch_marl_heads(const HeadsArgs& a, int groups, hipStream_t s);
 

@@ -185,7 +185,9 @@ __global__ void __launch_bounds__(256, 2) linear_act_kernel(LinearArgs a) {
 // ELU_ONLY: the PPO policy's activation compiled in (one compare per output element instead of the run-time dispatch).
 // MI = 2: 128 x 128 tile per block (64 x 64 per wave); MI = 1: 64 x 128 (32 x 64 per wave), for launches whose 128-row tiling
 // would put one block on a CU: two waves per SIMD are what keeps the matrix pipe fed across barriers and fragment reads.
-template <bool TAIL, bool ELU_ONLY, int MI>
+// LN (grouped MARL inference, MI = 2 and ELU only): bit 0 = leave row statistics of the output for the LayerNorm behind this layer
+// (LinearArgs::part_out), bit 1 = the LayerNorm in front of this layer is folded into it (LinearArgs::stat_in, s).
+template <bool TAIL, bool ELU_ONLY, int MI, int LN = 0>
 __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N = a.N, K = a.K;
@@ -312,8 +314,65 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
             yp[(size_t)((r & 3) + 8 * (r >> 2)) * N] = v;                                                    \
         }                                                                                                    \
     }
-    MMS_EPI(acc00, 0, 0) MMS_EPI(acc01, 0, 1)
-    if (MI == 2) { MMS_EPI(acc10, 1, 0) MMS_EPI(acc11, 1, 1) }
+    if constexpr (LN == 0) {
+        MMS_EPI(acc00, 0, 0) MMS_EPI(acc01, 0, 1)
+        if (MI == 2) { MMS_EPI(acc10, 1, 0) MMS_EPI(acc11, 1, 1) }
+    } else {
+        static_assert(LN == 0 || (MI == 2 && ELU_ONLY), "the LayerNorm folds exist for the 128 x 128 ELU tiling only");
+        const int col0 = n0 + wc + li, col1 = col0 + 32;
+        const float bias0 = Bv[col0], bias1 = Bv[col1];
+        float s0 = 0.f, s1 = 0.f;
+        if (LN & 2) { s0 = a.s[g][col0]; s1 = a.s[g][col1]; }
+        const float2* stat = reinterpret_cast<const float2*>(a.stat_in[g]);
+        float2* part = reinterpret_cast<float2*>(a.part_out[g]) + (size_t)(2 * tn + (wave & 1)) * a.M;
+#define MMS_EPI_LN(ACC0, ACC1, I)                                                                                               \
+        {                                                                                                                        \
+            const int rbase = m0 + wr + 32 * (I) + 4 * lh;                                                                       \
+            float ps[16], pq[16];                                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                                     \
+                const int row = rbase + (r & 3) + 8 * (r >> 2);                                                                  \
+                float v0 = ACC0[r], v1 = ACC1[r];                                                                                \
+                if (LN & 2) {                                                                                                    \
+                    const float2 st = stat[row];                      /* (mean, rstd): the same address across the 32 lanes */  \
+                    v0 = st.y * (v0 - st.x * s0);                                                                                \
+                    v1 = st.y * (v1 - st.x * s1);                                                                                \
+                }                                                                                                                \
+                v0 += bias0; v1 += bias1;                                                                                        \
+                v0 = (v0 > 0.f) ? v0 : (expf(v0) - 1.f);                                                                         \
+                v1 = (v1 > 0.f) ? v1 : (expf(v1) - 1.f);                                                                         \
+                Y[(size_t)row * N + col0] = v0;                                                                                  \
+                Y[(size_t)row * N + col1] = v1;                                                                                  \
+                ps[r] = v0 + v1;                                                                                                 \
+                pq[r] = v0 * v0 + v1 * v1;                                                                                       \
+            }                                                                                                                    \
+            if (LN & 1) {                                                                                                        \
+                /* sums over the wave's 64 columns: a halving butterfly over the 32 lanes of a half (ds_swizzle, xor masks as   \
+                   immediates): each step a lane keeps half of its values and adds the partner's, so lane li ends with row      \
+                   r = li >> 1 of its sixteen */                                                                                 \
+                MMS_BFLY(ps, pq, 8, 16) MMS_BFLY(ps, pq, 4, 8) MMS_BFLY(ps, pq, 2, 4) MMS_BFLY(ps, pq, 1, 2)                     \
+                ps[0] += MMS_SWZ(ps[0], 1);                                                                                      \
+                pq[0] += MMS_SWZ(pq[0], 1);                                                                                      \
+                const int r = li >> 1;                                                                                           \
+                if ((li & 1) == 0) part[rbase + (r & 3) + 8 * (r >> 2)] = make_float2(ps[0], pq[0]);                              \
+            }                                                                                                                    \
+        }
+#define MMS_SWZ(v, mask) __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x1F | ((mask) << 10)))
+#define MMS_BFLY(A, B, HALF, MASK)                                                                                              \
+        {                                                                                                                        \
+            const bool up = (li & (MASK)) != 0;                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < (HALF); i++) {                                                                 \
+                const float ka = up ? A[(HALF) + i] : A[i], sa = up ? A[i] : A[(HALF) + i];                                      \
+                const float kb = up ? B[(HALF) + i] : B[i], sb = up ? B[i] : B[(HALF) + i];                                      \
+                A[i] = ka + MMS_SWZ(sa, MASK);                                                                                   \
+                B[i] = kb + MMS_SWZ(sb, MASK);                                                                                   \
+            }                                                                                                                    \
+        }
+        MMS_EPI_LN(acc00, acc01, 0)
+        MMS_EPI_LN(acc10, acc11, 1)
+#undef MMS_EPI_LN
+#undef MMS_BFLY
+#undef MMS_SWZ
+    }
 #undef MMS_EPI
 }
 #undef MMS_MFMA4
@@ -321,7 +380,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
 
 // More than 64 KB of dynamic LDS needs an opt-in per kernel and per device; remembered so that it is asked for once.
 static hipError_t allow_large_lds(const void* kernel, int slot) {
-    static bool done[12][64] = {};
+    static bool done[16][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -341,7 +400,9 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     // 128-row tiles that would leave CUs without a block: 64-row tiles, twice the blocks.  (At exactly one block per CU -- the
     // policy's 512-wide layer -- both tilings measure the same, 72-78 us: the fixed cost of a launch dominates, not the slice rate.)
     static const int small_max = getenv("MMS_LINEAR_SMALL_MAX") ? atoi(getenv("MMS_LINEAR_SMALL_MAX")) : 255;
-    const bool small = (size_t)grid.x * grid.y * grid.z <= (size_t)small_max && a.M > 64 && !getenv("MMS_LINEAR_TALL_TILES");
+    const bool ln_out = a.part_out[0] != nullptr, ln_in = a.stat_in[0] != nullptr;
+    // (the LayerNorm folds exist for the 128-row tiling only: a small grid keeps it when they are asked for)
+    const bool small = (size_t)grid.x * grid.y * grid.z <= (size_t)small_max && a.M > 64 && !getenv("MMS_LINEAR_TALL_TILES") && !ln_out && !ln_in;
     const bool fast = a.M % (small ? 64 : kTM) == 0 && a.N % kTN == 0 && a.K >= 8 && !getenv("MMS_LINEAR_GENERIC");
     if (small) grid.y = (a.M + 63) / 64;
 #define MMS_LAUNCH_FAST(TAIL, ELU, MI, SLOT)                                                                                   \
@@ -350,7 +411,21 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
         if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(kern), SLOT); e != hipSuccess) return e;              \
         hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(256), kLinearLds, s, a);                                 \
     }
+#define MMS_LAUNCH_FAST_LN(TAIL, LNF, SLOT)                                                                                     \
+    {                                                                                                                          \
+        auto kern = linear_act_fast_kernel<TAIL, true, 2, LNF>;                                                                \
+        if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(kern), SLOT); e != hipSuccess) return e;              \
+        hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(256), kLinearLds, s, a);                                 \
+    }
     const bool tail = a.K % kBK != 0, elu = a.act == 1;
+    if (ln_out || ln_in) {                  // the LayerNorm folds: the callers (mms_linear_group_act) only ask for them where they exist
+        if (!(fast && !small && elu) || (ln_in && tail)) return hipErrorInvalidValue;
+        if (ln_in && ln_out) MMS_LAUNCH_FAST_LN(false, 3, 12)
+        else if (ln_in) MMS_LAUNCH_FAST_LN(false, 2, 13)
+        else if (tail) MMS_LAUNCH_FAST_LN(true, 1, 14)
+        else MMS_LAUNCH_FAST_LN(false, 1, 15)
+        return hipGetLastError();
+    }
     if (fast && !small) {
         if (!tail && elu) MMS_LAUNCH_FAST(false, true, 2, 3)
         else if (tail && elu) MMS_LAUNCH_FAST(true, true, 2, 4)
@@ -364,6 +439,7 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     } else if (small) hipLaunchKernelGGL(linear_act_kernel<1>, grid, dim3(256), kLinearLds, s, a);
     else hipLaunchKernelGGL(linear_act_kernel<2>, grid, dim3(256), kLinearLds, s, a);
 #undef MMS_LAUNCH_FAST
+#undef MMS_LAUNCH_FAST_LN
     return hipGetLastError();
 }
 
@@ -474,6 +550,30 @@ __global__ void __launch_bounds__(256) marl_heads_kernel(HeadsArgs a) {
         }
         if (lane == 0 && a.counters[g]) a.counters[g][row] = c + 1;
     }
+}
+
+// (mean, rstd) per row from the slot partials: thread = row, the slots summed in order
+__global__ void __launch_bounds__(256) row_stats_kernel(RowStatsArgs a) {
+    const int g = blockIdx.y;
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.M) return;
+    const float2* part = reinterpret_cast<const float2*>(a.part[g]);
+    float sum = 0.f, sq = 0.f;
+    for (int k = 0; k < a.slots; k++) {
+        const float2 p = part[(size_t)k * a.M + row];
+        sum += p.x;
+        sq += p.y;
+    }
+    const float inv = 1.0f / (float)a.width;
+    const float mean = sum * inv;
+    const float var = fmaxf(sq * inv - mean * mean, 0.f);
+    reinterpret_cast<float2*>(a.stat[g])[row] = make_float2(mean, 1.0f / sqrtf(var + a.eps));
+}
+
+hipError_t launch_row_stats(const RowStatsArgs& a, int groups, hipStream_t s) {
+    if (a.M == 0 || groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((a.M + 255) / 256), groups), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_layernorm(const LayerNormArgs& a, int groups, hipStream_t s) {
