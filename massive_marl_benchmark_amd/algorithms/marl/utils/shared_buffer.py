@@ -110,6 +110,30 @@ def all_gather_envs(tensors, group=None):
     return out
 
 
+def happo_factor_chain(order, owner_of, train_agent, factor, group=None):
+    """The sequential-update chain of HAPPO / HATRPO (agents/algorithms/marl/runner.py:266-316) with AGENT-PARALLEL training
+    (SURVEY.md section 8e): agents are updated one after another in `order` (the reference draws torch.randperm), agent k's
+    surrogate is weighted by `factor` = the product, over the agents updated before it, of exp(sum_dims(new_logp - old_logp))
+    (:312-313).  `owner_of(k)` names the rank that trains agent k; on that rank `train_agent(k, factor)` is called -- it must
+    `update_factor`, evaluate the old log-probs, train, evaluate the new ones (runner.py:277-311) and return
+    (old_logp, new_logp), each [T, N, act_dim] -- and the updated [T, N, 1] factor travels to everybody with ONE broadcast per
+    agent from its owner (the next owner needs it; the others need it only to stay in step, and a broadcast over RCCL costs what
+    a send does at this size: T N floats = 131 KB at 4096 envs).  `order` must be the same on every rank (draw it on rank 0 and
+    broadcast it, or seed it).  Without a process group (or world size 1) this is exactly the reference's loop.  Returns factor."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if multi else 0
+    for k in [int(x) for x in order]:
+        src = owner_of(k) if multi else 0
+        if rank == src:
+            old_logp, new_logp = train_agent(k, factor)
+            factor = factor * torch.exp((new_logp.detach() - old_logp.detach()).sum(dim=-1, keepdim=True))   # runner.py:312-313
+        if multi:
+            factor = factor.contiguous()
+            dist.broadcast(factor, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    return factor
+
+
 class SharedRolloutBuffers:
     def __init__(self, config, env, device):
         self.T = config["episode_length"]

@@ -266,6 +266,27 @@ local = {k: torch.from_numpy(np.ascontiguousarray(v[:, rank * NL:(rank + 1) * NL
 got = all_gather_envs(local)
 for k, v in glob.items():
     assert got[k].shape == v.shape and np.array_equal(got[k].numpy(), v), k
+# HAPPO's sequential factor chain with agent-parallel training (runner.py:266-316): rank r trains agents r, r + world, ...
+from massive_marl_benchmark_amd.algorithms.marl.utils.shared_buffer import happo_factor_chain
+A, T, N, D = 6, 3, 8, 4
+g = torch.Generator().manual_seed(17)
+old = torch.randn(A, T, N, D, generator=g) * 0.1
+new = torch.randn(A, T, N, D, generator=g) * 0.1
+order = torch.randperm(A, generator=g)
+seen = []
+def train_agent(k, factor):
+    seen.append((k, factor.clone()))
+    return old[k], new[k]
+f = happo_factor_chain(order, lambda k: k %% world, train_agent, torch.ones(T, N, 1))
+ref = torch.ones(T, N, 1)
+want = {}
+for k in [int(x) for x in order]:                                   # the reference's single-process loop
+    want[k] = ref.clone()
+    ref = ref * torch.exp((new[k] - old[k]).sum(-1, keepdim=True))
+assert torch.allclose(f, ref, rtol=1e-6, atol=0)
+assert [k for k, _ in seen] == [int(x) for x in order if int(x) %% world == rank]
+for k, fk in seen:
+    assert torch.allclose(fk, want[k], rtol=1e-6, atol=0), k       # every owner saw the factor of the agents updated before its own
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
