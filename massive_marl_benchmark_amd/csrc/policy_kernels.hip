@@ -259,6 +259,9 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
         const float* ab = a_fr + (BUF) * kBuf;                                                                                   \
         const float* bb = b_fr + (BUF) * kBuf;                                                                                   \
         const int kl = ((KT) + 2 < nkt ? (KT) + 2 : nkt - 1) * kBK;      /* past the end: reload the last slice, never stored */ \
+        /* (TAIL) the last slice holds K - 32 (nkt - 1) valid k: only the 8-k groups that contain any are multiplied -- the     \
+           388-wide first layer ends with 4 valid k, i.e. 16 MFMAs instead of 64 (the skipped ones would add exact zeros) */    \
+        const int ng = (TAIL && (KT) == nkt - 1) ? g_last : 4;                                                                   \
         MMS_FRAGS(1, ab, bb, 8)                                                                                                  \
         MMS_MFMA4(0, x)                                                                                                          \
         MMS_LD(LD, 0, kl)            \
@@ -272,27 +275,32 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
         MMS_MFMA4(0, w)                                                                                                          \
         MMS_LD(LD, 3, kl) \
         __builtin_amdgcn_sched_barrier(0);                                                                                       \
-        MMS_FRAGS(0, ab, bb, 16)                                                                                                 \
-        MMS_MFMA4(1, x)                                                                                                          \
-        MMS_ST(ST, 0, (1 - (BUF)) * kBuf) \
-        __builtin_amdgcn_sched_barrier(0);                                                                                       \
-        MMS_MFMA4(1, y)                                                                                                          \
-        MMS_ST(ST, 1, (1 - (BUF)) * kBuf) \
-        __builtin_amdgcn_sched_barrier(0);                                                                                       \
-        MMS_MFMA4(1, z)                                                                                                          \
-        MMS_ST(ST, 2, (1 - (BUF)) * kBuf) \
-        __builtin_amdgcn_sched_barrier(0);                                                                                       \
-        MMS_MFMA4(1, w)                                                                                                          \
-        MMS_ST(ST, 3, (1 - (BUF)) * kBuf) \
-        __builtin_amdgcn_sched_barrier(0);                                                                                       \
-        MMS_FRAGS(1, ab, bb, 24)                                                                                                 \
-        MMS_MFMA4(0, x) MMS_MFMA4(0, y) MMS_MFMA4(0, z) MMS_MFMA4(0, w)                                                          \
-        __syncthreads();                                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                                       \
-        MMS_FRAGS(0, a_fr + (1 - (BUF)) * kBuf, b_fr + (1 - (BUF)) * kBuf, 0)                                                    \
-        MMS_MFMA4(1, x) MMS_MFMA4(1, y) MMS_MFMA4(1, z) MMS_MFMA4(1, w)                                                          \
+        if (ng > 1) {                                                                                                            \
+            MMS_FRAGS(0, ab, bb, 16)                                                                                             \
+            MMS_MFMA4(1, x)                                                                                                      \
+            MMS_ST(ST, 0, (1 - (BUF)) * kBuf) \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            MMS_MFMA4(1, y)                                                                                                      \
+            MMS_ST(ST, 1, (1 - (BUF)) * kBuf) \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            MMS_MFMA4(1, z)                                                                                                      \
+            MMS_ST(ST, 2, (1 - (BUF)) * kBuf) \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            MMS_MFMA4(1, w)                                                                                                      \
+            MMS_ST(ST, 3, (1 - (BUF)) * kBuf) \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            if (ng > 2) {                                                                                                        \
+                MMS_FRAGS(1, ab, bb, 24)                                                                                         \
+                MMS_MFMA4(0, x) MMS_MFMA4(0, y) MMS_MFMA4(0, z) MMS_MFMA4(0, w)                                                  \
+                __syncthreads();                  /* (ng is block-uniform: every wave of the block takes the same path) */      \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                MMS_FRAGS(0, a_fr + (1 - (BUF)) * kBuf, b_fr + (1 - (BUF)) * kBuf, 0)                                            \
+                if (ng > 3) { MMS_MFMA4(1, x) MMS_MFMA4(1, y) MMS_MFMA4(1, z) MMS_MFMA4(1, w) }                                  \
+            }                                                                                                                    \
+        }                                                                                                                        \
     }
 
+    const int g_last = (K - (nkt - 1) * kBK + 7) >> 3;      // 8-k groups of the last slice that hold valid k (1..4)
     for (int kt = 0; kt < nkt; kt += 2) {                   // two slices per trip so that the register sets alternate by name
         MMS_SLICE(0, 1, 0, kt)
         if (kt + 1 >= nkt) break;
