@@ -226,7 +226,7 @@ def main():
             if storage.step == NSTEPS:
                 ac_.join()                                                   # deferred critic passes: values are read from here on
                 with torch.no_grad():
-                    last_values = ac_.critic(obs_clipped.to(pdtype)).float()
+                    last_values = (ac_.critic(obs_clipped.to(pdtype)) if args.library_gemms else ac_.value(obs_clipped.to(pdtype))).float()
                 storage.compute_returns(last_values, GAMMA, LAM)
                 storage.clear()
 

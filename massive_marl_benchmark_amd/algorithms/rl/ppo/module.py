@@ -58,6 +58,7 @@ class ActorCritic(nn.Module):
         self._side = None       # second HIP stream: the critic MLP runs beside the actor MLP (see act)
         self._trunk = None
         self._act_bufs = None
+        self._value_bufs = None
 
     @staticmethod
     def init_weights(sequential, scales):
@@ -208,6 +209,31 @@ class ActorCritic(nn.Module):
         """Make the current stream wait for deferred critic passes (see `defer_value`)."""
         if self._side is not None:
             torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+
+    def value(self, critic_in):
+        """Not in the reference (ppo.py:163 calls `act` once more for the bootstrap value of a rollout and discards the action): the
+        critic alone, [N, 1].  fp32 ELU critics on the GPU run their hidden layers through mms_linear2_act (one network; bias + ELU
+        in the epilogue) and the 1-wide output layer as a matrix-vector product; anything else goes through the torch module."""
+        with torch.no_grad():
+            lin = [m for m in self.critic if isinstance(m, nn.Linear)]
+            acts = [m for m in self.critic if not isinstance(m, nn.Linear)]
+            x = critic_in
+            ok = (self.fuse_layers and x.is_cuda and x.dtype == torch.float32 and len(lin) >= 2 and lin[-1].out_features == 1
+                  and all(isinstance(m, nn.ELU) and m.alpha == 1.0 for m in acts)
+                  and all(l.weight.dtype == torch.float32 and l.in_features % 4 == 0 and l.bias is not None for l in lin))
+            if not ok:
+                return self.critic(x)
+            L, idx, stream = _lib.for_device(x.device)
+            p = lambda t: ctypes.c_void_p(t.data_ptr())
+            h, M = x.contiguous(), x.shape[0]
+            key = (M, str(x.device))
+            if self._value_bufs is None or self._value_bufs[0] != key:
+                self._value_bufs = (key, [torch.empty(M, l.out_features, device=x.device) for l in lin[:-1]])
+            for l, y in zip(lin[:-1], self._value_bufs[1]):
+                _lib.check(L.mms_linear2_act(idx, M, l.out_features, l.in_features, p(h), p(l.weight.detach()), p(l.bias.detach()), p(y),
+                                             None, None, None, None, 1, stream), None, "mms_linear2_act", L)
+                h = y
+            return (torch.mv(h, lin[-1].weight.detach()[0]) + lin[-1].bias.detach()).view(-1, 1)
 
     def act_inference(self, observations):
         return self.actor(observations)

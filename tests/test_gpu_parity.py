@@ -1363,3 +1363,22 @@ def test_long_soak_stays_bounded(torch_cuda):
     rc = eng.tensor("reset_count")
     assert int(rc.min()) >= 2 and int(rc.max()) < 400                                      # every env has fallen and restarted, none is stuck resetting
     eng.close()
+
+
+@pytest.mark.gpu
+def test_actor_critic_value_path(torch_cuda):
+    """ActorCritic.value (the bootstrap value of a rollout: the critic alone through mms_linear2_act with one network + a
+    matrix-vector output layer) against the torch module it replaces; fp32 products and sums on both sides: 1e-5 of the scale."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
+    torch.manual_seed(3)
+    ac = ActorCritic((388,), (0,), (80,), 0.8, {"pi_hid_sizes": [1024, 1024, 512], "vf_hid_sizes": [1024, 1024, 512], "activation": "elu"}, seed=1).cuda()
+    x = torch.randn(4096, 388, device="cuda") * 2
+    with torch.no_grad():
+        want = ac.critic(x)
+    got = ac.value(x)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-5 * (1.0 + want.abs().max().item())
+    odd = torch.randn(37, 388, device="cuda")                       # a batch the fast tiling does not cover
+    with torch.no_grad():
+        assert (ac.value(odd) - ac.critic(odd)).abs().max().item() <= 1e-5 * (1.0 + ac.critic(odd).abs().max().item())
