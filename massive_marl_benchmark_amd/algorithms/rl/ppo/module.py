@@ -59,6 +59,7 @@ class ActorCritic(nn.Module):
         self._trunk = None
         self._act_bufs = None
         self._value_bufs = None
+        self._one_bufs = None
 
     @staticmethod
     def init_weights(sequential, scales):
@@ -118,6 +119,22 @@ class ActorCritic(nn.Module):
                                          p(hc), p(lc.weight.detach()), p(lc.bias.detach()), p(yc), 1, stream), None, "mms_linear2_act", L)
             ha, hc = ya, yc
         return ha, hc
+
+    def _hidden_one(self, net, x):
+        """Hidden layers of ONE network through mms_linear2_act (bias + ELU in the epilogue); activations in persistent buffers."""
+        lin = [m for m in net if isinstance(m, nn.Linear)][:-1]
+        L, idx, stream = _lib.for_device(x.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        M = x.shape[0]
+        key = (M, str(x.device), id(net))
+        if self._one_bufs is None or self._one_bufs[0] != key:
+            self._one_bufs = (key, [torch.empty(M, l.out_features, device=x.device) for l in lin])
+        h = x
+        for l, y in zip(lin, self._one_bufs[1]):
+            _lib.check(L.mms_linear2_act(idx, M, l.out_features, l.in_features, p(h), p(l.weight.detach()), p(l.bias.detach()), p(y),
+                                         None, None, None, None, 1, stream), None, "mms_linear2_act", L)
+            h = y
+        return h
 
     def _actor_pass(self, x):
         """The actor MLP up to what the sampling kernel takes: (mean, None) or, when the last Linear layer can run inside
@@ -181,6 +198,20 @@ class ActorCritic(nn.Module):
                             and lc.in_features % 4 == 0 and lc.out_features == 1 and lc.bias is not None):
                         return self._sample(None, None, hidden=ha, vhidden=hc)       # both heads + sampling in one launch
                     return self._sample(la(ha), lc(hc))
+            if (self.fuse_layers and self.fuse_head and self.defer_value and observations.is_cuda and dtype == torch.float32
+                    and self._fp32_layers_qualify() and self.actor[-1].in_features % 64 == 0 and self.actor[-1].out_features <= 128):
+                # The action needs the ACTOR only: its layers run alone on this stream (mms_linear2_act, one network), the sampling
+                # kernel and the env step follow at once, and the whole critic pass (`value`) runs beside them on the second stream;
+                # `join()` is where the owner waits for the values (before the GAE).
+                if self._side is None:
+                    self._side = torch.cuda.Stream(observations.device)
+                cur = torch.cuda.current_stream(observations.device)
+                self._side.wait_stream(cur)                                 # the observation row is ready
+                ha = self._hidden_one(self.actor, observations.contiguous())
+                act, logp, val, mu, sigma = self._sample(None, None, hidden=ha, vhidden=None)
+                with torch.cuda.stream(self._side):
+                    val.copy_(self.value(critic_in))
+                return act, logp, val, mu, sigma
             if not (observations.is_cuda and self.two_streams):
                 mean, hidden = self._actor_pass(observations.to(dtype))
                 return self._sample(mean, self.critic(critic_in), hidden)
