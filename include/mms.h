@@ -252,7 +252,7 @@ int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const float* x0
 
 /* y_g = act(x_g @ w_g^T + b_g), g < groups: mms_linear2_act for any number of networks (same kernel, same shapes rules).
  * The three ln_* arguments (all NULL: none) fold the LayerNorms on either side of the layer into it, so that the normalised
- * activations are never written (they need act = ELU, M and N multiples of 128, and K a multiple of 32 for ln_stat_in):
+ * activations are never written (they need act = ELU and M and N multiples of 128):
  *   ln_part_out[g] [N/64, M, 2]: the epilogue also leaves per output row and per 64-column slot the sum and the sum of squares of
  *     the activations; mms_row_stats_group turns them into (mean, rstd) per row.  No atomics: the result does not depend on scheduling.
  *   ln_stat_in[g] [M, 2] + ln_s[g] [N]: x_g is the PRE-LayerNorm activation h and the layer W (LN(h) gamma + beta) + b is evaluated
@@ -266,10 +266,16 @@ int mms_linear_group_act(int device, int32_t groups, int64_t M, int32_t N, int32
 int mms_row_stats_group(int device, int32_t groups, int64_t M, int32_t slots, int32_t width, const float* const* part, float* const* stat,
                         float eps, void* hip_stream);
 
+/* stat_g[r] = (mean, 1 / sqrt(var + eps)) of row r of x_g [M, K] (row pitch x_pitch floats, 0 = K; K <= 4096): the statistics of a
+ * LayerNorm whose normalised output is never needed because the layer behind it takes them through ln_stat_in -- the feature
+ * LayerNorm of the centralised observation, which every critic of an env shares. */
+int mms_row_moments_group(int device, int32_t groups, int64_t M, int32_t K, int32_t x_pitch, const float* const* x, float* const* stat,
+                          float eps, void* hip_stream);
+
 /* nn.LayerNorm over the last dimension (biased variance, eps inside the root): y_g[r, 0:K] = LN(x_g[r, 0:K]) * gamma_g + beta_g,
  * y_g[r, K:Kp] = 0.  x rows have pitch x_pitch floats (0 = K; A * K reads one agent's rows of an [N, A, K] block where they lie),
  * y rows pitch Kp >= K (Kp > K pads a 46-wide observation to the multiple of 4 the layer kernel wants); y_g == x_g with
- * Kp == x_pitch == K is the in-place form.  K <= 1024. */
+ * Kp == x_pitch == K is the in-place form.  K <= 4096 (the 100-ant swarm's centralised observation is 3808 wide). */
 int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, int32_t x_pitch, const float* const* x,
                         const float* const* gamma, const float* const* beta, float* const* y, float eps, void* hip_stream);
 

@@ -19,7 +19,7 @@ step for TenAnt.  The networks are independent and of the same shape, so here ev
 
 `GroupedPolicyInference` takes the agents' Actor / Critic modules AS THEY ARE (the reference's classes, or anything with the same
 attributes: `.base.feature_norm`, `.base.mlp.fc1`, `.base.mlp.fc2`, `.act.action_out.{fc_mean, log_std, std_x_coef, std_y_coef}`,
-`.v_out`) and reads their parameters in place: an optimizer step needs no copy back, only `refresh()` for the zero-padded copy of
+`.v_out`; any number of agents: more than sixteen run as chunks of sixteen) and reads their parameters in place: an optimizer step needs no copy back, only `refresh()` for the zero-padded copy of
 the actors' first weight matrix (46 -> 48 columns).  Recurrent policies (use_recurrent_policy / use_naive_recurrent_policy) and
 non-Box action spaces are not covered: the constructor raises, nothing falls back silently.
 
@@ -76,8 +76,15 @@ class GroupedPolicyInference:
     def __init__(self, actors, critics, seed=0, row_offset=0, fold_layernorm=True):
         if len(actors) != len(critics) or not actors:
             raise ValueError("one actor and one critic per agent")
-        if 2 * len(actors) > 32:
-            raise ValueError("at most 16 agents per GroupedPolicyInference (MMS_MAX_GROUPS = 32 networks per launch)")
+        self._chunks = None
+        if len(actors) > 16:
+            # MMS_MAX_GROUPS = 32 networks per launch = 16 agents: more agents (the 100-ant swarm) run as chunks of sixteen, each its
+            # own set of grouped launches.  The noise key of agent k stays seed + k however the agents are chunked.
+            self.n = len(actors)
+            self._ranges = [(lo, min(lo + 16, self.n)) for lo in range(0, self.n, 16)]
+            self._chunks = [GroupedPolicyInference(actors[lo:hi], critics[lo:hi], seed=int(seed) + lo, row_offset=row_offset,
+                                                   fold_layernorm=fold_layernorm) for lo, hi in self._ranges]
+            return
         for m in list(actors) + list(critics):
             if getattr(m, "_use_recurrent_policy", False) or getattr(m, "_use_naive_recurrent_policy", False):
                 raise NotImplementedError("GroupedPolicyInference: recurrent policies are not covered (actor_critic.py:64-65)")
@@ -117,6 +124,10 @@ class GroupedPolicyInference:
     def refresh(self):
         """Call after the parameters changed (an optimizer step): rebuilds the zero-padded first actor weights and the std vectors;
         everything else is read from the modules' own storage."""
+        if self._chunks is not None:
+            for c in self._chunks:
+                c.refresh()
+            return
         dev, n = self.device, self.n
         d = lambda t: t.detach()
         self.kp_a = (self.obs_dim + 3) & ~3
@@ -143,6 +154,16 @@ class GroupedPolicyInference:
             bias = torch.stack([d(b[l][0].bias) for b in both])
             Wt = (W * gam[:, None, :]).contiguous()
             self._fold[l] = (Wt, Wt.sum(-1).contiguous(), (torch.einsum("gnk,gk->gn", W, bet) + bias).contiguous())
+        # the critics' first layer behind the feature LayerNorm of the centralised observation, folded the same way: the raw
+        # share_obs rows are read where they lie (every critic of an env reads the SAME rows: one statistics pass, no normalised copies)
+        self._fold_c1 = None
+        if self.sobs_dim % 4 == 0:
+            W = torch.stack([d(b[0][0].weight) for b in self.c_blocks])
+            gam = torch.stack([d(c.base.feature_norm.weight) for c in self.critics])
+            bet = torch.stack([d(c.base.feature_norm.bias) for c in self.critics])
+            bias = torch.stack([d(b[0][0].bias) for b in self.c_blocks])
+            Wt = (W * gam[:, None, :]).contiguous()
+            self._fold_c1 = (Wt, Wt.sum(-1).contiguous(), (torch.einsum("gnk,gk->gn", W, bet) + bias).contiguous())
         self._bind()
 
     def _bind(self):
@@ -171,6 +192,9 @@ class GroupedPolicyInference:
                 self.p["b%d" % l] = arr([d(b[l][0].bias) for b in both])
         for l, (Wt, sv, cv) in self._fold.items():
             self.p["fw%d" % l], self.p["fs%d" % l], self.p["fc%d" % l] = arr(list(Wt.unbind(0))), arr(list(sv.unbind(0))), arr(list(cv.unbind(0)))
+        if self._fold_c1 is not None:
+            Wt, sv, cv = self._fold_c1
+            self.p["fw1_c"], self.p["fs1_c"], self.p["fc1_c"] = arr(list(Wt.unbind(0))), arr(list(sv.unbind(0))), arr(list(cv.unbind(0)))
         heads = [a.act.action_out.fc_mean for a in self.actors]
         vouts = [c.v_out for c in self.critics]
         self.p["hw"] = arr([d(m.weight) for m in heads] + [d(m.weight) for m in vouts])
@@ -189,6 +213,7 @@ class GroupedPolicyInference:
         self.actions, self.logp, self.values = z(n, M, self.act_dim), z(n, M, self.act_dim), z(n, M, 1)
         self.counters = torch.zeros(n, M, dtype=torch.int64, device=dev)
         self.part, self.stat = z(2 * n, max(1, H // 64), M, 2), z(2 * n, M, 2)        # row statistics of the folded LayerNorms
+        self.stat_c = z(n, M, 2)                                                       # ... of the critics' feature LayerNorm
         ub = lambda t: list(t.unbind(0))
         self.q = {
             "x_a": _ptrs(ub(self.x_a)), "x_c": _ptrs(ub(self.x_c)),
@@ -196,6 +221,7 @@ class GroupedPolicyInference:
             "h0_a": _ptrs(ub(self.h[0][:n])), "h0_c": _ptrs(ub(self.h[0][n:])),
             "out": _ptrs(ub(self.actions) + ub(self.values)), "logp": _ptrs(ub(self.logp) + [None] * n),
             "cnt": _ptrs(ub(self.counters) + [None] * n),
+            "stat_c": _ptrs(ub(self.stat_c)), "stat_c0": _ptrs([self.stat_c[0]] * n),
             "part": _ptrs(ub(self.part)), "part_a": _ptrs(ub(self.part[:n])), "part_c": _ptrs(ub(self.part[n:])), "stat": _ptrs(ub(self.stat)),
         }
         self._M = M
@@ -212,6 +238,15 @@ class GroupedPolicyInference:
         n = self.n
         if len(share_obs) != n or len(obs) != n:
             raise ValueError("one observation tensor per agent")
+        if self._chunks is not None:
+            res = ([], [], [])
+            for c, (lo, hi) in zip(self._chunks, self._ranges):
+                o = None if out is None else tuple(None if x is None else x[lo:hi] for x in out)
+                got = c.get_actions(share_obs[lo:hi], obs[lo:hi], deterministic=deterministic, out=o)
+                for dst, part in zip(res, got):
+                    if part is not None:
+                        dst.extend(part)
+            return res[0], res[1], (None if deterministic else res[2])
         M = obs[0].shape[0]
         self._buffers(M)
         L, idx, stream = _lib.for_device(self.device)
@@ -221,12 +256,20 @@ class GroupedPolicyInference:
         obs_p, obs_pitch = _row_ptrs([f32(t) for t in obs])
         sobs_p, sobs_pitch = _row_ptrs([f32(t) for t in share_obs])
         chk(L.mms_layernorm_group(idx, n, M, self.obs_dim, self.kp_a, obs_pitch, obs_p, p["fn_a_g"], p["fn_a_b"], q["x_a"], self.eps, stream), "mms_layernorm_group")
-        chk(L.mms_layernorm_group(idx, n, M, self.sobs_dim, self.kp_c, sobs_pitch, sobs_p, p["fn_c_g"], p["fn_c_b"], q["x_c"], self.eps, stream), "mms_layernorm_group")
         H = self.hidden
         fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0
+        fold_c1 = fold and self._fold_c1 is not None and sobs_pitch == self.sobs_dim
+        if not fold_c1:
+            chk(L.mms_layernorm_group(idx, n, M, self.sobs_dim, self.kp_c, sobs_pitch, sobs_p, p["fn_c_g"], p["fn_c_b"], q["x_c"], self.eps, stream), "mms_layernorm_group")
         slots = H // 64
         chk(L.mms_linear_group_act(idx, n, M, H, self.kp_a, q["x_a"], p["w1_a"], p["b1_a"], q["h0_a"], 1, None, None, q["part_a"] if fold else None, stream), "mms_linear_group_act")
-        chk(L.mms_linear_group_act(idx, n, M, H, self.kp_c, q["x_c"], p["w1_c"], p["b1_c"], q["h0_c"], 1, None, None, q["part_c"] if fold else None, stream), "mms_linear_group_act")
+        if fold_c1:
+            shared_rows = len({int(v) for v in sobs_p}) == 1                 # one centralised observation for all critics: one pass
+            chk(L.mms_row_moments_group(idx, 1 if shared_rows else n, M, self.sobs_dim, sobs_pitch, sobs_p, q["stat_c"], self.eps, stream), "mms_row_moments_group")
+            chk(L.mms_linear_group_act(idx, n, M, H, self.sobs_dim, sobs_p, p["fw1_c"], p["fc1_c"], q["h0_c"], 1, p["fs1_c"],
+                                       q["stat_c0"] if shared_rows else q["stat_c"], q["part_c"], stream), "mms_linear_group_act")
+        else:
+            chk(L.mms_linear_group_act(idx, n, M, H, self.kp_c, q["x_c"], p["w1_c"], p["b1_c"], q["h0_c"], 1, None, None, q["part_c"] if fold else None, stream), "mms_linear_group_act")
         cur = 0
         for l in range(self.depth):
             if l > 0 and fold:                                      # LayerNorm l - 1 folded in; leaves the statistics of LayerNorm l
@@ -245,7 +288,9 @@ class GroupedPolicyInference:
             values, actions, logp = list(self.values.unbind(0)), list(self.actions.unbind(0)), list(self.logp.unbind(0))
             out_p, logp_p, pitch = q["out"], q["logp"], None
         else:
-            values, actions, logp = (list(x) for x in out)
+            values = list(out[0])
+            actions = list(self.actions.unbind(0)) if out[1] is None else list(out[1])      # (None: scratch -- values_into)
+            logp = list(self.logp.unbind(0)) if out[2] is None else list(out[2])
             ap, a_pitch = _row_ptrs(actions)
             lp, l_pitch = _row_ptrs(logp)
             vp, v_pitch = _row_ptrs(values)
@@ -276,7 +321,7 @@ class GroupedPolicyInference:
         values, actions, logp = self.get_actions([b.share_obs[step] for b in buffers], [b.obs[step] for b in buffers])
         rnn_states = torch.transpose(torch.stack([b.rnn_states[step] for b in buffers]), 1, 0)
         rnn_states_critic = torch.transpose(torch.stack([b.rnn_states_critic[step] for b in buffers]), 1, 0)
-        return self.values.transpose(0, 1), actions, logp, rnn_states, rnn_states_critic
+        return torch.stack(values, 1), actions, logp, rnn_states, rnn_states_critic
 
     @torch.no_grad()
     def collect_into(self, shared, deterministic=False):
@@ -296,7 +341,6 @@ class GroupedPolicyInference:
         """Critic values of observation slot `slot` (default: the last one -- the bootstrap values of Runner.compute,
         runner.py:229-241, taken from share_obs[-1]) into dst [N, agents]; the actor outputs of the pass go to scratch."""
         s, n = slot, self.n
-        self._buffers(shared.obs[s].shape[0])
-        out = ([dst[:, k:k + 1] for k in range(n)], list(self.actions.unbind(0)), list(self.logp.unbind(0)))
-        self.get_actions([shared.share_obs[s]] * n, [shared.obs[s][:, k] for k in range(n)], deterministic=True, out=out)
+        self.get_actions([shared.share_obs[s]] * n, [shared.obs[s][:, k] for k in range(n)], deterministic=True,
+                         out=([dst[:, k:k + 1] for k in range(n)], None, None))
         return dst

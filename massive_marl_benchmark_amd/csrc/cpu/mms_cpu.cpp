@@ -403,8 +403,8 @@ MMS_API int mms_linear_group_act(int device, int32_t groups, int64_t M, int32_t 
         return 1;
     }
     if ((ln_stat_in != nullptr) != (ln_s != nullptr)) { g_error = "mms_linear_group_act: ln_stat_in and ln_s come together"; return 1; }
-    if ((ln_stat_in || ln_part_out) && (act != 1 || M % 128 != 0 || N % 128 != 0 || K < 8 || (ln_stat_in && K % 32 != 0))) {
-        g_error = "mms_linear_group_act: the LayerNorm folds need act = ELU, M and N multiples of 128 (K a multiple of 32 for ln_stat_in)";
+    if ((ln_stat_in || ln_part_out) && (act != 1 || M % 128 != 0 || N % 128 != 0 || K < 8)) {
+        g_error = "mms_linear_group_act: the LayerNorm folds need act = ELU, M and N multiples of 128";
         return 1;
     }
     for (int g = 0; g < groups; g++) {
@@ -457,13 +457,26 @@ static void ln_row(const float* x, int K, float eps, float& mean, float& rstd) {
     for (int k = 0; k < K; k++) q += (x[k] - mean) * (x[k] - mean);
     rstd = 1.0f / sqrtf(q / (float)K + eps);
 }
+MMS_API int mms_row_moments_group(int device, int32_t groups, int64_t M, int32_t K, int32_t x_pitch, const float* const* x, float* const* stat,
+                                  float eps, void*) {
+    if (cpu_only(device)) return 1;
+    if (bad_groups(groups, "mms_row_moments_group")) return 1;
+    if (x_pitch == 0) x_pitch = K;
+    if (!x || !stat || M < 0 || K <= 0 || K > 4096 || x_pitch < K) { g_error = "mms_row_moments_group: bad arguments (1 <= K <= 4096)"; return 1; }
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !stat[g]) { g_error = "mms_row_moments_group: null pointer in a group"; return 1; }
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < M; m++) ln_row(x[g] + m * x_pitch, K, eps, stat[g][2 * m], stat[g][2 * m + 1]);
+    }
+    return 0;
+}
 MMS_API int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, int32_t x_pitch, const float* const* x,
                                 const float* const* gamma, const float* const* beta, float* const* y, float eps, void*) {
     if (cpu_only(device)) return 1;
     if (bad_groups(groups, "mms_layernorm_group")) return 1;
     if (x_pitch == 0) x_pitch = K;
-    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 1024 || Kp < K || x_pitch < K) {
-        g_error = "mms_layernorm_group: bad arguments (1 <= K <= 1024, Kp >= K, x_pitch >= K or 0)";
+    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 4096 || Kp < K || x_pitch < K) {
+        g_error = "mms_layernorm_group: bad arguments (1 <= K <= 4096, Kp >= K, x_pitch >= K or 0)";
         return 1;
     }
     for (int g = 0; g < groups; g++) {

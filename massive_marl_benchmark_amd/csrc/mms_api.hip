@@ -445,8 +445,8 @@ __attribute__((visibility("default"))) int mms_linear_group_act(int device, int3
         return 1;
     }
     if ((ln_stat_in != nullptr) != (ln_s != nullptr)) { g_create_error = "mms_linear_group_act: ln_stat_in and ln_s come together"; return 1; }
-    if ((ln_stat_in || ln_part_out) && (act != 1 || M % 128 != 0 || N % 128 != 0 || K < 8 || (ln_stat_in && K % 32 != 0))) {
-        g_create_error = "mms_linear_group_act: the LayerNorm folds need act = ELU, M and N multiples of 128 (K a multiple of 32 for ln_stat_in)";
+    if ((ln_stat_in || ln_part_out) && (act != 1 || M % 128 != 0 || N % 128 != 0 || K < 8)) {
+        g_create_error = "mms_linear_group_act: the LayerNorm folds need act = ELU, M and N multiples of 128";
         return 1;
     }
     mms::LinearArgs a = {};
@@ -479,14 +479,30 @@ __attribute__((visibility("default"))) int mms_row_stats_group(int device, int32
     return 0;
 }
 
+__attribute__((visibility("default"))) int mms_row_moments_group(int device, int32_t groups, int64_t M, int32_t K, int32_t x_pitch, const float* const* x,
+                                                                 float* const* stat, float eps, void* s) {
+    MMS_DEV(device)
+    if (bad_group_count(groups, "mms_row_moments_group")) return 1;
+    if (x_pitch == 0) x_pitch = K;
+    if (!x || !stat || M < 0 || K <= 0 || K > 4096 || x_pitch < K) { g_create_error = "mms_row_moments_group: bad arguments (1 <= K <= 4096)"; return 1; }
+    mms::LayerNormArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !stat[g]) { g_create_error = "mms_row_moments_group: null pointer in a group"; return 1; }
+        a.x[g] = x[g]; a.y[g] = stat[g];
+    }
+    a.M = M; a.K = K; a.Kp = K; a.x_pitch = x_pitch; a.eps = eps; a.stats_only = 1;
+    MMS_FREE(mms::launch_layernorm(a, groups, (hipStream_t)s));
+    return 0;
+}
+
 __attribute__((visibility("default"))) int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, int32_t x_pitch,
                                                                const float* const* x, const float* const* gamma, const float* const* beta, float* const* y,
                                                                float eps, void* s) {
     MMS_DEV(device)
     if (bad_group_count(groups, "mms_layernorm_group")) return 1;
     if (x_pitch == 0) x_pitch = K;
-    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 1024 || Kp < K || x_pitch < K) {
-        g_create_error = "mms_layernorm_group: bad arguments (1 <= K <= 1024, Kp >= K, x_pitch >= K or 0)";
+    if (!x || !gamma || !beta || !y || M < 0 || K <= 0 || K > 4096 || Kp < K || x_pitch < K) {
+        g_create_error = "mms_layernorm_group: bad arguments (1 <= K <= 4096, Kp >= K, x_pitch >= K or 0)";
         return 1;
     }
     mms::LayerNormArgs a = {};

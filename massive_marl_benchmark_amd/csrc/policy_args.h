@@ -47,6 +47,7 @@ struct LayerNormArgs {
     int K, Kp;
     int x_pitch;    // floats between consecutive input rows (>= K): K for a dense matrix, A * K for one agent's rows of an [N, A, K] block
     float eps;
+    int stats_only; // 1: y_g[r * 2 + {0, 1}] = (mean, 1 / sqrt(var + eps)) of row r instead of the normalised row (gamma / beta unused)
 };
 
 // The output layer of each network on LayerNorm(h_g): out_g[r, j] = b_g[j] + sum_k w_g[j, k] LN(h_g[r])[k], j < A_g <= 16.

@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256, 2) linear_act_fast_kernel(LinearArgs a) {
 
 // More than 64 KB of dynamic LDS needs an opt-in per kernel and per device; remembered so that it is asked for once.
 static hipError_t allow_large_lds(const void* kernel, int slot) {
-    static bool done[16][64] = {};
+    static bool done[18][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -427,8 +427,10 @@ hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s) {
     }
     const bool tail = a.K % kBK != 0, elu = a.act == 1;
     if (ln_out || ln_in) {                  // the LayerNorm folds: the callers (mms_linear_group_act) only ask for them where they exist
-        if (!(fast && !small && elu) || (ln_in && tail)) return hipErrorInvalidValue;
-        if (ln_in && ln_out) MMS_LAUNCH_FAST_LN(false, 3, 12)
+        if (!(fast && !small && elu)) return hipErrorInvalidValue;
+        if (ln_in && ln_out && tail) MMS_LAUNCH_FAST_LN(true, 3, 16)
+        else if (ln_in && tail) MMS_LAUNCH_FAST_LN(true, 2, 17)
+        else if (ln_in && ln_out) MMS_LAUNCH_FAST_LN(false, 3, 12)
         else if (ln_in) MMS_LAUNCH_FAST_LN(false, 2, 13)
         else if (tail) MMS_LAUNCH_FAST_LN(true, 1, 14)
         else MMS_LAUNCH_FAST_LN(false, 1, 15)
@@ -468,18 +470,21 @@ __device__ __forceinline__ float wave_all_sum(float x) {
 constexpr int kLnPerLane = 16;            // row widths up to 1024: element k of a row sits in lane k % 64, slot k / 64
 
 // mean and 1 / sqrt(var + eps) of one row held lane-strided in v[0 : n) (two passes in registers: torch's LayerNorm statistics)
-__device__ __forceinline__ void row_stats(const float (&v)[kLnPerLane], int K, int lane, float eps, float& mean, float& rstd) {
+template <int PL = kLnPerLane>
+__device__ __forceinline__ void row_stats(const float (&v)[PL], int K, int lane, float eps, float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnPerLane; i++) if (lane + 64 * i < K) s += v[i];
+    for (int i = 0; i < PL; i++) if (lane + 64 * i < K) s += v[i];
     mean = wave_all_sum(s) / (float)K;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnPerLane; i++) if (lane + 64 * i < K) { const float d = v[i] - mean; q += d * d; }
+    for (int i = 0; i < PL; i++) if (lane + 64 * i < K) { const float d = v[i] - mean; q += d * d; }
     rstd = 1.0f / sqrtf(wave_all_sum(q) / (float)K + eps);
 }
 
-// one wave per row, four rows per block, blockIdx.y = network
+// one wave per row, four rows per block, blockIdx.y = network.  PL = register slots per lane: 16 for rows up to 1024 wide, 64 for
+// rows up to 4096 (the 3808-wide centralised observation of the 100-ant swarm)
+template <int PL>
 __global__ void __launch_bounds__(256) layernorm_rows_kernel(LayerNormArgs a) {
     const int g = blockIdx.y, lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -489,13 +494,17 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(LayerNormArgs a) {
     const float* __restrict__ gamma = a.gamma[g];
     const float* __restrict__ beta = a.beta[g];
     float* y = a.y[g] + row * Kp;
-    float v[kLnPerLane];
+    float v[PL];
 #pragma unroll
-    for (int i = 0; i < kLnPerLane; i++) v[i] = (lane + 64 * i < K) ? x[lane + 64 * i] : 0.f;
+    for (int i = 0; i < PL; i++) v[i] = (lane + 64 * i < K) ? x[lane + 64 * i] : 0.f;
     float mean, rstd;
-    row_stats(v, K, lane, a.eps, mean, rstd);
+    row_stats<PL>(v, K, lane, a.eps, mean, rstd);
+    if (a.stats_only) {
+        if (lane == 0) reinterpret_cast<float2*>(a.y[g])[row] = make_float2(mean, rstd);
+        return;
+    }
 #pragma unroll
-    for (int i = 0; i < kLnPerLane; i++) {
+    for (int i = 0; i < PL; i++) {
         const int k = lane + 64 * i;
         if (k < K) y[k] = (v[i] - mean) * rstd * gamma[k] + beta[k];
         else if (k < Kp) y[k] = 0.f;
@@ -586,7 +595,8 @@ hipError_t launch_row_stats(const RowStatsArgs& a, int groups, hipStream_t s) {
 
 hipError_t launch_layernorm(const LayerNormArgs& a, int groups, hipStream_t s) {
     if (a.M == 0 || groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((a.M + 3) / 4), groups), dim3(256), 0, s, a);
+    if (a.K <= 64 * kLnPerLane) hipLaunchKernelGGL(layernorm_rows_kernel<kLnPerLane>, dim3((unsigned)((a.M + 3) / 4), groups), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(layernorm_rows_kernel<64>, dim3((unsigned)((a.M + 3) / 4), groups), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=16, help="timed rollouts of T = 8 steps")
+    ap.add_argument("--agents", type=int, default=10, help="ants per env: 100 with --num-envs 2048 is BASELINE configs[4]'s per-GPU shard")
+    ap.add_argument("--skip-reference-way", action="store_true")
     args = ap.parse_args()
     import torch
     import marl_modules as mm
@@ -34,7 +36,8 @@ def main():
     from massive_marl_benchmark_amd.tasks.agent_base.multi_vec_task import MultiVecTaskPython
     from massive_marl_benchmark_amd.tasks.ten_ant import TenAnt
 
-    n, T, A = args.num_envs, 8, 10
+    n, T, A = args.num_envs, 8, args.agents
+    OBS, SHARE = 46, 38 * A + 8
     conf = dict(episode_length=T, n_rollout_threads=n, hidden_size=512, recurrent_N=1, gamma=0.99, gae_lambda=0.95, use_gae=True,
                 use_popart=False, use_valuenorm=False, use_proper_time_limits=False)
 
@@ -43,13 +46,13 @@ def main():
         cfg["env"]["numEnvs"] = n
         cfg["clip_observations"] = 7.0
         cfg["seed"] = 3
-        return MultiVecTaskPython(TenAnt(cfg, None, "physx", "cuda", 0, True, is_multi_agent=True), "cuda:0")
+        return MultiVecTaskPython(TenAnt(cfg, None, "physx", "cuda", 0, True, is_multi_agent=True, num_ants=A), "cuda:0")
 
     gen = torch.Generator().manual_seed(5)
     actors, critics = [], []
     for i in range(A):
         torch.manual_seed(i)
-        a, c = mm.Actor(46, 8), mm.Critic(388)
+        a, c = mm.Actor(OBS, 8), mm.Critic(SHARE)
         mm.randomize(a, gen, 0.05)
         mm.randomize(c, gen, 0.05)
         actors.append(a.cuda())
@@ -68,38 +71,39 @@ def main():
         ms = e0.elapsed_time(e1) / (iters * T)
         return {"ms_per_env_step": ms, "env_steps_per_s": n / (ms * 1e-3), "agent_steps_per_s": n * A / (ms * 1e-3)}
 
-    out = {"task": "TenAnt", "algo": "mappo", "num_envs": n, "agents": A, "T": T, "hidden": 512, "layer_N": 2}
+    out = {"task": "TenAnt", "algo": "mappo", "num_envs": n, "agents": A, "T": T, "hidden": 512, "layer_N": 2, "obs": OBS, "share_obs": SHARE}
 
     # ---- the reference's way, on this engine ------------------------------------------------------------------------------------
-    env = make_env()
-    bufs = [SeparatedReplayBuffer(conf, env.observation_space[k], env.share_observation_space[k], env.action_space[k], "cuda:0") for k in range(A)]
-    obs, share, _ = env.reset()
-    for k in range(A):
-        bufs[k].share_obs[0].copy_(share[:, k]); bufs[k].obs[0].copy_(obs[:, k])
-    rnn = torch.zeros(n, 1, 512, device="cuda")
+    if not args.skip_reference_way:
+      env = make_env()
+      bufs = [SeparatedReplayBuffer(conf, env.observation_space[k], env.share_observation_space[k], env.action_space[k], "cuda:0") for k in range(A)]
+      obs, share, _ = env.reset()
+      for k in range(A):
+          bufs[k].share_obs[0].copy_(share[:, k]); bufs[k].obs[0].copy_(obs[:, k])
+      rnn = torch.zeros(n, 1, 512, device="cuda")
 
-    def reference_way():
-        with torch.no_grad():
-            for t in range(T):
-                vals, acts, lps = [], [], []
-                for k in range(A):                                                    # runner.py:198-227
-                    mean, std, value = mm.torch_forward(actors[k], critics[k], bufs[k].obs[t], bufs[k].share_obs[t])
-                    dist = torch.distributions.Normal(mean, std)
-                    act = dist.sample()
-                    vals.append(value); acts.append(act); lps.append(dist.log_prob(act))
-                obs, share, rew, dones, _, _ = env.step(acts)
-                dones_env = torch.all(dones != 0, dim=1)
-                masks = torch.ones(n, A, 1, device="cuda")
-                masks[dones_env] = 0
-                for k in range(A):
-                    bufs[k].insert(share[:, k], obs[:, k], rnn, rnn, acts[k], lps[k], vals[k], rew[:, k], masks[:, k])
-            for k in range(A):                                                        # runner.py:229-241 (compute)
-                _, _, nxt = mm.torch_forward(actors[k], critics[k], bufs[k].obs[-1], bufs[k].share_obs[-1])
-                bufs[k].compute_returns(nxt, None)
-                bufs[k].after_update()
-    out["reference_way_eager"] = timed(reference_way, max(2, args.iters // 4))
-    env.task.engine.close()
-    del bufs
+      def reference_way():
+          with torch.no_grad():
+              for t in range(T):
+                  vals, acts, lps = [], [], []
+                  for k in range(A):                                                    # runner.py:198-227
+                      mean, std, value = mm.torch_forward(actors[k], critics[k], bufs[k].obs[t], bufs[k].share_obs[t])
+                      dist = torch.distributions.Normal(mean, std)
+                      act = dist.sample()
+                      vals.append(value); acts.append(act); lps.append(dist.log_prob(act))
+                  obs, share, rew, dones, _, _ = env.step(acts)
+                  dones_env = torch.all(dones != 0, dim=1)
+                  masks = torch.ones(n, A, 1, device="cuda")
+                  masks[dones_env] = 0
+                  for k in range(A):
+                      bufs[k].insert(share[:, k], obs[:, k], rnn, rnn, acts[k], lps[k], vals[k], rew[:, k], masks[:, k])
+              for k in range(A):                                                        # runner.py:229-241 (compute)
+                  _, _, nxt = mm.torch_forward(actors[k], critics[k], bufs[k].obs[-1], bufs[k].share_obs[-1])
+                  bufs[k].compute_returns(nxt, None)
+                  bufs[k].after_update()
+      out["reference_way_eager"] = timed(reference_way, max(2, args.iters // 4))
+      env.task.engine.close()
+      del bufs
 
     # ---- fused --------------------------------------------------------------------------------------------------------------------
     env = make_env()
@@ -129,8 +133,9 @@ def main():
     torch.cuda.synchronize()
     out["fused_graph"] = timed(graph.replay, args.iters)
     out["finite"] = bool(torch.isfinite(sh.returns).all()) and bool(torch.isfinite(sh.share_obs).all())
-    out["speedup_eager"] = out["reference_way_eager"]["ms_per_env_step"] / out["fused_eager"]["ms_per_env_step"]
-    out["speedup_graph_vs_reference_eager"] = out["reference_way_eager"]["ms_per_env_step"] / out["fused_graph"]["ms_per_env_step"]
+    if "reference_way_eager" in out:
+        out["speedup_eager"] = out["reference_way_eager"]["ms_per_env_step"] / out["fused_eager"]["ms_per_env_step"]
+        out["speedup_graph_vs_reference_eager"] = out["reference_way_eager"]["ms_per_env_step"] / out["fused_graph"]["ms_per_env_step"]
     env.task.engine.close()
     print(json.dumps(out), flush=True)
 
