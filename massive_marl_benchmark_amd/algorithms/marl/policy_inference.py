@@ -72,6 +72,13 @@ def _row_ptrs(tensors):
     return arr, pitch.pop()
 
 
+def _critic_halves(table, n):
+    """For every pointer array over all 2n networks (actors first, critics behind them) the array of its critic half, as `key/c`."""
+    for key, arr in list(table.items()):
+        if len(arr) == 2 * n and "/c" not in key:
+            table[key + "/c"] = (ctypes.c_void_p * n)(*list(arr)[n:])
+
+
 class GroupedPolicyInference:
     def __init__(self, actors, critics, seed=0, row_offset=0, fold_layernorm=True):
         if len(actors) != len(critics) or not actors:
@@ -202,6 +209,8 @@ class GroupedPolicyInference:
         self.p["std"] = arr(self._std + [None] * self.n)
         self.p["std_none"] = arr([None] * (2 * self.n))
         self._A = (ctypes.c_int32 * (2 * self.n))(*([self.act_dim] * self.n + [1] * self.n))
+        self._A1 = (ctypes.c_int32 * self.n)(*([1] * self.n))
+        _critic_halves(self.p, self.n)
 
     def _buffers(self, M):
         if self._M == M:
@@ -224,6 +233,7 @@ class GroupedPolicyInference:
             "stat_c": _ptrs(ub(self.stat_c)), "stat_c0": _ptrs([self.stat_c[0]] * n),
             "part": _ptrs(ub(self.part)), "part_a": _ptrs(ub(self.part[:n])), "part_c": _ptrs(ub(self.part[n:])), "stat": _ptrs(ub(self.stat)),
         }
+        _critic_halves(self.q, n)
         self._M = M
 
     # -- inference ----------------------------------------------------------------------------------------------------------------
@@ -337,10 +347,61 @@ class GroupedPolicyInference:
         return shared.actions[s]
 
     @torch.no_grad()
+    def get_values(self, share_obs, out=None):
+        """The critics alone (policy.get_values, mappo_policy.py:77-88; Runner.compute, runner.py:229-241): per-agent lists of
+        [M, share_obs_dim] in, [M, 1] values out (views of a buffer the next call overwrites, or the `out` destinations)."""
+        n = self.n
+        if len(share_obs) != n:
+            raise ValueError("one observation tensor per agent")
+        if self._chunks is not None:
+            res = []
+            for c, (lo, hi) in zip(self._chunks, self._ranges):
+                res.extend(c.get_values(share_obs[lo:hi], None if out is None else out[lo:hi]))
+            return res
+        M = share_obs[0].shape[0]
+        self._buffers(M)
+        L, idx, stream = _lib.for_device(self.device)
+        p, q = self.p, self.q
+        chk = lambda rc, what: _lib.check(rc, None, what, L)
+        f32 = lambda t: t.detach() if t.dtype == torch.float32 else t.detach().float()
+        sobs_p, sobs_pitch = _row_ptrs([f32(t) for t in share_obs])
+        H = self.hidden
+        fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0
+        fold_c1 = fold and self._fold_c1 is not None and sobs_pitch == self.sobs_dim
+        slots = H // 64
+        if fold_c1:
+            shared_rows = len({int(v) for v in sobs_p}) == 1
+            chk(L.mms_row_moments_group(idx, 1 if shared_rows else n, M, self.sobs_dim, sobs_pitch, sobs_p, q["stat_c"], self.eps, stream), "mms_row_moments_group")
+            chk(L.mms_linear_group_act(idx, n, M, H, self.sobs_dim, sobs_p, p["fw1_c"], p["fc1_c"], q["h0_c"], 1, p["fs1_c"],
+                                       q["stat_c0"] if shared_rows else q["stat_c"], q["part_c"], stream), "mms_linear_group_act")
+        else:
+            chk(L.mms_layernorm_group(idx, n, M, self.sobs_dim, self.kp_c, sobs_pitch, sobs_p, p["fn_c_g"], p["fn_c_b"], q["x_c"], self.eps, stream), "mms_layernorm_group")
+            chk(L.mms_linear_group_act(idx, n, M, H, self.kp_c, q["x_c"], p["w1_c"], p["b1_c"], q["h0_c"], 1, None, None, q["part_c"] if fold else None, stream), "mms_linear_group_act")
+        cur = 0
+        for l in range(self.depth):
+            if l > 0 and fold:
+                chk(L.mms_row_stats_group(idx, n, M, slots, H, q["part/c"], q["stat/c"], self.eps, stream), "mms_row_stats_group")
+                chk(L.mms_linear_group_act(idx, n, M, H, H, q["h%d/c" % cur], p["fw%d/c" % l], p["fc%d/c" % l], q["h%d/c" % (1 - cur)], 1, p["fs%d/c" % l],
+                                           q["stat/c"], q["part/c"] if l + 1 < self.depth else None, stream), "mms_linear_group_act")
+                cur = 1 - cur
+                continue
+            if l > 0:
+                chk(L.mms_linear_group_act(idx, n, M, H, H, q["h%d/c" % cur], p["w%d/c" % l], p["b%d/c" % l], q["h%d/c" % (1 - cur)], 1, None, None, None, stream), "mms_linear_group_act")
+                cur = 1 - cur
+            if l + 1 < self.depth and not fold:
+                chk(L.mms_layernorm_group(idx, n, M, H, H, H, q["h%d/c" % cur], p["ln%d_g/c" % l], p["ln%d_b/c" % l], q["h%d/c" % cur], self.eps, stream), "mms_layernorm_group")
+        last = self.depth - 1
+        values = list(self.values.unbind(0)) if out is None else list(out)
+        vp, v_pitch = _row_ptrs(values)
+        pitch = (ctypes.c_int32 * n)(*([v_pitch] * n))
+        chk(L.mms_marl_heads_act(idx, n, M, H, q["h%d/c" % cur], p["ln%d_g/c" % last], p["ln%d_b/c" % last], p["hw/c"], p["hb/c"], self._A1,
+                                 None, vp, None, pitch, None, self.seed, self.row_offset, self.eps, stream), "mms_marl_heads_act")
+        return values
+
+    @torch.no_grad()
     def values_into(self, shared, dst, slot=-1):
         """Critic values of observation slot `slot` (default: the last one -- the bootstrap values of Runner.compute,
-        runner.py:229-241, taken from share_obs[-1]) into dst [N, agents]; the actor outputs of the pass go to scratch."""
-        s, n = slot, self.n
-        self.get_actions([shared.share_obs[s]] * n, [shared.obs[s][:, k] for k in range(n)], deterministic=True,
-                         out=([dst[:, k:k + 1] for k in range(n)], None, None))
+        runner.py:229-241, taken from share_obs[-1]) into dst [N, agents]: the critics alone (`get_values`)."""
+        n = self.n
+        self.get_values([shared.share_obs[slot]] * n, out=[dst[:, k:k + 1] for k in range(n)])
         return dst
