@@ -18,6 +18,8 @@
 #else
 #define MMS_HD inline
 #endif
+// (rare paths -- an ant in reach of the box: block frequencies steer the register allocator's spill weights and the block layout)
+#define MMS_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
 namespace mms {
 
@@ -470,7 +472,8 @@ struct LegPass {
     S6 U1, U2;
     float D1, D2, u1, u2;
     float sc[4];          // sin / cos of the two joint angles (the rest of the kinematics is evaluated again)
-    bool near_box;
+    bool near_box;        // broad phase: some sphere of this ant may reach the box
+    bool touch_box;       // ... and one of THIS lane's spheres does: only then the outward pass evaluates the reactions on the box
 };
 // extra state for the foot force sensors (OneAnt only)
 struct SensorPass { Contact tip_g, tip_b; M3 Rf; V3 J2; };
@@ -542,6 +545,7 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         park_store(park, 5, K.c2.a.z, K.c2.l.x, K.c2.l.y, K.c2.l.z);
     }
     P.near_box = has_box && ant_near_box(Ow, box, ant_reach(M, L));
+    P.touch_box = false;
     // ---- foot body: inertia, bias force, tip contacts, joint 2 -------------------------------------------------
     Sym6 IAf;
     V3 cf = K.J2 + (0.5f * M->foot_len) * K.uf;
@@ -552,9 +556,10 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf);
         contact_fold_ground(g, h, IAf, pAf);
         if (SENSORS) { SP->tip_g = g; SP->tip_b = contact_none(); }
-        if (P.near_box) {
+        if (MMS_UNLIKELY(P.near_box)) {
             Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IAf, pAf);
+            P.touch_box = P.touch_box || b.active != 0.f;
             if (SENSORS) SP->tip_b = b;
         }
     }
@@ -584,11 +589,13 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         contact_fold_ground(g, h, IAl, pAl);
         g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl);
         contact_fold_ground(g, h, IAl, pAl);
-        if (P.near_box) {
+        if (MMS_UNLIKELY(P.near_box)) {
             Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IAl, pAl);
+            P.touch_box = P.touch_box || b.active != 0.f;
             b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IAl, pAl);
+            P.touch_box = P.touch_box || b.active != 0.f;
         }
     }
     float t1 = DR ? joint_tau(M, h, S.q[0], S.qd[0], L.lower[0] + dr->lo[0], L.upper[0] + dr->hi[0], tau1, De1, M->joint_damping * dr->damp[0])
@@ -625,9 +632,10 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         V3 zero = V3{0, 0, 0};
         Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, zero, M->torso_radius, v0);
         contact_fold_ground(g, h, IA0, pA0);
-        if (P.near_box) {
+        if (MMS_UNLIKELY(P.near_box)) {
             Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, zero, M->torso_radius, v0, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IA0, pA0);
+            P.touch_box = P.touch_box || b.active != 0.f;
         }
     }
 }
@@ -669,8 +677,10 @@ MMS_HD void leg_outward(const mms_model* M, const LegConst& L, float h, AntLane&
     float qdd2 = (P.u2 - dot(P.U2, af)) / P.D2;
     af = af + qdd2 * s2;
     wrench = S6{V3{0, 0, 0}, V3{0, 0, 0}};
-    if (P.near_box) {
-        M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);          // rare: the full kinematics again for the contact points
+    // Only a lane that HAD an active box contact in the inward pass (same state, same box pose: the same contacts are active here)
+    // evaluates them again; the broad phase alone is true for every ant standing around the box, i.e. for every wave of TenAnt.
+    if (MMS_UNLIKELY(P.touch_box)) {
+        M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);          // the full kinematics again for the contact points
         LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
         S6 v0 = S6{S.ang, S.vel};
         Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
