@@ -526,16 +526,21 @@ MMS_HD float ant_reach(const mms_model* M, const LegConst& L) {
 
 // Phase A (inward pass of one leg chain).  Returns this lane's contribution (Ia, pa) to the torso's
 // articulated inertia; lane l == 0 also adds the torso body itself and the torso sphere contacts.
+// In two parts: `leg_inward_open` is everything that does not depend on the box (kinematics, the foot body's inertia and bias
+// force, the tip's ground contact), `leg_inward_close` the rest.  The step kernel puts the barrier behind which this substep's box
+// pose is valid BETWEEN them, so that the ant waves work through the opening while the box lanes finish the previous substep's
+// serial tail; `leg_inward` is the two back to back (host builds, one-wave layouts).
+struct LegInward { M3 Rt; LegKin K; Sym6 IAf; S6 pAf; };
+
 template <bool SENSORS, bool DR = false>
-MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const AntLane& S, int leg, float tau1, float tau2,
-                       bool has_box, const BoxPose& box, LegPass& P, SensorPass* SP, Sym6& IA0, S6& pA0, const KinPark& park = KinPark{nullptr, 0},
-                       const LegDR* dr = nullptr) {
-    M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
+MMS_HD void leg_inward_open(const mms_model* M, const LegConst& L, float h, const AntLane& S, LegPass& P, SensorPass* SP, LegInward& W,
+                            const KinPark& park = KinPark{nullptr, 0}, const LegDR* dr = nullptr) {
+    W.Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);
     V3 Ow = S.pos;
-    S6 v0 = S6{S.ang, S.vel};
     sincos_joint(S.q[0], P.sc[0], P.sc[1]);
     sincos_joint(S.q[1], P.sc[2], P.sc[3]);
-    LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
+    W.K = leg_kinematics(M, L, S, W.Rt, P.sc);
+    const LegKin& K = W.K;
     if (park.base) {
         park_store(park, 0, K.s1.a.x, K.s1.a.y, K.s1.a.z, K.s1.l.x);
         park_store(park, 1, K.s1.l.y, K.s1.l.z, K.s2.a.x, K.s2.a.y);
@@ -544,24 +549,34 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
         park_store(park, 4, K.c1.l.y, K.c1.l.z, K.c2.a.x, K.c2.a.y);
         park_store(park, 5, K.c2.a.z, K.c2.l.x, K.c2.l.y, K.c2.l.z);
     }
-    P.near_box = has_box && ant_near_box(Ow, box, ant_reach(M, L));
-    P.touch_box = false;
-    // ---- foot body: inertia, bias force, tip contacts, joint 2 -------------------------------------------------
-    Sym6 IAf;
+    // ---- foot body: inertia, bias force, the tip's ground contact ------------------------------------------------
     V3 cf = K.J2 + (0.5f * M->foot_len) * K.uf;
     const float mf = DR ? dr->m_foot : 1.f;
-    spatial_inertia_axisym(M->foot_mass * mf, cf, K.uf, M->foot_ia * mf, M->foot_it * mf, IAf);
-    S6 pAf = bias_force_axisym(K.vf, M->foot_mass * mf, cf, K.uf, M->foot_ia * mf, M->foot_it * mf, M->gravity);
-    {
-        Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf);
-        contact_fold_ground(g, h, IAf, pAf);
-        if (SENSORS) { SP->tip_g = g; SP->tip_b = contact_none(); }
-        if (MMS_UNLIKELY(P.near_box)) {
-            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box, M->antbox_mu, M->slip_eps);
-            contact_fold_box(b, h, IAf, pAf);
-            P.touch_box = P.touch_box || b.active != 0.f;
-            if (SENSORS) SP->tip_b = b;
-        }
+    spatial_inertia_axisym(M->foot_mass * mf, cf, K.uf, M->foot_ia * mf, M->foot_it * mf, W.IAf);
+    W.pAf = bias_force_axisym(K.vf, M->foot_mass * mf, cf, K.uf, M->foot_ia * mf, M->foot_it * mf, M->gravity);
+    Contact g = sphere_ground(M->gnd_k, M->gnd_c, M->gnd_mu, M->slip_eps, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf);
+    contact_fold_ground(g, h, W.IAf, W.pAf);
+    if (SENSORS) { SP->tip_g = g; SP->tip_b = contact_none(); }
+}
+
+template <bool SENSORS, bool DR = false>
+MMS_HD void leg_inward_close(const mms_model* M, const LegConst& L, float h, const AntLane& S, int leg, float tau1, float tau2,
+                             bool has_box, const BoxPose& box, LegPass& P, SensorPass* SP, Sym6& IA0, S6& pA0, LegInward& W,
+                             const LegDR* dr = nullptr) {
+    const M3& Rt = W.Rt;
+    const LegKin& K = W.K;
+    Sym6& IAf = W.IAf;
+    S6& pAf = W.pAf;
+    V3 Ow = S.pos;
+    S6 v0 = S6{S.ang, S.vel};
+    P.near_box = has_box && ant_near_box(Ow, box, ant_reach(M, L));
+    P.touch_box = false;
+    // ---- foot body: the tip's box contact, joint 2 ---------------------------------------------------------------
+    if (MMS_UNLIKELY(P.near_box)) {
+        Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box, M->antbox_mu, M->slip_eps);
+        contact_fold_box(b, h, IAf, pAf);
+        P.touch_box = P.touch_box || b.active != 0.f;
+        if (SENSORS) SP->tip_b = b;
     }
     float De1, De2;
     float t2 = DR ? joint_tau(M, h, S.q[1], S.qd[1], L.lower[1] + dr->lo[1], L.upper[1] + dr->hi[1], tau2, De2, M->joint_damping * dr->damp[1])
@@ -638,6 +653,15 @@ MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const Ant
             P.touch_box = P.touch_box || b.active != 0.f;
         }
     }
+}
+
+template <bool SENSORS, bool DR = false>
+MMS_HD void leg_inward(const mms_model* M, const LegConst& L, float h, const AntLane& S, int leg, float tau1, float tau2,
+                       bool has_box, const BoxPose& box, LegPass& P, SensorPass* SP, Sym6& IA0, S6& pA0, const KinPark& park = KinPark{nullptr, 0},
+                       const LegDR* dr = nullptr) {
+    LegInward W;
+    leg_inward_open<SENSORS, DR>(M, L, h, S, P, SP, W, park, dr);
+    leg_inward_close<SENSORS, DR>(M, L, h, S, leg, tau1, tau2, has_box, box, P, SP, IA0, pA0, W, dr);
 }
 
 // Phase B (after the quad reduction): root solve, outward pass, contact forces, integration.

@@ -264,16 +264,22 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
         constexpr bool kSensors = (TASK == MMS_TASK_ONE_ANT);
         constexpr bool kOneWave = (BLOCK == 64 && EPB == 1);
         // inward pass, quad reduction, root solve, outward pass; returns this lane's reaction on the box
-        auto ant_phase = [&]() -> S6 {
+        auto ant_phase = [&](bool wait_for_box) -> S6 {
             S6 wr = S6{V3{0, 0, 0}, V3{0, 0, 0}};
             Sym6 IA0;
             S6 pA0;
             LegPass P;
             SensorPass SP;
+            LegInward W;
+            // the opening of the inward pass (kinematics, foot body, the tip's ground contact) does not need the box: the ant waves
+            // work through it while the box lanes finish the previous substep's serial tail; the barrier behind which this
+            // substep's box pose is valid sits HERE, not at the end of the previous substep
+            if (is_ant && simulate) leg_inward_open<kSensors, DR>(M, L, h, S, P, &SP, W, park, s_dr);
+            if (wait_for_box) __syncthreads();
             if (is_ant && simulate) {
                 const float tau1 = s_act[0] * L.gear[0] * C->power_scale;    // ten_ant.py:889
                 const float tau2 = s_act[1] * L.gear[1] * C->power_scale;
-                leg_inward<kSensors, DR>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0, park, s_dr);
+                leg_inward_close<kSensors, DR>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0, W, s_dr);
             }
             // (quads never mix ant and box lanes, and `simulate` is per env: a quad that skipped the inward pass skips the outward
             // pass too, so what the reduction leaves in its lanes is never read -- no zero fill)
@@ -311,7 +317,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
         // (the loop itself is block-uniform so that every lane reaches every barrier)
         const bool box_friction = M->boxgnd_mu > 0.f;                // uniform: box-ground friction couples all six accelerations
         for (int s = 0; s < C->substeps; s++) {
-            S6 wr = ant_phase();
+            S6 wr = ant_phase(s > 0);
             // The box's own ground contacts (with or without friction) do not depend on this substep's ant reactions: the corner
             // lanes evaluate and reduce them BEFORE the barrier -- in the layouts whose box lanes fill waves of their own that is time in which those waves would
             // only wait for the ant lanes; after the barrier the box needs the wrench, one small solve and the integration.
@@ -357,7 +363,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
                 } else if (simulate) box_finish(M, h, B, R, bc, w);
                 if (corner == 0) box_store(B);
             }
-            __syncthreads();
+            // (no barrier here: the next substep's ant phase waits for the box pose after its box-independent opening, and behind
+            // the last substep only the box lead reads what it wrote itself until the epilogue's own barrier)
         }
     }
 
