@@ -473,8 +473,7 @@ struct LegPass {
     float D1, D2, u1, u2;
     float sc[4];          // sin / cos of the two joint angles (the rest of the kinematics is evaluated again)
     bool near_box;        // broad phase: some sphere of this ant may reach the box
-    int touch_box;        // ... and which of THIS lane's spheres do (bit 0 hip end, 1 knee, 2 tip, 3 torso): the outward pass evaluates
-                          // the reactions on the box of exactly those
+    bool touch_box;       // ... and one of THIS lane's spheres does: only then the outward pass evaluates the reactions on the box
 };
 // extra state for the foot force sensors (OneAnt only)
 struct SensorPass { Contact tip_g, tip_b; M3 Rf; V3 J2; };
@@ -571,12 +570,12 @@ MMS_HD void leg_inward_close(const mms_model* M, const LegConst& L, float h, con
     V3 Ow = S.pos;
     S6 v0 = S6{S.ang, S.vel};
     P.near_box = has_box && ant_near_box(Ow, box, ant_reach(M, L));
-    P.touch_box = 0;
+    P.touch_box = false;
     // ---- foot body: the tip's box contact, joint 2 ---------------------------------------------------------------
     if (MMS_UNLIKELY(P.near_box)) {
         Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box, M->antbox_mu, M->slip_eps);
         contact_fold_box(b, h, IAf, pAf);
-        if (b.active != 0.f) P.touch_box |= 4;
+        P.touch_box = P.touch_box || b.active != 0.f;
         if (SENSORS) SP->tip_b = b;
     }
     float De1, De2;
@@ -608,10 +607,10 @@ MMS_HD void leg_inward_close(const mms_model* M, const LegConst& L, float h, con
         if (MMS_UNLIKELY(P.near_box)) {
             Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IAl, pAl);
-            if (b.active != 0.f) P.touch_box |= 1;
+            P.touch_box = P.touch_box || b.active != 0.f;
             b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IAl, pAl);
-            if (b.active != 0.f) P.touch_box |= 2;
+            P.touch_box = P.touch_box || b.active != 0.f;
         }
     }
     float t1 = DR ? joint_tau(M, h, S.q[0], S.qd[0], L.lower[0] + dr->lo[0], L.upper[0] + dr->hi[0], tau1, De1, M->joint_damping * dr->damp[0])
@@ -651,7 +650,7 @@ MMS_HD void leg_inward_close(const mms_model* M, const LegConst& L, float h, con
         if (MMS_UNLIKELY(P.near_box)) {
             Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, zero, M->torso_radius, v0, box, M->antbox_mu, M->slip_eps);
             contact_fold_box(b, h, IA0, pA0);
-            if (b.active != 0.f) P.touch_box |= 8;
+            P.touch_box = P.touch_box || b.active != 0.f;
         }
     }
 }
@@ -704,26 +703,18 @@ MMS_HD void leg_outward(const mms_model* M, const LegConst& L, float h, AntLane&
     wrench = S6{V3{0, 0, 0}, V3{0, 0, 0}};
     // Only a lane that HAD an active box contact in the inward pass (same state, same box pose: the same contacts are active here)
     // evaluates them again; the broad phase alone is true for every ant standing around the box, i.e. for every wave of TenAnt.
-    if (MMS_UNLIKELY(P.touch_box != 0)) {
-        if (P.touch_box & 7) {
-            M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);      // the full kinematics again for the contact points
-            LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
-            if (P.touch_box & 1) {
-                Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
-                box_reaction(b, h, Ow, box, al, wrench);
-            }
-            if (P.touch_box & 2) {
-                Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
-                box_reaction(b, h, Ow, box, al, wrench);
-            }
-            if (P.touch_box & 4) {
-                Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box, M->antbox_mu, M->slip_eps);
-                box_reaction(b, h, Ow, box, af, wrench);
-            }
-        }
-        if (P.touch_box & 8) {                                // (set by lane 0 of the quad only)
-            S6 v0 = S6{S.ang, S.vel};
-            Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, V3{0, 0, 0}, M->torso_radius, v0, box, M->antbox_mu, M->slip_eps);
+    if (MMS_UNLIKELY(P.touch_box)) {
+        M3 Rt = quat_to_mat(S.qx, S.qy, S.qz, S.qw);          // the full kinematics again for the contact points
+        LegKin K = leg_kinematics(M, L, S, Rt, P.sc);
+        S6 v0 = S6{S.ang, S.vel};
+        Contact b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J1, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
+        box_reaction(b, h, Ow, box, al, wrench);
+        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.J2, M->limb_radius, K.vl, box, M->antbox_mu, M->slip_eps);
+        box_reaction(b, h, Ow, box, al, wrench);
+        b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, K.tip, M->limb_radius, K.vf, box, M->antbox_mu, M->slip_eps);
+        box_reaction(b, h, Ow, box, af, wrench);
+        if (leg == 0) {
+            b = sphere_box(M->antbox_k, M->antbox_c, M->pen_ramp, h, Ow, V3{0, 0, 0}, M->torso_radius, v0, box, M->antbox_mu, M->slip_eps);
             box_reaction(b, h, Ow, box, a0, wrench);
         }
     }
