@@ -303,3 +303,46 @@ def test_two_rank_gloo_statistics_and_sharding(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def test_kernel_resources_of_the_built_library():
+    """Static guard on the built HIP library (no GPU needed): the gfx950 code object is cut out of libmms.so's offload bundle and its
+    kernel metadata read with llvm-readelf.  The TenAnt step layouts must stay at <= 168 VGPRs (three waves per SIMD: the whole
+    4096-env grid resident in one round; and the 512-thread swarm layout loses 30 % above it, profiles/r02_swarm_occupancy.txt)
+    without scratch (a single spilled dword costs 0.8 MB of HBM writes per launch), and no policy kernel may spill."""
+    import re
+    import struct
+    import subprocess
+    from massive_marl_benchmark_amd import _lib
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not found")
+    data = open(_lib.LIB_PATH, "rb").read()
+    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0
+    n = struct.unpack_from("<Q", data, i + 24)[0]
+    off, code = i + 32, None
+    for _ in range(n):
+        o, s, tl = struct.unpack_from("<QQQ", data, off)
+        off += 24
+        triple = data[off:off + tl].decode()
+        off += tl
+        if "gfx950" in triple:
+            code = data[i + o:i + o + s]
+    assert code, "no gfx950 code object in libmms.so"
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(code)
+        f.flush()
+        notes = subprocess.check_output([readelf, "--notes", f.name]).decode()
+    kernels = {}
+    for block in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = (int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)), int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)))
+    step = {k: v for k, v in kernels.items() if "ant_step_kernelILi0E" in k}
+    assert len(step) >= 8, sorted(kernels)
+    for k, (vgpr, scratch) in step.items():
+        assert vgpr <= 168 and scratch == 0, (k, vgpr, scratch)
+    for k, (vgpr, scratch) in kernels.items():
+        if "linear_act" in k or "marl_heads" in k or "layernorm_rows" in k or "ppo_head_act" in k:
+            assert scratch == 0, (k, vgpr, scratch)
