@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """MAPPO policy inference of one collect step, TenAnt shapes (ten agents, obs 46 / share_obs 388 / 8 actions, hidden 512, layer_N 2,
-cfg/mappo/config.yaml) at 4096 envs: the grouped operators (algorithms/marl/policy_inference.py: 13 launches for all twenty
+cfg/mappo/config.yaml) at 4096 envs: the grouped operators (algorithms/marl/policy_inference.py: ten launches for all twenty
 networks) against the reference's way -- agent by agent, torch modules (runner.py:186-216 -> actor_critic.py:43-69, 137-155; the
 fp32 torch statement of tests/marl_modules.py: LayerNorm, Linear, ELU, ..., Normal sample, log_prob), eager and as a hipGraph.
 
