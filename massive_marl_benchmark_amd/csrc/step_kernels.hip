@@ -274,12 +274,15 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
             // the opening of the inward pass (kinematics, foot body, the tip's ground contact) does not need the box: the ant waves
             // work through it while the box lanes finish the previous substep's serial tail; the barrier behind which this
             // substep's box pose is valid sits HERE, not at the end of the previous substep
-            if (is_ant && simulate) leg_inward_open<kSensors, DR>(M, L, h, S, P, &SP, W, park, s_dr);
-            if (wait_for_box) __syncthreads();
+            // (one wave per block -- the 64-thread layouts: nothing to overlap; the pass stays in one piece behind the barrier)
+            constexpr bool kSplit = BLOCK > 64;
+            if (kSplit && is_ant && simulate) leg_inward_open<kSensors, DR>(M, L, h, S, P, &SP, W, park, s_dr);
+            if (kSplit ? wait_for_box : false) __syncthreads();
             if (is_ant && simulate) {
                 const float tau1 = s_act[0] * L.gear[0] * C->power_scale;    // ten_ant.py:889
                 const float tau2 = s_act[1] * L.gear[1] * C->power_scale;
-                leg_inward_close<kSensors, DR>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0, W, s_dr);
+                if (!kSplit) leg_inward<kSensors, DR>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0, park, s_dr);
+                else leg_inward_close<kSensors, DR>(M, L, h, S, leg, tau1, tau2, true, *s_bp, P, &SP, IA0, pA0, W, s_dr);
             }
             // (quads never mix ant and box lanes, and `simulate` is per env: a quad that skipped the inward pass skips the outward
             // pass too, so what the reduction leaves in its lanes is never read -- no zero fill)
@@ -365,6 +368,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
             }
             // (no barrier here: the next substep's ant phase waits for the box pose after its box-independent opening, and behind
             // the last substep only the box lead reads what it wrote itself until the epilogue's own barrier)
+            if (BLOCK == 64) __syncthreads();
         }
     }
 
