@@ -279,7 +279,8 @@ int mms_row_moments_group(int device, int32_t groups, int64_t M, int32_t K, int3
 int mms_layernorm_group(int device, int32_t groups, int64_t M, int32_t K, int32_t Kp, int32_t x_pitch, const float* const* x,
                         const float* const* gamma, const float* const* beta, float* const* y, float eps, void* hip_stream);
 
-/* The last LayerNorm + the output layer (+ the Gaussian sample) of each network: out_g[r, j] = b_g[j] + sum_k w_g[j, k] *
+/* (eps < 0: no LayerNorm -- the plain output layer on h_g; gamma / beta are not read.)
+ * The last LayerNorm + the output layer (+ the Gaussian sample) of each network: out_g[r, j] = b_g[j] + sum_k w_g[j, k] *
  * LN(h_g[r])[k], j < A[g] <= 16, H <= 1024.  std[g] != NULL ([A[g]] standard deviations): out_g = that mean + std z with z ~ N(0,1)
  * from the counter-based stream keyed (seed + g, row_offset + r, counters[g][r], j) (counters[g][r] += 1; counters or counters[g]
  * NULL: counter 0), and logp[g][r, j] = log N(out_j | mean_j, std_j), PER DIMENSION, [M, A[g]] (FixedNormal.log_probs,

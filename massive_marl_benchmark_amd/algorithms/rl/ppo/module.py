@@ -251,7 +251,8 @@ class ActorCritic(nn.Module):
             x = critic_in
             ok = (self.fuse_layers and x.is_cuda and x.dtype == torch.float32 and len(lin) >= 2 and lin[-1].out_features == 1
                   and all(isinstance(m, nn.ELU) and m.alpha == 1.0 for m in acts)
-                  and all(l.weight.dtype == torch.float32 and l.in_features % 4 == 0 and l.bias is not None for l in lin))
+                  and all(l.weight.dtype == torch.float32 and l.in_features % 4 == 0 and l.bias is not None for l in lin)
+                  and lin[-1].in_features <= 1024)
             if not ok:
                 return self.critic(x)
             L, idx, stream = _lib.for_device(x.device)
@@ -264,7 +265,14 @@ class ActorCritic(nn.Module):
                 _lib.check(L.mms_linear2_act(idx, M, l.out_features, l.in_features, p(h), p(l.weight.detach()), p(l.bias.detach()), p(y),
                                              None, None, None, None, 1, stream), None, "mms_linear2_act", L)
                 h = y
-            return (torch.mv(h, lin[-1].weight.detach()[0]) + lin[-1].bias.detach()).view(-1, 1)
+            # the 1-wide output layer: one launch of the grouped heads operator without its LayerNorm (eps < 0) instead of a
+            # library matrix-vector product + its output fill + a bias add
+            out = torch.empty(M, 1, device=x.device)
+            one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+            w, b = lin[-1].weight.detach(), lin[-1].bias.detach()
+            _lib.check(L.mms_marl_heads_act(idx, 1, M, lin[-1].in_features, one(h), one(w), one(w), one(w), one(b), (ctypes.c_int32 * 1)(1), None,
+                                            one(out), None, None, None, 0, 0, -1.0, stream), None, "mms_marl_heads_act", L)
+            return out
 
     def act_inference(self, observations):
         return self.actor(observations)

@@ -515,8 +515,12 @@ MMS_API int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H,
 #pragma omp parallel for schedule(static)
         for (int64_t m = 0; m < M; m++) {
             float mean, rstd, xh[1024];
-            ln_row(h[g] + m * H, H, eps, mean, rstd);
-            for (int k = 0; k < H; k++) xh[k] = (h[g][m * H + k] - mean) * rstd * gamma[g][k] + beta[g][k];
+            if (eps >= 0.f) {
+                ln_row(h[g] + m * H, H, eps, mean, rstd);
+                for (int k = 0; k < H; k++) xh[k] = (h[g][m * H + k] - mean) * rstd * gamma[g][k] + beta[g][k];
+            } else {
+                for (int k = 0; k < H; k++) xh[k] = h[g][m * H + k];
+            }
             const int64_t c = cnt ? cnt[m] : 0;
             for (int j = 0; j < A[g]; j++) {
                 float p = 0.f;

@@ -539,10 +539,12 @@ __global__ void __launch_bounds__(256) marl_heads_kernel(HeadsArgs a) {
         float v[kLnPerLane];
 #pragma unroll
         for (int i = 0; i < kLnPerLane; i++) v[i] = (lane + 64 * i < H) ? h[lane + 64 * i] : 0.f;
-        float mean, rstd;
-        row_stats(v, H, lane, a.eps, mean, rstd);
+        if (a.eps >= 0.f) {                             // (eps < 0: no LayerNorm in front of the output layer)
+            float mean, rstd;
+            row_stats(v, H, lane, a.eps, mean, rstd);
 #pragma unroll
-        for (int i = 0; i < kLnPerLane; i++) v[i] = (v[i] - mean) * rstd * gm[i] + bt[i];      // (slots past H: gm = bt = 0)
+            for (int i = 0; i < kLnPerLane; i++) v[i] = (v[i] - mean) * rstd * gm[i] + bt[i];  // (slots past H: gm = bt = 0)
+        }
         float mine = 0.f;                               // lane j keeps output j
         for (int j = 0; j < A; j++) {
             const float* wj = s_w + j * H;
