@@ -246,15 +246,18 @@ def test_make_entry_glue():
 
 @pytest.mark.skipif(not os.path.isdir(os.environ.get("MMS_REFERENCE", "/root/reference")), reason="reference tree not present")
 def test_reference_learners_drop_in_unchanged(tmp_path):
-    """The reference's real PPO.run (agents/algorithms/rl/ppo/ppo.py:99-175) and Runner.run (agents/algorithms/marl/runner.py:114-151,
-    mappo), imported in place and unmodified, over this build's VecTaskPython / MultiVecTaskPython on the CPU build -- with the
-    reference's own storage / module / buffer classes, with this build's drop-in ones, and with the grouped policy inference as the
-    Runner's collect step.  The committed log of the same script:
+    """The reference's real learners, imported in place and unmodified, over this build's VecTaskPython / MultiVecTaskPython on the
+    CPU build: PPO.run (agents/algorithms/rl/ppo/ppo.py:99-175), Runner.run (agents/algorithms/marl/runner.py:114-151) as mappo, happo
+    and hatrpo (the sequential update_factor path, :266-316), DDPG.run (rl/ddpg/ddpg.py:116-204) and TD3.run (rl/td3/td3.py) on
+    MultiIngenuity -- each with the reference's own storage / module / buffer classes and with this build's drop-in ones, mappo also
+    with the grouped policy inference as the Runner's collect step.  The committed log of the same script:
     tests/golden/reference_learners_dropin.log."""
     log = tmp_path / "dropin.log"
     env = dict(os.environ, MMS_DROPIN_LOG=str(log), OMP_NUM_THREADS="4")
     r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tests", "golden", "run_reference_learners.py")], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, timeout=600)
+                       stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
     text = log.read_text()
-    assert text.count(": ok") == 5 and "Runner.run" in text and "PPO.run" in text and "GroupedPolicyInference as Runner.collect: ok" in text
+    assert text.count(": ok") == 13 and "GroupedPolicyInference as Runner.collect: ok" in text
+    for learner, n in (("PPO.run", 2), ("mappo, unmodified", 3), ("happo, unmodified", 2), ("hatrpo, unmodified", 2), ("DDPG.run", 2), ("TD3.run", 2)):
+        assert text.count(learner) == n, (learner, text)
