@@ -30,7 +30,8 @@
  *     / set_actor_dof_properties (base_task.py:343-395)
  *   ActorCritic.act sampling tail + RolloutStorage.add_transitions       mms_ppo_act, mms_ppo_heads_act,
  *     (algorithms/rl/ppo/module.py:73-87; storage.py:33-47)              mms_bind_rollout_out
- *   ActorCritic hidden layers (module.py:27-52)                          mms_linear2_act
+ *   ActorCritic hidden layers (module.py:27-52)                          mms_linear2_act, mms_linear_group_act_split,
+ *                                                                        mms_split_planes
  *   Actor / Critic forward of every MAPPO / HAPPO agent                  mms_linear_group_act, mms_layernorm_group,
  *     (algorithms/marl/actor_critic.py:43-69, 137-155; runner.py:186-216)  mms_row_stats_group, mms_marl_heads_act
  *
@@ -292,6 +293,24 @@ int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H, const f
                        const float* const* beta, const float* const* w, const float* const* b, const int32_t* A, const float* const* std,
                        float* const* out, float* const* logp, const int32_t* out_pitch, int64_t* const* counters, uint64_t seed,
                        int64_t row_offset, float eps, void* hip_stream);
+
+/* ---- the same layers on the bf16 matrix pipe with fp32 operands carried as three bf16 planes (csrc/split_kernels.hip) -----------
+ * An fp32 number is exactly a0 + a1 + a2 with a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1); the product is formed as the six
+ * bf16 MFMA products a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0 with fp32 accumulation (the dropped terms are < 2^-25 |a b|): the fp32
+ * product of module.py:27-52 at 16 / 6 of the fp32 MFMA rate, with an error against the float64 product that is not larger than the
+ * exact-fp32 MFMA kernel's (tests/test_gpu_parity.py measures both on the same inputs).
+ * Plane format "P32": bf16 [rows, KC, 3, 32], KC = ceil(K / 32): per row and per 32 consecutive k the three planes, 192 contiguous bytes;
+ * columns past K are zero.  MMS_P32_BYTES(rows, K) bytes. */
+#define MMS_P32_BYTES(rows, K) ((size_t)(rows) * (size_t)(((K) + 31) / 32) * 192)
+
+/* planes <- split(x): x [rows, K] f32 with row pitch x_pitch floats (0 = K; rows 16-byte aligned).  Weights once per optimizer step,
+ * the observation once per env step; hidden activations are left in P32 by the layer that produces them (out_planes below). */
+int mms_split_planes(int device, int64_t rows, int32_t K, int32_t x_pitch, const float* x, void* planes, void* hip_stream);
+
+/* y_g = act(x_g @ w_g^T + b_g), g < groups, as mms_linear_group_act, with x_g [M, K] and w_g [N, K] given as P32 planes and b_g [N] f32.
+ * out_planes != 0: y_g is left as P32 planes of [M, N] (the next split layer's x); 0: y_g [M, N] f32.  M and N multiples of 128. */
+int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
+                               const float* const* b, void* const* y, int32_t act, int32_t out_planes, void* hip_stream);
 
 const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
 int mms_abi_version(void);

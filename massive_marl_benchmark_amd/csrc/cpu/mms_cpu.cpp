@@ -387,6 +387,82 @@ MMS_API int mms_linear2_act(int device, int64_t M, int32_t N, int32_t K, const f
     return 0;
 }
 
+// ---- split-operand layers (csrc/split_kernels.hip): fp32 carried as three bf16 planes, format P32 = bf16 [rows, KC, 3, 32] ------------
+// On the host the planes are summed back (a0 + a1 + a2 IS the fp32 number) and the product is the same fmaf chain as mms_linear2_act.
+static inline uint16_t f2bf(float f) {                                    // round to nearest even, as v_cvt_pk_bf16_f32
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf2f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline void split3(float v, uint16_t* p0, uint16_t* p1, uint16_t* p2) {
+    *p0 = f2bf(v); v -= bf2f(*p0);
+    *p1 = f2bf(v); v -= bf2f(*p1);
+    *p2 = f2bf(v);
+}
+static inline float join3(const uint16_t* chunk, int j) { return (bf2f(chunk[j]) + bf2f(chunk[32 + j])) + bf2f(chunk[64 + j]); }
+
+MMS_API int mms_split_planes(int device, int64_t rows, int32_t K, int32_t x_pitch, const float* x, void* planes, void*) {
+    if (cpu_only(device)) return 1;
+    if (x_pitch == 0) x_pitch = K;
+    if (!x || !planes || rows < 0 || K <= 0 || x_pitch < K) { g_error = "mms_split_planes: bad arguments"; return 1; }
+    const int KC = (K + 31) / 32;
+    uint16_t* out = (uint16_t*)planes;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++)
+        for (int kc = 0; kc < KC; kc++) {
+            uint16_t* c = out + (r * KC + kc) * 96;
+            for (int j = 0; j < 32; j++) {
+                const int k = kc * 32 + j;
+                split3(k < K ? x[r * x_pitch + k] : 0.f, c + j, c + 32 + j, c + 64 + j);
+            }
+        }
+    return 0;
+}
+
+MMS_API int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
+                                       const float* const* b, void* const* y, int32_t act, int32_t out_planes, void*) {
+    if (cpu_only(device)) return 1;
+    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_linear_group_act_split: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
+    if (!x || !w || !b || !y || M < 0 || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3) {
+        g_error = "mms_linear_group_act_split: bad arguments (M and N multiples of 128, act 0..3)";
+        return 1;
+    }
+    const int KC = (K + 31) / 32, NC = N / 32;
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !w[g] || !b[g] || !y[g]) { g_error = "mms_linear_group_act_split: null pointer in a group"; return 1; }
+        const uint16_t* xp = (const uint16_t*)x[g];
+        const uint16_t* wp = (const uint16_t*)w[g];
+        std::vector<float> wf((size_t)N * KC * 32);
+        for (int64_t n = 0; n < N; n++)
+            for (int k = 0; k < KC * 32; k++) wf[n * KC * 32 + k] = join3(wp + (n * KC + k / 32) * 96, k % 32);
+#pragma omp parallel for schedule(static)
+        for (int64_t m = 0; m < M; m++) {
+            std::vector<float> xr((size_t)KC * 32);
+            for (int k = 0; k < KC * 32; k++) xr[k] = join3(xp + (m * KC + k / 32) * 96, k % 32);
+            for (int n = 0; n < N; n++) {
+                float s = 0.f;
+                const float* wr = wf.data() + (size_t)n * KC * 32;
+                for (int k = 0; k < KC * 32; k++) s = fmaf(xr[k], wr[k], s);
+                const float v = act_fn(s + b[g][n], act);
+                if (out_planes) {
+                    uint16_t* c = (uint16_t*)y[g] + (m * NC + n / 32) * 96 + n % 32;
+                    split3(v, c, c + 32, c + 64);
+                } else {
+                    ((float*)y[g])[m * N + n] = v;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 // ---- grouped policy inference (the same three operators as the HIP build; plain loops) -------------------------------------------
 static bool bad_groups(int32_t groups, const char* what) {
     if (groups >= 1 && groups <= MMS_MAX_GROUPS) return false;

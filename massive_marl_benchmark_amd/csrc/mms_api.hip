@@ -427,6 +427,42 @@ __attribute__((visibility("default"))) int mms_linear2_act(int device, int64_t M
     return 0;
 }
 
+// ---- split-operand layers (split_kernels.hip) ---------------------------------------------------------------------------------
+__attribute__((visibility("default"))) int mms_split_planes(int device, int64_t rows, int32_t K, int32_t x_pitch, const float* x, void* planes, void* s) {
+    MMS_DEV(device)
+    if (x_pitch == 0) x_pitch = K;
+    if (!x || !planes || rows < 0 || K <= 0 || x_pitch < K || (x_pitch % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 ||
+        (reinterpret_cast<uintptr_t>(planes) & 15) != 0) {
+        g_create_error = "mms_split_planes: bad arguments (x and planes 16-byte aligned, x_pitch >= K and a multiple of 4)";
+        return 1;
+    }
+    MMS_FREE(mms::launch_split_planes(x, planes, rows, K, x_pitch, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x,
+                                                                      const void* const* w, const float* const* b, void* const* y, int32_t act,
+                                                                      int32_t out_planes, void* s) {
+    MMS_DEV(device)
+    if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_linear_group_act_split: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
+    if (!x || !w || !b || !y || M < 0 || M > 0x7fffffff || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3) {
+        g_create_error = "mms_linear_group_act_split: bad arguments (M and N multiples of 128, act 0..3)";
+        return 1;
+    }
+    mms::SplitLinearArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !w[g] || !b[g] || !y[g]) { g_create_error = "mms_linear_group_act_split: null pointer in a group"; return 1; }
+        if (((reinterpret_cast<uintptr_t>(x[g]) | reinterpret_cast<uintptr_t>(w[g]) | reinterpret_cast<uintptr_t>(y[g]) | reinterpret_cast<uintptr_t>(b[g])) & 15) != 0) {
+            g_create_error = "mms_linear_group_act_split: operands must be 16-byte aligned";
+            return 1;
+        }
+        a.x[g] = x[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.y[g] = y[g];
+    }
+    a.M = (int)M; a.N = N; a.KC = (K + 31) / 32; a.act = act; a.out_planes = out_planes ? 1 : 0;
+    MMS_FREE(mms::launch_linear_split(a, groups, (hipStream_t)s));
+    return 0;
+}
+
 // ---- grouped policy inference (MAPPO / HAPPO: all agents' networks per launch) -----------------------------------------------
 static bool bad_group_count(int32_t groups, const char* what) {
     if (groups >= 1 && groups <= mms::kMaxGroups) return false;

@@ -71,7 +71,21 @@ struct HeadsArgs {
     float eps;
 };
 
+// The same layer with both operands in the three-plane bf16 format "P32" (split_kernels.hip): x_g [M, KC, 3, 32] bf16, w_g [N, KC, 3, 32]
+// bf16, b_g [N] f32; y_g either P32 planes [M, N / 32, 3, 32] (out_planes, the next split layer's input) or f32 [M, N].
+struct SplitLinearArgs {
+    const void* x[kMaxGroups];
+    const void* w[kMaxGroups];
+    const float* b[kMaxGroups];
+    void* y[kMaxGroups];
+    int M, N, KC;       // KC = ceil(K / 32) chunks per row
+    int act;            // as LinearArgs::act
+    int out_planes;
+};
+
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
+hipError_t launch_linear_split(const SplitLinearArgs& a, int groups, hipStream_t s);
+hipError_t launch_split_planes(const float* x, void* planes, int64_t rows, int K, int x_pitch, hipStream_t s);
 hipError_t launch_row_stats(const RowStatsArgs& a, int groups, hipStream_t s);
 hipError_t launch_layernorm(const LayerNormArgs& a, int groups, hipStream_t s);
 hipError_t launch_marl_heads(const HeadsArgs& a, int groups, hipStream_t s);
