@@ -7,7 +7,10 @@
 
 One "step" = one PPO rollout step over this rank's 4096 envs: actor + critic inference (the reference's
 ActorCritic, agents/algorithms/rl/ppo/module.py: two MLPs [1024,1024,512], ELU, fp32 -- each hidden layer of both networks one
-fp32-MFMA launch with bias + ELU fused, mms_linear2_act), both last layers + Gaussian action sample + log-prob + the
+launch with bias + ELU fused: mms_linear_group_act_split, the fp32 product evaluated on the bf16 matrix pipe from operands carried
+as three bf16 planes (exact split, six plane products, fp32 accumulation; its error against float64 is measured in this run next to
+the exact-fp32 MFMA kernel's, `policy_layers_error_vs_f64`, and the rollout with the exact-fp32 MFMA layers, mms_linear2_act, is
+timed beside it: `rollout_exact_fp32_layers`), both last layers + Gaussian action sample + log-prob + the
 add_transitions stores (mms_ppo_heads_act, one HIP launch), the fused VecTask
 step (mms_step: physics substeps + reset + obs + reward in one HIP launch, writing observation / reward / done
 straight into the rollout slots), and every nsteps=8 steps the GAE scan + advantage normalisation
@@ -85,6 +88,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout step eagerly instead of replaying a hipGraph")
     ap.add_argument("--library-gemms", action="store_true",
                     help="A/B: the policy's layers as library GEMMs + separate ELU passes (critic on a second stream) instead of mms_linear2_act / mms_ppo_heads_act")
+    ap.add_argument("--exact-fp32-layers", action="store_true",
+                    help="A/B: headline with the hidden layers on the exact-fp32 MFMA kernel (mms_linear2_act) instead of the three-plane split kernel")
     ap.add_argument("--one-stream", action="store_true", help="A/B: actor and critic MLPs on one stream")
     ap.add_argument("--defer-critic", action="store_true",
                     help="A/B: let the critic pass overlap the sampling kernel and the env step (joined before the GAE); faster, but "
@@ -148,7 +153,7 @@ def main():
     ring = [(torch.rand(N, act_dim, generator=g) * 2 - 1).to(device) for _ in range(16)]
 
     def sim_step(i):
-        actions_buf.copy_(ring[i % 16])
+        eng.bind_actions(ring[i % 16])              # the engine reads the caller's tensor in place (mms_bind_actions): no copy kernel
         eng.step()
 
     for i in range(64):                         # reset-all + settle
@@ -184,6 +189,7 @@ def main():
                 sim_graph.replay()
         torch.cuda.synchronize()
         sim_batches.append(time.perf_counter() - t0)
+    eng.bind_actions(None)
     sim_wall = 4.0 * sorted(sim_batches)[1]            # (lower) median batch x 4; the mean and every batch are reported beside it
     sim_wall_mean = sum(sim_batches)
     # step-kernel launch duration: back-to-back launches with nothing else on the stream, HIP events around them.
@@ -199,8 +205,9 @@ def main():
     kernel_ms_pre = time_step_kernel()
 
     # ---- PPO rollout series -----------------------------------------------------------------------------------
-    def measure_rollout(pdtype, K_req, W_req):
+    def measure_rollout(pdtype, K_req, W_req, split=True):
         ac_ = ac if pdtype == torch.float32 else ac_bf16
+        ac_.split_layers = bool(split)
         ac_.bind_rollout(None if args.unfused else storage, None if args.unfused else actions_buf)
         ac_.two_streams = not args.one_stream
         ac_.fuse_head = not args.library_gemms
@@ -347,8 +354,13 @@ def main():
         bf_elapsed, bf_K, _, _ = measure_rollout(torch.bfloat16, min(args.steps, 128), 16)     # informational series
     else:
         ac_bf16 = ac.to(torch.bfloat16)
-    elapsed, K, W, graphed = measure_rollout(pdtype, args.steps, args.warmup)
+    # the same rollout with the hidden layers on the exact-fp32 MFMA kernel (round 2's headline path), beside the split kernel
+    ex_elapsed, ex_K = 0.0, 0
+    if args.policy_dtype == "fp32" and not args.exact_fp32_layers and not args.library_gemms:
+        ex_elapsed, ex_K, _, _ = measure_rollout(torch.float32, min(args.steps, 128), 16, split=False)
+    elapsed, K, W, graphed = measure_rollout(pdtype, args.steps, args.warmup, split=not args.exact_fp32_layers)
     graph = graphed or None
+    layer_err = policy_layer_errors(torch, ac, obs_clipped) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
     eng.bind_obs_out(None)
     eng.bind_rollout_out(None, None)
     eng.set_obs_outputs(True, True)
@@ -360,12 +372,12 @@ def main():
     n_b2b = 64 + 8 * 16 + sim_steps + 2 * 256
     n_roll = sum(NSTEPS + w + k + 4 * NSTEPS for (w, k) in rollout_counts)
     kernel_ms = (n_b2b * kernel_ms_b2b + n_roll * kernel_ms_roll) / (n_b2b + n_roll)
-    tmax = torch.tensor([elapsed, sim_wall, kernel_ms, bf_elapsed, kernel_ms_b2b, kernel_ms_roll], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed, sim_wall, kernel_ms, bf_elapsed, kernel_ms_b2b, kernel_ms_roll, ex_elapsed], dtype=torch.float64, device=device)
     if dist is not None:
         if dist.get_backend() == "gloo":
             tmax = tmax.cpu()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed, sim_wall, kernel_ms, bf_elapsed, kernel_ms_b2b, kernel_ms_roll = [float(x) for x in tmax.tolist()]
+    elapsed, sim_wall, kernel_ms, bf_elapsed, kernel_ms_b2b, kernel_ms_roll, ex_elapsed = [float(x) for x in tmax.tolist()]
     finite = bool(torch.isfinite(obs_clipped).all().item()) and bool(torch.isfinite(rew).all().item())
     resets_seen = int(eng.tensor("reset_count").sum().item())
 
@@ -385,13 +397,18 @@ def main():
         traffic = tr["traffic_bytes_per_launch"] if (tr and tr.get("num_envs") == N) else None
         line = {
             "metric": "env-steps/sec (whole node), TenAnt 4096 envs/GPU, PPO rollout",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "warmup_effective": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("f32 (policy-layer products: fp32 operands as 3 exact bf16 planes, 6 bf16 MFMA products, fp32 accumulation; "
+                      "error vs float64 <= the exact-fp32 MFMA kernel's, see policy_layers_error_vs_f64)") if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "f32",
+            "data": "synthetic",
             "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
                                    "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else "mms_linear2_act + mms_ppo_heads_act",
+                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else (("mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)" if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "mms_linear2_act (exact fp32 MFMA)") + " + mms_ppo_heads_act"),
+                       "friction": {"rule": "average" if abs(eng.config.model.boxgnd_mu) > 0 else "min", "gnd_mu": eng.config.model.gnd_mu,
+                                    "boxgnd_mu": eng.config.model.boxgnd_mu, "antbox_mu": eng.config.model.antbox_mu,
+                                    "note": "this build's modelling choice (PhysX default combine rule), not reference-pinned: DESIGN.md section 4"},
                        "critic_deferred": bool(args.defer_critic), "finite": finite, "resets_total": resets_seen},
             "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
                          "value_mean": world * N * sim_steps / sim_wall_mean, "ms_per_step_mean": 1e3 * sim_wall_mean / sim_steps,
@@ -416,6 +433,12 @@ def main():
                                         "command averages"},
             "cpu_baseline": cpu,
         }
+        if ex_K:
+            line["rollout_exact_fp32_layers"] = {"value": world * N * ex_K / ex_elapsed, "unit": "env-steps/s", "steps": ex_K, "ms_per_step": 1e3 * ex_elapsed / ex_K,
+                                                 "note": "the same rollout with the hidden layers on the exact-fp32 MFMA kernel (mms_linear2_act, v_mfma_f32_32x32x2_f32): "
+                                                         "round 2's headline path, kept as the A/B of the split kernel"}
+        if layer_err is not None:
+            line["policy_layers_error_vs_f64"] = layer_err
         if bf_K:
             line["rollout_bf16_policy"] = {"value": world * N * bf_K / bf_elapsed, "unit": "env-steps/s", "steps": bf_K,
                                            "note": "same rollout with the policy MLPs in bf16 (fp32 accumulate); informational, not the headline"}
@@ -423,6 +446,32 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     eng.close()
+
+
+def policy_layer_errors(torch, ac, obs):
+    """Both networks' last hidden activations (three layers deep) on the bench's own observation rows and weights: the split kernel
+    and the exact-fp32 MFMA kernel, each against the same layers evaluated in float64."""
+    import copy
+    obs = obs.detach().clone()
+    out = {}
+    with torch.no_grad():
+        ref = [copy.deepcopy(net[:-1]).double()(obs.double()) for net in (ac.actor, ac.critic)]
+        scale = float(torch.cat(ref).pow(2).mean().sqrt())
+        for name, split in (("split_3xbf16", True), ("exact_fp32_mfma", False)):
+            keep = ac.split_layers
+            ac.split_layers = split
+            try:
+                hid = ac._fused_hidden(obs, obs)
+            finally:
+                ac.split_layers = keep
+            if hid is None:
+                return None
+            e = torch.cat([hid[g].double() - ref[g] for g in range(2)])
+            out[name] = {"rms": float(e.pow(2).mean().sqrt()) / scale, "max": float(e.abs().max()) / scale, "mean": float(e.mean()) / scale}
+    out["unit"] = "rms of the float64 activations (%.4f)" % scale
+    out["note"] = ("error of the last hidden layer's activations [2 x %d x %d], three layers deep, against the same layers in float64, on the "
+                   "observation rows and weights of this run" % (obs.shape[0], ref[0].shape[1]))
+    return out
 
 
 def cpu_baseline(n_envs, steps):
@@ -461,6 +510,35 @@ def cpu_baseline(n_envs, steps):
             one_ant.step(acts[i])
         n1 += 16
     out["one_ant_64_envs"] = {"value": 64 * n1 / (time.perf_counter() - t0), "unit": "env-steps/s", "steps": n1}
+    out["note"] = ("host-dependent: the same 400-step sample took 10.2 s and 13.6 s on two boxes of round 2 (160 K / 120 K env-steps/s) with "
+                   "identical code -- the pool's hosts differ and share their cores; compare within one run only")
+    # the PRODUCT's CPU build (lib/libmms_cpu.so = the reference's `--sim_device cpu` pipeline of this engine, csrc/cpu/: the kernels'
+    # own lane math compiled for the host, OpenMP over envs) on the same workload, beside the oracle port
+    try:
+        import torch
+        from massive_marl_benchmark_amd.engine import Engine
+        ce = Engine("TenAnt", num_envs=n_envs, device="cpu", seed=0, clip_obs=5.0)
+        acts = [torch.from_numpy(r) for r in ring]
+        for i in range(4):
+            ce.bind_actions(acts[i])
+            ce.step()
+        t0 = time.perf_counter()
+        ce.bind_actions(acts[4])
+        ce.step()
+        one = time.perf_counter() - t0
+        psteps = int(max(8, min(400, 10.0 / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        for i in range(psteps):
+            ce.bind_actions(acts[i % 16])
+            ce.step()
+        pdt = time.perf_counter() - t0
+        ce.bind_actions(None)
+        ce.close()
+        out["product_cpu_build"] = {"value": n_envs * psteps / pdt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                                    "sample": "libmms_cpu.so (the engine's own CPU build: device_type=cpu), TenAnt %d envs x %d sim steps, %.1f s"
+                                              % (n_envs, psteps, pdt)}
+    except Exception as e:                                  # the CPU build is optional for the bench; say why it is missing
+        out["product_cpu_build"] = {"value": None, "error": repr(e)}
     return out
 
 

@@ -160,6 +160,12 @@ int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_ho
  * [T,N,obs_dim]; NULL disables.  The pointer must stay valid until the next bind. */
 int mms_bind_obs_out(mms_handle h, void* dst);
 
+/* Optional source of the actions: mms_step reads `src` (f32 [N, num_actions], on the engine's device) IN PLACE instead of the
+ * engine's own "actions" buffer -- the tensor VecTaskPython.step(actions) was handed (vec_task.py:126-131 clamps and copies it into
+ * the task; here the clamp is in the kernel and the copy is gone).  NULL returns to the "actions" buffer.  The pointer must stay
+ * valid until the next bind. */
+int mms_bind_actions(mms_handle h, const float* src);
+
 /* Physical domain randomisation of the ants (cfg/TenAnt.yaml:97-122 actor_params, applied by base_task.py:343-395 through
  * set_actor_rigid_body_properties / set_actor_dof_properties).  The caller fills "dr_params" [N*A, MMS_DR_FLOATS] per ant:
  *   [0] torso, [1..4] leg, [5..8] foot mass scale (the inertia scales with the mass: recomputeInertia is the setter's default),

@@ -60,6 +60,8 @@ class ActorCritic(nn.Module):
         self._act_bufs = None
         self._value_bufs = None
         self._one_bufs = None
+        self._wplanes = None    # id(Linear) -> (version tag, P32 planes of its weight)
+        self._split_bufs = None
 
     @staticmethod
     def init_weights(sequential, scales):
@@ -73,6 +75,12 @@ class ActorCritic(nn.Module):
     # critic on a second stream (profiles/r01_v12_*).  With fuse_layers off, fuse_head alone puts only the actor's last layer into
     # the sampling kernel (no gain next to the critic's GEMMs: 371.8 us against 365.5 us, profiles/r01_v8_rollout_ab.txt).
     fuse_layers = True
+    # The hidden layers on the bf16 matrix pipe with fp32 operands carried as three bf16 planes (csrc/split_kernels.hip,
+    # mms_linear_group_act_split): the same fp32 product -- an fp32 number IS the sum of its three planes, six plane products are kept
+    # and accumulated in fp32, what is dropped is < 2^-25 of a product -- at ~1.8 x the rate of the exact-fp32 MFMA kernel and with an
+    # error against the float64 product that is not larger than that kernel's (tests/test_gpu_parity.py::test_split_layers_error).
+    # Applies when the batch and every hidden width are multiples of 128; False = the exact-fp32 MFMA kernel (mms_linear2_act).
+    split_layers = True
     fuse_head = True
     two_streams = True      # critic beside the actor on a second stream
     defer_value = False     # opt-in: `act` returns before the critic has finished; the owner calls join() before reading values
@@ -96,8 +104,75 @@ class ActorCritic(nn.Module):
                 and all(la.weight.shape == lc.weight.shape and la.weight.dtype == torch.float32 and la.in_features % 4 == 0
                         and la.bias is not None and lc.bias is not None for la, lc in zip(a_lin[:-1], c_lin[:-1])))
 
+    # -- split-operand layers ------------------------------------------------------------------
+    @staticmethod
+    def _p32_bytes(rows, K):
+        return rows * ((K + 31) // 32) * 192               # MMS_P32_BYTES (include/mms.h)
+
+    def _weight_planes(self, lin, L, idx, stream):
+        """P32 planes of a Linear layer's weight, re-split when the parameter has changed (its version counter moves with every
+        in-place optimizer step) or moved."""
+        if self._wplanes is None:
+            self._wplanes = {}
+        w = lin.weight.detach()
+        tag = (w._version, w.data_ptr(), str(w.device))
+        hit = self._wplanes.get(id(lin))
+        if hit is None or hit[0] != tag:
+            planes = hit[1] if hit is not None and hit[1].device == w.device else \
+                torch.empty(self._p32_bytes(lin.out_features, lin.in_features), dtype=torch.uint8, device=w.device)
+            wc = w.contiguous()
+            _lib.check(L.mms_split_planes(idx, lin.out_features, lin.in_features, 0, ctypes.c_void_p(wc.data_ptr()),
+                                          ctypes.c_void_p(planes.data_ptr()), stream), None, "mms_split_planes", L)
+            self._wplanes[id(lin)] = (tag, planes)
+            return planes
+        return hit[1]
+
+    def _split_applies(self, M, lins):
+        return self.split_layers and M > 0 and M % 128 == 0 and all(l.out_features % 128 == 0 for l in lins)
+
+    def _split_hidden(self, nets, inputs, tag):
+        """Hidden layers of the networks in `nets` (lists of their hidden Linear layers, the same shapes in every network), one
+        mms_linear_group_act_split launch per layer for all of them.  `inputs`: one fp32 [M, K] tensor per network (the same tensor
+        twice is split once).  Activations stay in the three-plane format between the layers; the last one leaves fp32 [M, H]."""
+        x0 = inputs[0]
+        dev, M, K = x0.device, x0.shape[0], x0.shape[1]
+        L, idx, stream = _lib.for_device(dev)
+        G, nl = len(nets), len(nets[0])
+        key = (tag, M, K, str(dev), G, tuple(l.out_features for l in nets[0]))
+        if self._split_bufs is None:
+            self._split_bufs = {}
+        bufs = self._split_bufs.get(key)
+        if bufs is None:
+            u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+            bufs = {"x": [u8(self._p32_bytes(M, K)) for _ in range(G)],
+                    "h": [[u8(self._p32_bytes(M, l.out_features)) for _ in range(G)] for l in nets[0][:-1]],
+                    "out": [torch.empty(M, nets[0][-1].out_features, device=dev) for _ in range(G)]}
+            self._split_bufs[key] = bufs
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        cur = []
+        for g, x in enumerate(inputs):
+            same = next((h for h in range(g) if inputs[h].data_ptr() == x.data_ptr() and inputs[h].shape == x.shape), None)
+            if same is not None:
+                cur.append(cur[same])
+                continue
+            assert x.dtype == torch.float32 and x.stride(1) == 1
+            _lib.check(L.mms_split_planes(idx, M, K, x.stride(0), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(bufs["x"][g].data_ptr()), stream),
+                       None, "mms_split_planes", L)
+            cur.append(bufs["x"][g])
+        for li in range(nl):
+            lins = [net[li] for net in nets]
+            last = li == nl - 1
+            out = bufs["out"] if last else bufs["h"][li]
+            wp = [self._weight_planes(l, L, idx, stream) for l in lins]
+            _lib.check(L.mms_linear_group_act_split(idx, G, M, lins[0].out_features, lins[0].in_features, arr(cur), arr(wp),
+                                                    arr([l.bias.detach() for l in lins]), arr(out), 1, 0 if last else 1, stream),
+                       None, "mms_linear_group_act_split", L)
+            cur = out
+        return bufs["out"]
+
     def _fused_hidden(self, x, critic_in):
-        """Hidden layers of BOTH networks, one mms_linear2_act launch per layer (fp32 MFMA, bias + ELU in the epilogue).
+        """Hidden layers of BOTH networks, one launch per layer (bias + ELU in the epilogue): mms_linear_group_act_split (three-plane
+        operands on the bf16 pipe) when the shapes allow, else mms_linear2_act (fp32 MFMA).
         Returns (actor hidden, critic hidden) or None when the two MLPs are not ELU networks of identical hidden shapes."""
         a_lin = [m for m in self.actor if isinstance(m, nn.Linear)]
         c_lin = [m for m in self.critic if isinstance(m, nn.Linear)]
@@ -108,6 +183,9 @@ class ActorCritic(nn.Module):
         L, idx, stream = _lib.for_device(dev)
         ha, hc = x.contiguous(), critic_in.contiguous()
         M = ha.shape[0]
+        if self._split_applies(M, a_lin[:-1]) and ha.data_ptr() % 16 == 0 and hc.data_ptr() % 16 == 0:
+            out = self._split_hidden([a_lin[:-1], c_lin[:-1]], [ha, hc], "act")
+            return out[0], out[1]
         # activations of the hidden layers: allocated once per (batch, device) and reused -- the eager path would otherwise take an
         # allocator round trip per layer and call
         key = (M, str(dev))
@@ -258,13 +336,16 @@ class ActorCritic(nn.Module):
             L, idx, stream = _lib.for_device(x.device)
             p = lambda t: ctypes.c_void_p(t.data_ptr())
             h, M = x.contiguous(), x.shape[0]
-            key = (M, str(x.device))
-            if self._value_bufs is None or self._value_bufs[0] != key:
-                self._value_bufs = (key, [torch.empty(M, l.out_features, device=x.device) for l in lin[:-1]])
-            for l, y in zip(lin[:-1], self._value_bufs[1]):
-                _lib.check(L.mms_linear2_act(idx, M, l.out_features, l.in_features, p(h), p(l.weight.detach()), p(l.bias.detach()), p(y),
-                                             None, None, None, None, 1, stream), None, "mms_linear2_act", L)
-                h = y
+            if self._split_applies(M, lin[:-1]) and h.data_ptr() % 16 == 0:
+                h = self._split_hidden([lin[:-1]], [h], "value")[0]
+            else:
+                key = (M, str(x.device))
+                if self._value_bufs is None or self._value_bufs[0] != key:
+                    self._value_bufs = (key, [torch.empty(M, l.out_features, device=x.device) for l in lin[:-1]])
+                for l, y in zip(lin[:-1], self._value_bufs[1]):
+                    _lib.check(L.mms_linear2_act(idx, M, l.out_features, l.in_features, p(h), p(l.weight.detach()), p(l.bias.detach()), p(y),
+                                                 None, None, None, None, 1, stream), None, "mms_linear2_act", L)
+                    h = y
             # the 1-wide output layer: one launch of the grouped heads operator without its LayerNorm (eps < 0) instead of a
             # library matrix-vector product + its output fill + a bias add
             out = torch.empty(M, 1, device=x.device)

@@ -36,6 +36,7 @@ struct mms_engine {
     mms_config cfg;
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
     float* obs_out = nullptr;
+    const float* actions_in = nullptr;
     int write_raw_obs = 1, write_clipped_obs = 1, dr_enabled = 0;
     float* rew_out = nullptr;
     uint8_t* done_out = nullptr;
@@ -176,7 +177,7 @@ MMS_API int mms_get_tensor(mms_handle h, const char* name, mms_tensor* out) {
 
 static int do_step(mms_handle h, int physics) {
     if (!h) return fail(nullptr, "mms_step: null handle");
-    mms::HostBufs b{buf<float>(h, "actions"), h->write_raw_obs ? buf<float>(h, "obs") : nullptr,
+    mms::HostBufs b{h->actions_in ? const_cast<float*>(h->actions_in) : buf<float>(h, "actions"), h->write_raw_obs ? buf<float>(h, "obs") : nullptr,
                     h->write_clipped_obs ? buf<float>(h, "obs_clipped") : nullptr, buf<float>(h, "rew"), buf<int64_t>(h, "reset"),
                     buf<int64_t>(h, "progress"), buf<float>(h, "root_states"), buf<float>(h, "initial_root_states"),
                     buf<float>(h, "dof_state"), buf<float>(h, "env_origin"), buf<float>(h, "prev"), buf<float>(h, "reset_noise"),
@@ -215,6 +216,11 @@ MMS_API int mms_set_state(mms_handle h, const char* name, const void* src, int, 
 MMS_API int mms_bind_obs_out(mms_handle h, void* dst) {
     if (!h) return fail(nullptr, "mms_bind_obs_out: null handle");
     h->obs_out = (float*)dst;
+    return 0;
+}
+MMS_API int mms_bind_actions(mms_handle h, const float* src) {
+    if (!h) return fail(nullptr, "mms_bind_actions: null handle");
+    h->actions_in = src;
     return 0;
 }
 MMS_API int mms_set_dr(mms_handle h, int32_t enable) {

@@ -41,6 +41,7 @@ struct mms_engine {
     mms_config* d_cfg = nullptr;
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
     float* obs_out = nullptr;
+    const float* actions_in = nullptr;      // mms_bind_actions
     int write_raw_obs = 1, write_clipped_obs = 1;
     int dr_enabled = 0;
     float* rew_out = nullptr;
@@ -242,7 +243,7 @@ __attribute__((visibility("default"))) int mms_get_tensor(mms_handle h, const ch
 static mms::StepArgs step_args(mms_handle h, int physics) {
     mms::StepArgs a{};
     a.cfg = h->d_cfg;
-    a.actions = (const float*)find(h, "actions")->ptr;
+    a.actions = h->actions_in ? h->actions_in : (const float*)find(h, "actions")->ptr;
     a.obs = h->write_raw_obs ? (float*)find(h, "obs")->ptr : nullptr;
     a.obs_clipped = h->write_clipped_obs ? (float*)find(h, "obs_clipped")->ptr : nullptr;
     a.obs_out = h->obs_out;
@@ -314,6 +315,13 @@ __attribute__((visibility("default"))) int mms_set_state(mms_handle h, const cha
 __attribute__((visibility("default"))) int mms_bind_obs_out(mms_handle h, void* dst) {
     if (!h) return fail(nullptr, "mms_bind_obs_out: null handle");
     h->obs_out = (float*)dst;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_bind_actions(mms_handle h, const float* src) {
+    if (!h) return fail(nullptr, "mms_bind_actions: null handle");
+    if (src && (reinterpret_cast<uintptr_t>(src) & 7) != 0) return fail(h, "mms_bind_actions: the action tensor must be 8-byte aligned");
+    h->actions_in = src;
     return 0;
 }
 

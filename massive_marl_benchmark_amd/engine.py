@@ -100,6 +100,18 @@ class Engine:
         self._bound = tensor_or_none          # keep it alive
         self._check(self._L.mms_bind_obs_out(self._h, ptr), "mms_bind_obs_out")
 
+    def bind_actions(self, tensor_or_none):
+        """The step reads `tensor` ([N, num_actions] f32 on the engine's device, contiguous) in place instead of the engine's own
+        "actions" buffer (mms_bind_actions); None returns to that buffer.  The clamp to +-clip_actions is in the kernel."""
+        if tensor_or_none is None:
+            ptr = None
+        else:
+            t = tensor_or_none
+            assert t.device.type == self.device.type and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == self.num_envs * self.num_actions
+            ptr = ctypes.c_void_p(t.data_ptr())
+        self._bound_actions = tensor_or_none  # keep it alive
+        self._check(self._L.mms_bind_actions(self._h, ptr), "mms_bind_actions")
+
     def set_obs_outputs(self, raw=True, clipped=True):
         """Which engine-owned observation rows the step writes ("obs", "obs_clipped"); a rollout that binds a slot with
         bind_obs_out needs neither while the slot is bound."""

@@ -78,8 +78,18 @@ class BaseTask:
         """base_task.py:129-149.  `actions`: [num_envs, engine action width]; clamping happens in the kernel."""
         if self.dr_randomizations.get('actions', None):
             actions = self.dr_randomizations['actions']['noise_lambda'](actions)
-        if actions.data_ptr() != self._actions.data_ptr():
-            self._actions.copy_(actions.reshape(self._actions.shape))
+        # the engine reads the caller's tensor where it lies (mms_bind_actions) when it can: fp32, contiguous, on the engine's device;
+        # anything else is copied into the engine's own "actions" buffer (the reference clones it, ten_ant.py:887)
+        a = actions
+        if (a.data_ptr() != self._actions.data_ptr() and a.dtype == torch.float32 and a.is_contiguous() and a.device == self._actions.device
+                and a.numel() == self._actions.numel() and a.data_ptr() % 8 == 0):
+            self.engine.bind_actions(a)
+            self.actions = a.view(self._actions.shape)
+        else:
+            self.engine.bind_actions(None)
+            if a.data_ptr() != self._actions.data_ptr():
+                self._actions.copy_(a.reshape(self._actions.shape))
+            self.actions = self._actions
         if self.randomize and bool(self.reset_buf.any()):
             self.apply_randomizations(self.randomization_params)          # reset_idx does this (ten_ant.py:812-813)
         self.engine.step()

@@ -245,6 +245,60 @@ def test_make_entry_glue():
 
 
 @pytest.mark.skipif(not os.path.isdir(os.environ.get("MMS_REFERENCE", "/root/reference")), reason="reference tree not present")
+def test_split_operand_layers_on_cpu_build():
+    """mms_split_planes / mms_linear_group_act_split on the CPU build (the same ABI as the HIP kernels of csrc/split_kernels.hip): the
+    three bf16 planes of a value sum back to it EXACTLY, columns past K are zero, and a layer on the planes equals torch's
+    Linear + ELU; the ActorCritic module takes the split path on the CPU build when the shapes allow and follows an in-place
+    parameter update."""
+    L = _lib.lib_cpu()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    nbytes = lambda rows, K: rows * ((K + 31) // 32) * 192
+
+    def join(planes, rows, K):
+        v = planes.view(torch.bfloat16).view(rows, (K + 31) // 32, 3, 32).float()
+        return ((v[:, :, 0] + v[:, :, 1]) + v[:, :, 2]).reshape(rows, -1)[:, :K], v
+    torch.manual_seed(3)
+    for rows, K, pitch in ((128, 388, 388), (9, 36, 40), (4, 1, 4)):
+        x = torch.randn(rows, pitch)
+        x[0, 0] = 1.0 + 2.0 ** -23
+        planes = torch.full((nbytes(rows, K),), 0xAB, dtype=torch.uint8)
+        assert L.mms_split_planes(-1, rows, K, pitch, p(x), p(planes), None) == 0
+        back, v = join(planes, rows, K)
+        assert torch.equal(back, x[:, :K])
+        assert float(v.permute(0, 1, 3, 2).reshape(rows, -1, 3)[:, K:].abs().sum()) == 0.0
+    M, N, K = 128, 256, 100
+    x = [torch.randn(M, K) for _ in range(2)]
+    w = [torch.randn(N, K) / K ** 0.5 for _ in range(2)]
+    b = [torch.randn(N) for _ in range(2)]
+    xp = [torch.empty(nbytes(M, K), dtype=torch.uint8) for _ in range(2)]
+    wp = [torch.empty(nbytes(N, K), dtype=torch.uint8) for _ in range(2)]
+    for g in range(2):
+        assert L.mms_split_planes(-1, M, K, 0, p(x[g]), p(xp[g]), None) == 0 and L.mms_split_planes(-1, N, K, 0, p(w[g]), p(wp[g]), None) == 0
+    for planes_out in (1, 0):
+        ys = [torch.empty(nbytes(M, N) if planes_out else M * N * 4, dtype=torch.uint8) for _ in range(2)]
+        assert L.mms_linear_group_act_split(-1, 2, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), 1, planes_out, None) == 0, _lib.last_error(None, L)
+        for g in range(2):
+            out = join(ys[g], M, N)[0] if planes_out else ys[g].view(torch.float32).view(M, N)
+            ref = torch.nn.functional.elu(torch.nn.functional.linear(x[g].double(), w[g].double(), b[g].double()))
+            assert float((out.double() - ref).abs().max()) < 2e-6
+    assert L.mms_linear_group_act_split(-1, 1, 100, 128, 32, arr(xp[:1]), arr(wp[:1]), arr(b[:1]), arr(ys[:1]), 1, 0, None) != 0
+    assert "multiples of 128" in _lib.last_error(None, L)
+    # the module on the CPU build
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
+    ac = ActorCritic((36,), (0,), (8,), 0.8, {"pi_hid_sizes": [128, 128], "vf_hid_sizes": [128, 128], "activation": "elu"}, seed=3)
+    obs, states = torch.randn(128, 36), torch.zeros(128, 0)
+    hidden = ac._fused_hidden(obs, obs)
+    assert hidden is not None and ac._split_bufs
+    with torch.no_grad():
+        assert float((ac.actor[:-1](obs) - hidden[0]).abs().max()) < 1e-5 and float((ac.critic[:-1](obs) - hidden[1]).abs().max()) < 1e-5
+        for q in ac.parameters():
+            q.add_(0.05 * torch.randn_like(q))                        # an in-place "optimizer step"
+        hidden = ac._fused_hidden(obs, obs)
+        assert float((ac.actor[:-1](obs) - hidden[0]).abs().max()) < 1e-5 and float((ac.critic[:-1](obs) - hidden[1]).abs().max()) < 1e-5
+        assert float((ac.value(obs) - ac.critic(obs)).abs().max()) < 1e-5 if obs.is_cuda else True
+
+
 def test_reference_learners_drop_in_unchanged(tmp_path):
     """The reference's real learners, imported in place and unmodified, over this build's VecTaskPython / MultiVecTaskPython on the
     CPU build: PPO.run (agents/algorithms/rl/ppo/ppo.py:99-175), Runner.run (agents/algorithms/marl/runner.py:114-151) as mappo, happo

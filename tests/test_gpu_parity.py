@@ -3,6 +3,7 @@
 vectors produced from the reference's own functions.  Nothing here reads /root/reference.
 
 Gates: tests/parity.py (shared with tests/test_lane_emulation.py); integer outputs are bit-exact."""
+import copy
 import ctypes
 import os
 
@@ -528,6 +529,28 @@ def test_vec_wrappers(torch_cuda):
     assert o.shape == (16, 388) and r.shape == (16,) and d.dtype == torch.int64 and info == {}
     assert float(o2.abs().max()) <= 5.0
     assert env.get_state().shape == (16, 0)
+    # the engine reads the caller's action tensor in place (mms_bind_actions; vec_task.py:126-131 copies it): same trajectory as
+    # copying into the engine's "actions" buffer, clamp to +-1 included; a non-contiguous / wrong-dtype tensor falls back to the copy
+    task2 = TenAnt(dict(cfg, env=dict(cfg["env"])), None, "physx", "cuda", 0, True)
+    env2 = VecTaskPython(task2, "cuda:0", 5.0, 1.0)
+    ref_task = TenAnt(dict(cfg, env=dict(cfg["env"])), None, "physx", "cuda", 0, True)
+    ref = ref_task.engine
+    g = torch.Generator().manual_seed(4)
+    for t in range(12):
+        a = (torch.rand(16, 80, generator=g) * 3 - 1.5).cuda()
+        if t == 5:
+            a = a.double()                                        # falls back to the copy
+        if t == 7:
+            a = a.t().contiguous().t()                            # not contiguous: copy
+        o2, r2, d2, _ = env2.step(a)
+        assert (task2.engine._bound_actions is None) == (t in (5, 7))
+        ref.tensor("actions").copy_(a.float())
+        ref.step()
+        torch.cuda.synchronize()
+        assert torch.equal(o2, ref.tensor("obs_clipped")) and torch.equal(r2, ref.tensor("rew")) and torch.equal(d2, ref.tensor("reset"))
+        assert torch.equal(task2.actions.float().reshape(16, 80), a.float())
+    ref.close()
+    task2.engine.close()
     task.engine.close()
 
 
@@ -1051,6 +1074,149 @@ def test_linear2_act_kernel(torch_cuda):
             scale = x[g].abs().double() @ w[g].abs().double().t() + b[g].abs().double()
             assert float(((y[g].double() - ref).abs() / scale).max()) < 5e-7, (M, N, K, act, g)   # fp32 products and sums, K <= 1028
     assert L.mms_linear2_act(0, 8, 8, 6, p(x[0]), p(w[0]), p(b[0]), p(y[0]), None, None, None, None, 1, stream) != 0     # K % 4
+
+
+def _p32_bytes(rows, K):
+    return rows * ((K + 31) // 32) * 192
+
+
+def _planes_to_f32(torch, planes, rows, K):
+    """P32 planes (include/mms.h) -> [rows, K] float32: the three planes of an element sum to it exactly"""
+    KC = (K + 31) // 32
+    v = planes.view(torch.bfloat16).view(rows, KC, 3, 32).float()
+    return ((v[:, :, 0] + v[:, :, 1]) + v[:, :, 2]).reshape(rows, KC * 32)[:, :K], v
+
+
+def test_split_planes_exact(torch_cuda):
+    """mms_split_planes: every fp32 value is EXACTLY the sum of its three bf16 planes (so the split layers multiply the fp32 operands
+    themselves, not roundings of them), columns past K are zero, row pitches other than K are honoured; extremes included."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    L = _lib.lib()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(2)
+    for (rows, K, pitch) in ((4096, 388, 388), (1024, 1024, 1024), (7, 36, 40), (3, 1, 4), (5, 1028, 1028), (130, 64, 64)):
+        x = torch.randn(rows, pitch, device="cuda")
+        x[0, :min(K, 8)] = torch.tensor([0.0, -0.0, 1e-30, -3e38, 1.0 + 2 ** -23, 2 ** -126, 65504.0, -1e-20], device="cuda")[:min(K, 8)]
+        planes = torch.full((_p32_bytes(rows, K),), 0xAB, dtype=torch.uint8, device="cuda")
+        _lib.check(L.mms_split_planes(0, rows, K, pitch, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(planes.data_ptr()), stream), None, "split")
+        back, v = _planes_to_f32(torch, planes, rows, K)
+        assert torch.equal(back, x[:, :K]), (rows, K, pitch)
+        KC = (K + 31) // 32
+        if KC * 32 > K:
+            assert float(v.permute(0, 1, 3, 2).reshape(rows, KC * 32, 3)[:, K:].abs().max()) == 0.0
+    x = torch.randn(8, 8, device="cuda")
+    planes = torch.empty(_p32_bytes(8, 8), dtype=torch.uint8, device="cuda")
+    assert L.mms_split_planes(0, 8, 8, 4, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(planes.data_ptr()), stream) != 0      # pitch < K
+    assert L.mms_split_planes(0, 8, 8, 8, None, ctypes.c_void_p(planes.data_ptr()), stream) != 0
+
+
+def test_split_layers_error(torch_cuda):
+    """mms_linear_group_act_split (fp32 operands as three bf16 planes, six bf16 MFMA products, fp32 accumulation) against the float64
+    product, NEXT TO the exact-fp32 MFMA kernel (mms_linear2_act) on the same inputs: the split kernel's error must not be larger --
+    that is what makes it the same fp32 arithmetic on a faster pipe and not a narrower precision.  Gates: every element within the
+    fp32 kernel's own per-element bound (5e-7 of sum |x||w| + |b|, test_linear2_act_kernel), rms error <= 1.02 x the fp32 kernel's
+    rms error on every shape (measured 0.83-0.85 x), worst error <= 1.25 x its worst error.  Shapes: the PPO policy's three hidden
+    layers at 4096 rows (both tilings: 256 x 128 and 128 x 128 blocks), one and two networks, all four epilogues, planes-out and
+    fp32-out; the P32 output of one launch is the input of the next."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    L = _lib.lib()
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(5)
+    acts = {0: lambda v: v, 1: torch.nn.functional.elu, 2: torch.relu, 3: torch.tanh}
+    margins = {}
+    for (M, N, K, act, G, planes_out) in ((4096, 1024, 388, 1, 2, 1), (4096, 1024, 1024, 1, 2, 1), (4096, 512, 1024, 1, 2, 0),
+                                          (4096, 1024, 1024, 1, 1, 0), (128, 128, 32, 0, 1, 1), (256, 384, 100, 2, 2, 1),
+                                          (384, 128, 1028, 3, 3, 0), (8192, 256, 256, 2, 1, 1)):
+        x = [torch.randn(M, K, device="cuda") for _ in range(G)]
+        x = [torch.where(t > 0, t, torch.expm1(t)).contiguous() for t in x]                      # ELU-shaped activations
+        w = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(G)]
+        b = [torch.randn(N, device="cuda") * 0.1 for _ in range(G)]
+        xp = [torch.empty(_p32_bytes(M, K), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        wp = [torch.empty(_p32_bytes(N, K), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        for g in range(G):
+            _lib.check(L.mms_split_planes(0, M, K, 0, p(x[g]), p(xp[g]), stream), None, "split x")
+            _lib.check(L.mms_split_planes(0, N, K, 0, p(w[g]), p(wp[g]), stream), None, "split w")
+        ys = [torch.full((_p32_bytes(M, N) if planes_out else M * N * 4,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(G)]
+        rc = L.mms_linear_group_act_split(0, G, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), act, planes_out, stream)
+        assert rc == 0, _lib.last_error(None)
+        y32 = [torch.empty(M, N, device="cuda") for _ in range(G)]
+        for g in range(G):
+            assert L.mms_linear2_act(0, M, N, (K + 3) // 4 * 4, p(torch.nn.functional.pad(x[g], (0, (-K) % 4))), p(torch.nn.functional.pad(w[g], (0, (-K) % 4))),
+                                     p(b[g]), p(y32[g]), None, None, None, None, act, stream) == 0
+        torch.cuda.synchronize()
+        e_split, e_f32 = [], []
+        for g in range(G):
+            out = _planes_to_f32(torch, ys[g], M, N)[0] if planes_out else ys[g].view(torch.float32).view(M, N)
+            ref = acts[act](torch.nn.functional.linear(x[g].double(), w[g].double(), b[g].double()))
+            scale = x[g].abs().double() @ w[g].abs().double().t() + b[g].abs().double()
+            assert float(((out.double() - ref).abs() / scale).max()) < 5e-7, (M, N, K, act, g)
+            e_split.append(out.double() - ref)
+            e_f32.append(y32[g].double() - ref)
+        es, ef = torch.cat(e_split), torch.cat(e_f32)
+        rms_ratio = float(es.pow(2).mean().sqrt() / ef.pow(2).mean().sqrt())
+        max_ratio = float(es.abs().max() / ef.abs().max())
+        margins["%dx%dx%d" % (M, N, K)] = {"rms_ratio": rms_ratio, "max_ratio": max_ratio}
+        if K >= 100:                                                 # (tiny K: both errors are a few ulps of single roundings)
+            assert rms_ratio <= 1.02 and max_ratio <= 1.25, (M, N, K, rms_ratio, max_ratio)
+        if planes_out and N % 128 == 0 and act == 1:                 # chained: this layer's planes feed the next split layer unchanged
+            w2 = [torch.randn(128, N, device="cuda") / N ** 0.5 for _ in range(G)]
+            w2p = [torch.empty(_p32_bytes(128, N), dtype=torch.uint8, device="cuda") for _ in range(G)]
+            for g in range(G):
+                _lib.check(L.mms_split_planes(0, 128, N, 0, p(w2[g]), p(w2p[g]), stream), None, "split w2")
+            y2 = [torch.empty(M, 128, device="cuda") for _ in range(G)]
+            b2 = [torch.zeros(128, device="cuda") for _ in range(G)]
+            assert L.mms_linear_group_act_split(0, G, M, 128, N, arr(ys), arr(w2p), arr(b2), arr(y2), 0, 0, stream) == 0
+            torch.cuda.synchronize()
+            for g in range(G):
+                h = _planes_to_f32(torch, ys[g], M, N)[0]
+                ref2 = h.double() @ w2[g].double().t()
+                assert float((y2[g].double() - ref2).abs().max() / ref2.abs().max()) < 2e-6
+    parity.record("gpu/split_layers_vs_fp32_mfma", **margins)
+    # argument checks: M, N multiples of 128; groups in range; null pointers
+    z = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    zb = torch.zeros(256, device="cuda")
+    one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+    assert L.mms_linear_group_act_split(0, 1, 100, 128, 32, one(z), one(z), one(zb), one(z), 1, 0, stream) != 0
+    assert L.mms_linear_group_act_split(0, 1, 128, 100, 32, one(z), one(z), one(zb), one(z), 1, 0, stream) != 0
+    assert L.mms_linear_group_act_split(0, 0, 128, 128, 32, one(z), one(z), one(zb), one(z), 1, 0, stream) != 0
+    assert L.mms_linear_group_act_split(0, 1, 128, 128, 32, one(z), (ctypes.c_void_p * 1)(None), one(zb), one(z), 1, 0, stream) != 0
+    assert "null pointer" in _lib.last_error(None)
+
+
+def test_actor_critic_split_layers(torch_cuda):
+    """ActorCritic.act / .value with the hidden layers on the split path (batch and hidden widths multiples of 128) against the torch
+    modules and against the exact-fp32 kernel path; an in-place optimizer step is picked up (the weight planes are re-split when the
+    parameter's version moves)."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
+    torch.manual_seed(0)
+    n = 256
+    ac = ActorCritic((388,), (0,), (80,), 0.8, {"pi_hid_sizes": [256, 128, 128], "vf_hid_sizes": [256, 128, 128], "activation": "elu"}, seed=3).cuda()
+    obs = torch.randn(n, 388, device="cuda").clamp(-5, 5)
+    states = torch.zeros(n, 0, device="cuda")
+    assert ac.split_layers and ac._split_applies(n, [m for m in ac.actor if isinstance(m, torch.nn.Linear)][:-1])
+    for trial in range(2):
+        _, _, v_s, mu_s, _ = ac.act(obs, states)
+        val_s = ac.value(obs)
+        assert ac._split_bufs, "the split path did not run"
+        ac.split_layers = False
+        _, _, v_f, mu_f, _ = ac.act(obs, states)
+        ac.split_layers = True
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            mu_t, v_t = ac.actor(obs), ac.critic(obs)
+            mu_d, v_d = copy.deepcopy(ac.actor).double()(obs.double()), copy.deepcopy(ac.critic).double()(obs.double())
+        assert float((mu_s - mu_t).abs().max()) < 1e-5 and float((v_s - v_t).abs().max()) < 1e-5 and float((val_s - v_t).abs().max()) < 1e-5
+        # against float64: not worse than the exact-fp32 kernel path
+        assert float((mu_s.double() - mu_d).abs().max()) <= 1.5 * float((mu_f.double() - mu_d).abs().max()) + 1e-7
+        assert float((v_s.double() - v_d).abs().max()) <= 1.5 * float((v_f.double() - v_d).abs().max()) + 1e-7
+        with torch.no_grad():                                        # "optimizer step": in place, the version counters move
+            for q in ac.parameters():
+                q.add_(0.01 * torch.randn_like(q))
 
 
 def test_fused_act_and_bound_rollout(torch_cuda):
