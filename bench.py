@@ -114,7 +114,9 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (the engine has no CPU path)")
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK / MASTER_ADDR in the environment) the process group is initialised at ANY world size, 1 included:
+    # the RCCL init, barrier and all_reduce(MAX) path of the multi-GPU runs is then the one a single-GPU box can rehearse
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ and "TORCHELASTIC_RUN_ID" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # MMS_BENCH_BACKEND=gloo is a rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
@@ -409,7 +411,8 @@ def main():
                        "friction": {"rule": "average" if abs(eng.config.model.boxgnd_mu) > 0 else "min", "gnd_mu": eng.config.model.gnd_mu,
                                     "boxgnd_mu": eng.config.model.boxgnd_mu, "antbox_mu": eng.config.model.antbox_mu,
                                     "note": "this build's modelling choice (PhysX default combine rule), not reference-pinned: DESIGN.md section 4"},
-                       "critic_deferred": bool(args.defer_critic), "finite": finite, "resets_total": resets_seen},
+                       "critic_deferred": bool(args.defer_critic), "finite": finite, "resets_total": resets_seen,
+                       "distributed": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size()}},
             "sim_only": {"value": sim_value, "unit": "env-steps/s", "steps": sim_steps, "ms_per_step": 1e3 * sim_wall / sim_steps,
                          "value_mean": world * N * sim_steps / sim_wall_mean, "ms_per_step_mean": 1e3 * sim_wall_mean / sim_steps,
                          "note": "engine step with pre-drawn actions (ring of 16); four equal batches: `value` from the median batch, "

@@ -19,8 +19,10 @@ step for TenAnt.  The networks are independent and of the same shape, so here ev
 
 `GroupedPolicyInference` takes the agents' Actor / Critic modules AS THEY ARE (the reference's classes, or anything with the same
 attributes: `.base.feature_norm`, `.base.mlp.fc1`, `.base.mlp.fc2`, `.act.action_out.{fc_mean, log_std, std_x_coef, std_y_coef}`,
-`.v_out`; any number of agents: more than sixteen run as chunks of sixteen) and reads their parameters in place: an optimizer step needs no copy back, only `refresh()` for the zero-padded copy of
-the actors' first weight matrix (46 -> 48 columns).  Recurrent policies (use_recurrent_policy / use_naive_recurrent_policy) and
+`.v_out`; any number of agents: more than sixteen run as chunks of sixteen).  Biases, LayerNorm affines and head weights are read in
+place; DERIVED copies exist of the zero-padded first actor weights (46 -> 48 columns), the folded weights `W diag(gamma)` with their
+`s` / `c` vectors, and the action standard deviations -- `refresh()` rebuilds them, and every inference call checks the parameters'
+version counters (an in-place optimizer step moves them) and refreshes by itself when they have changed, so a stale network is never run.  Recurrent policies (use_recurrent_policy / use_naive_recurrent_policy) and
 non-Box action spaces are not covered: the constructor raises, nothing falls back silently.
 
 The noise stream is this build's counter-based generator (seed + agent, global env row, per-row draw counter), as in
@@ -137,6 +139,7 @@ class GroupedPolicyInference:
             return
         dev, n = self.device, self.n
         d = lambda t: t.detach()
+        self._versions = self._param_versions()
         self.kp_a = (self.obs_dim + 3) & ~3
         self.kp_c = (self.sobs_dim + 3) & ~3
 
@@ -172,6 +175,17 @@ class GroupedPolicyInference:
             Wt = (W * gam[:, None, :]).contiguous()
             self._fold_c1 = (Wt, Wt.sum(-1).contiguous(), (torch.einsum("gnk,gk->gn", W, bet) + bias).contiguous())
         self._bind()
+
+    def _param_versions(self):
+        """(data_ptr, version) of every source parameter: what the derived copies of refresh() were built from"""
+        return tuple((q.data_ptr(), q._version) for m in self.actors + self.critics for q in m.parameters())
+
+    def _ensure_fresh(self):
+        if self._chunks is not None:
+            for c in self._chunks:
+                c._ensure_fresh()
+        elif self._versions != self._param_versions():
+            self.refresh()
 
     def _bind(self):
         d = lambda t: t.detach()
@@ -220,7 +234,13 @@ class GroupedPolicyInference:
         self.x_a, self.x_c = z(n, M, self.kp_a), z(n, M, self.kp_c)                    # normalised (and padded) inputs
         self.h = [z(2 * n, M, H), z(2 * n, M, H)]                                     # hidden activations, ping-pong
         self.actions, self.logp, self.values = z(n, M, self.act_dim), z(n, M, self.act_dim), z(n, M, 1)
-        self.counters = torch.zeros(n, M, dtype=torch.int64, device=dev)
+        # draw counters of the noise stream (seed + agent, row, counter): one tensor per batch size, kept across re-allocations of the
+        # other buffers, so that alternating batch sizes (training at M, evaluation at M', back to M) never replays noise already used
+        if not hasattr(self, "_counters_by_M"):
+            self._counters_by_M = {}
+        if M not in self._counters_by_M:
+            self._counters_by_M[M] = torch.zeros(n, M, dtype=torch.int64, device=dev)
+        self.counters = self._counters_by_M[M]
         self.part, self.stat = z(2 * n, max(1, H // 64), M, 2), z(2 * n, M, 2)        # row statistics of the folded LayerNorms
         self.stat_c = z(n, M, 2)                                                       # ... of the critics' feature LayerNorm
         ub = lambda t: list(t.unbind(0))
@@ -248,6 +268,7 @@ class GroupedPolicyInference:
         n = self.n
         if len(share_obs) != n or len(obs) != n:
             raise ValueError("one observation tensor per agent")
+        self._ensure_fresh()
         if self._chunks is not None:
             res = ([], [], [])
             for c, (lo, hi) in zip(self._chunks, self._ranges):
@@ -263,12 +284,13 @@ class GroupedPolicyInference:
         p, q = self.p, self.q
         chk = lambda rc, what: _lib.check(rc, None, what, L)
         f32 = lambda t: t.detach() if t.dtype == torch.float32 else t.detach().float()
-        obs_p, obs_pitch = _row_ptrs([f32(t) for t in obs])
-        sobs_p, sobs_pitch = _row_ptrs([f32(t) for t in share_obs])
+        obs_f, sobs_f = [f32(t) for t in obs], [f32(t) for t in share_obs]     # (held until the launches below have been issued)
+        obs_p, obs_pitch = _row_ptrs(obs_f)
+        sobs_p, sobs_pitch = _row_ptrs(sobs_f)
         chk(L.mms_layernorm_group(idx, n, M, self.obs_dim, self.kp_a, obs_pitch, obs_p, p["fn_a_g"], p["fn_a_b"], q["x_a"], self.eps, stream), "mms_layernorm_group")
         H = self.hidden
-        fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0
-        fold_c1 = fold and self._fold_c1 is not None and sobs_pitch == self.sobs_dim
+        fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0 and self.kp_a >= 8
+        fold_c1 = fold and self._fold_c1 is not None and sobs_pitch == self.sobs_dim and self.sobs_dim >= 8
         if not fold_c1:
             chk(L.mms_layernorm_group(idx, n, M, self.sobs_dim, self.kp_c, sobs_pitch, sobs_p, p["fn_c_g"], p["fn_c_b"], q["x_c"], self.eps, stream), "mms_layernorm_group")
         slots = H // 64
@@ -353,6 +375,7 @@ class GroupedPolicyInference:
         n = self.n
         if len(share_obs) != n:
             raise ValueError("one observation tensor per agent")
+        self._ensure_fresh()
         if self._chunks is not None:
             res = []
             for c, (lo, hi) in zip(self._chunks, self._ranges):
@@ -364,10 +387,11 @@ class GroupedPolicyInference:
         p, q = self.p, self.q
         chk = lambda rc, what: _lib.check(rc, None, what, L)
         f32 = lambda t: t.detach() if t.dtype == torch.float32 else t.detach().float()
-        sobs_p, sobs_pitch = _row_ptrs([f32(t) for t in share_obs])
+        sobs_f = [f32(t) for t in share_obs]                                  # (held until the launches below have been issued)
+        sobs_p, sobs_pitch = _row_ptrs(sobs_f)
         H = self.hidden
         fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0
-        fold_c1 = fold and self._fold_c1 is not None and sobs_pitch == self.sobs_dim
+        fold_c1 = fold and self._fold_c1 is not None and sobs_pitch == self.sobs_dim and self.sobs_dim >= 8
         slots = H // 64
         if fold_c1:
             shared_rows = len({int(v) for v in sobs_p}) == 1

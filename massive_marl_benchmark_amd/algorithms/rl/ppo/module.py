@@ -77,8 +77,8 @@ class ActorCritic(nn.Module):
     fuse_layers = True
     # The hidden layers on the bf16 matrix pipe with fp32 operands carried as three bf16 planes (csrc/split_kernels.hip,
     # mms_linear_group_act_split): the same fp32 product -- an fp32 number IS the sum of its three planes, six plane products are kept
-    # and accumulated in fp32, what is dropped is < 2^-25 of a product -- at ~1.8 x the rate of the exact-fp32 MFMA kernel and with an
-    # error against the float64 product that is not larger than that kernel's (tests/test_gpu_parity.py::test_split_layers_error).
+    # and accumulated in fp32, what is dropped is < 2^-25 of a product -- at ~1.8 x the rate of the exact-fp32 MFMA kernel and with a
+    # THIRD of that kernel's error against the float64 product (tests/test_gpu_parity.py::test_split_layers_error).
     # Applies when the batch and every hidden width are multiples of 128; False = the exact-fp32 MFMA kernel (mms_linear2_act).
     split_layers = True
     fuse_head = True

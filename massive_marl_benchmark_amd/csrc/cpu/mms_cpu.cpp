@@ -87,6 +87,7 @@ MMS_API int mms_create(const mms_config* cfg, mms_handle* out) {
     if (cfg->num_envs <= 0 || cfg->num_agents <= 0) return fail(nullptr, "mms_create: num_envs and num_agents must be positive");
     if (cfg->task == MMS_TASK_MULTI_INGENUITY && cfg->num_agents != 4) return fail(nullptr, "mms_create: MultiIngenuity has 4 helicopters per env");
     if (cfg->task == MMS_TASK_ONE_ANT && cfg->num_agents != 1) return fail(nullptr, "mms_create: OneAnt has one ant per env");
+    if (cfg->task != MMS_TASK_MULTI_INGENUITY && cfg->num_agents > 126) return fail(nullptr, "mms_create: at most 126 ants per env");
     mms_engine* e = new mms_engine();
     e->cfg = *cfg;
     const int N = cfg->num_envs, A = cfg->num_agents;
@@ -206,10 +207,11 @@ MMS_API int mms_set_state(mms_handle h, const char* name, const void* src, int, 
     mms_buffer* b = find(h, name);
     if (!b) return fail(h, std::string("mms_set_state: unknown buffer '") + name + "'");
     if (!env_ids) { memcpy(b->ptr, src, b->bytes); return 0; }
-    for (int64_t i = 0; i < n; i++) {
+    if (b->row_bytes <= 0) return fail(h, "mms_set_state: buffer is not per-env");
+    if (n < 0) return fail(h, "mms_set_state: negative row count");
+    for (int64_t i = 0; i < n; i++)                          // all ids are checked before anything is written
         if (env_ids[i] < 0 || env_ids[i] >= h->cfg.num_envs) return fail(h, "mms_set_state: env id out of range");
-        memcpy((char*)b->ptr + env_ids[i] * b->row_bytes, (const char*)src + i * b->row_bytes, (size_t)b->row_bytes);
-    }
+    for (int64_t i = 0; i < n; i++) memcpy((char*)b->ptr + env_ids[i] * b->row_bytes, (const char*)src + i * b->row_bytes, (size_t)b->row_bytes);
     return 0;
 }
 

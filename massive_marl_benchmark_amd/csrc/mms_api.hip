@@ -42,6 +42,8 @@ struct mms_engine {
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
     float* obs_out = nullptr;
     const float* actions_in = nullptr;      // mms_bind_actions
+    void* scratch = nullptr;                // staging of mms_set_state(env_ids)
+    size_t scratch_bytes = 0;
     int write_raw_obs = 1, write_clipped_obs = 1;
     int dr_enabled = 0;
     float* rew_out = nullptr;
@@ -100,6 +102,15 @@ static int add_buffer(mms_engine* e, const char* name, int dtype, std::initializ
     MMS_HIP(e, hipMemset(b.ptr, 0, alloc));
     e->bufs.push_back(b);
     return 0;
+}
+
+// rows of a per-env buffer scattered to their env slots in one launch (mms_set_state with env ids): block = row, 4-byte words
+__global__ void __launch_bounds__(256) scatter_rows_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, const int64_t* __restrict__ ids,
+                                                           int64_t row_words) {
+    const int64_t i = blockIdx.x;
+    uint32_t* d = dst + ids[i] * row_words;
+    const uint32_t* s = src + i * row_words;
+    for (int64_t k = threadIdx.x; k < row_words; k += 256) d[k] = s[k];
 }
 
 extern "C" {
@@ -223,6 +234,7 @@ __attribute__((visibility("default"))) int mms_destroy(mms_handle h) {
     for (auto& b : h->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
     if (h->d_cfg) (void)hipFree(h->d_cfg);
+    if (h->scratch) (void)hipFree(h->scratch);
     delete h;
     return 0;
 }
@@ -303,9 +315,33 @@ __attribute__((visibility("default"))) int mms_set_state(mms_handle h, const cha
         MMS_HIP(h, hipMemcpyAsync(b->ptr, src, b->bytes, kind, s));
     } else {
         if (b->row_bytes <= 0) return fail(h, "mms_set_state: buffer is not per-env");
-        for (int64_t i = 0; i < n; i++) {
+        if (n < 0) return fail(h, "mms_set_state: negative row count");
+        for (int64_t i = 0; i < n; i++)                      // all ids are checked before anything is written
             if (env_ids[i] < 0 || env_ids[i] >= h->cfg.num_envs) return fail(h, "mms_set_state: env id out of range");
-            MMS_HIP(h, hipMemcpyAsync((char*)b->ptr + env_ids[i] * b->row_bytes, (const char*)src + i * b->row_bytes, (size_t)b->row_bytes, kind, s));
+        if (n <= 16 || (b->row_bytes & 3) != 0) {
+            for (int64_t i = 0; i < n; i++)
+                MMS_HIP(h, hipMemcpyAsync((char*)b->ptr + env_ids[i] * b->row_bytes, (const char*)src + i * b->row_bytes, (size_t)b->row_bytes, kind, s));
+        } else {
+            // the indexed setter of the reference (gym.set_*_tensor_indexed, ten_ant.py:867-875) takes thousands of ids: one scatter
+            // launch instead of one copy per env.  Staging (ids, and the rows when they come from the host) lives in engine scratch.
+            const size_t id_bytes = (size_t)n * 8, row_total = (size_t)n * (size_t)b->row_bytes;
+            const size_t need = id_bytes + (src_is_host ? row_total : 0);
+            if (need > h->scratch_bytes) {
+                if (h->scratch) MMS_HIP(h, hipFree(h->scratch));
+                h->scratch = nullptr; h->scratch_bytes = 0;
+                MMS_HIP(h, hipMalloc(&h->scratch, need));
+                h->scratch_bytes = need;
+            }
+            MMS_HIP(h, hipMemcpyAsync(h->scratch, env_ids, id_bytes, hipMemcpyHostToDevice, s));
+            const void* rows = src;
+            if (src_is_host) {
+                MMS_HIP(h, hipMemcpyAsync((char*)h->scratch + id_bytes, src, row_total, hipMemcpyHostToDevice, s));
+                rows = (char*)h->scratch + id_bytes;
+            }
+            hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, (uint32_t*)b->ptr, (const uint32_t*)rows,
+                               (const int64_t*)h->scratch, b->row_bytes / 4);
+            MMS_HIP(h, hipGetLastError());
+            MMS_HIP(h, hipStreamSynchronize(s));                 // env_ids is the caller's host array; the scratch is reused by the next call
         }
     }
     if (src_is_host) MMS_HIP(h, hipStreamSynchronize(s));

@@ -5,10 +5,10 @@
 // (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1): 3 x 8 significant bits and a sign each), so
 //     a b = a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0) + [a1 b2 + a2 b1 + a2 b2 <= 2^-25 |a b|, dropped]
 // is six v_mfma_f32_16x16x32_bf16 products accumulated in fp32: 16 / 6 of the fp32 MFMA rate, and FEWER roundings per output
-// than the fp32 MFMA's k-ordered fma chain (6 per 32 k instead of 32).  Measured against the float64 product
-// (tools/microbench/split_bf16.hip, profiles/r03_split_bf16_microbench.txt; tests/test_gpu_parity.py): rms error 0.83-0.85 x and
-// worst error 0.7-0.8 x the exact-fp32 MFMA kernel's on the same inputs.  This is not narrower arithmetic; it is the same fp32
-// product evaluated on the bf16 pipe.
+// than the fp32 MFMA's k-ordered fma chain (the leading accumulator rounds once per 32 k instead of 32 times).  Measured against
+// the float64 product (tools/microbench/split_bf16.hip, profiles/r03_split_bf16_microbench.txt; tests/test_gpu_parity.py
+// ::test_split_layers_error): rms error 0.32 x and worst error 0.35-0.42 x the exact-fp32 MFMA kernel's on the same inputs, no
+// mean error.  This is not narrower arithmetic; it is the same fp32 product evaluated on the bf16 pipe.
 //
 // Plane format "P32" (how split operands live in HBM): [rows][KC][3][32] bf16, KC = ceil(K / 32): the three planes of 32
 // consecutive k of a row are 192 contiguous bytes, so the slice a block stages per k-step is one contiguous run per row.
@@ -154,8 +154,21 @@ __global__ void __launch_bounds__(512, 2) linear_split_kernel(SplitLinearArgs a)
     const int xfrag = (wm * 16 * MT) * kChunkBytes + frag;               // + plane * 64 + mt * 16 * 192
     const int wfrag = G::XBYTES + (wn * 64) * kChunkBytes + frag;        // + plane * 64 + nt * 16 * 192
 
-    auto compute = [&](int buf) {
+    // Two accumulators per output: `acc` takes the leading products a0 b0, `lo` the five small ones (<= 2^-8 of the leading term), and
+    // they are added once at the end.  The small products then meet an accumulator of their own size instead of being aligned to
+    // (and truncated against) the large one at every step: error against float64 0.32 x the exact-fp32 MFMA chain's (a single
+    // accumulator: 0.85 x, with a mean error of -5e-8 rms(Y) that this removes); no extra MFMAs, 64 more registers.
+    constexpr bool kDmaBehindFirstTile = MT == 4;    // measured: 256 x 128 tiles 80.5 -> 78.5 us (K = 1024), 128 x 128 tiles 43.3 -> 46.6 us
+    f32x4 lo[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // one k-step: W fragments of the wave's four n-tiles (kept for the step), then per m-tile its three X planes and 24 MFMAs;
+    // the DMA of the next slice is issued behind the first m-tile's MFMAs (kDmaBehindFirstTile) or in front of everything
+    auto step = [&](int buf, bool more, int kc_next) {
         const uint8_t* base = lds + buf * G::BUF;
+        if (!kDmaBehindFirstTile && more) dma_slice(kc_next, buf ^ 1);
         bf16x8 wf[4][3];
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
@@ -167,20 +180,28 @@ __global__ void __launch_bounds__(512, 2) linear_split_kernel(SplitLinearArgs a)
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) xf[pl] = *reinterpret_cast<const bf16x8*>(base + xfrag + pl * 64 + mt * 16 * kChunkBytes);
             // small terms first; product-major so that consecutive MFMAs go to different accumulators
-#define MMS_P(PW, PX)                                                                                                          \
+#define MMS_P(PW, PX, ACC)                                                                                                     \
     _Pragma("unroll") for (int nt = 0; nt < 4; nt++)                                                                            \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][PW], xf[PX], acc[mt][nt], 0, 0, 0);
-            MMS_P(2, 0) MMS_P(0, 2) MMS_P(1, 1) MMS_P(1, 0) MMS_P(0, 1) MMS_P(0, 0)
+        ACC[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][PW], xf[PX], ACC[mt][nt], 0, 0, 0);
+            MMS_P(2, 0, lo) MMS_P(0, 2, lo) MMS_P(1, 1, lo) MMS_P(1, 0, lo) MMS_P(0, 1, lo) MMS_P(0, 0, acc)
 #undef MMS_P
+            if (kDmaBehindFirstTile && mt == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) dma_slice(kc_next, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
     dma_slice(0, 0);
     for (int kt = 0; kt < KC; kt++) {
         __syncthreads();                                                // slice kt has landed (vmcnt(0) + barrier); everyone is done with slice kt - 1
-        if (kt + 1 < KC) dma_slice(kt + 1, (kt + 1) & 1);
-        compute(kt & 1);
+        step(kt & 1, kt + 1 < KC, kt + 1);
     }
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] += lo[i][j];
     __syncthreads();                                                    // the operand buffers become the waves' epilogue scratch
 
     // epilogue: lane holds, for tile (mt, nt), rows n = nbase + 16 nt + 4 g4 + reg (reg = 0..3) of column m = mbase + 16 mt + r16

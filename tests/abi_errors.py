@@ -1,0 +1,114 @@
+"""Error paths of the engine ABI (include/mms.h: every entry point returns 0 on success and non-zero on failure, with the reason in
+mms_last_error) -- one check list for both builds: tests/test_cpu_backend.py runs it on libmms_cpu.so, tests/test_gpu_parity.py on
+libmms.so.  Each failing call must return non-zero AND leave a non-empty message; nothing may be written by a call that fails."""
+import ctypes
+
+import numpy as np
+
+from massive_marl_benchmark_amd import _lib
+from massive_marl_benchmark_amd.model import MmsConfig, MmsTensor, make_config
+
+
+def check_abi_error_paths(L, device):
+    """L: the bound library, device: its device argument (-1 for the CPU build, a HIP ordinal for the HIP build)."""
+    vp = ctypes.c_void_p
+    n_checked = [0]
+
+    def fails(rc, handle=None, contains=None):
+        msg = _lib.last_error(handle, L)
+        assert rc != 0 and msg, (rc, msg)
+        if contains:
+            assert contains in msg, (contains, msg)
+        n_checked[0] += 1
+
+    def cfg(task="TenAnt", **kw):
+        return make_config(task, None, num_envs=8, device=device, **kw)
+
+    # ---- mms_create ----
+    h = vp()
+    fails(L.mms_create(None, ctypes.byref(h)), contains="null")
+    fails(L.mms_create(ctypes.byref(cfg()), None), contains="null")
+    c = cfg(); c.abi_version += 1
+    fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="ABI")
+    c = cfg(); c.task = 99
+    fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="task")
+    c = cfg(); c.num_envs = 0
+    fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="positive")
+    c = cfg(); c.num_agents = 0
+    fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="positive")
+    c = cfg(); c.num_agents = 127                                   # at most 126 ants per env (512-lane block)
+    fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="126")
+    c = cfg("MultiIngenuity"); c.num_agents = 3
+    fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="4 helicopters")
+    c = cfg("OneAnt"); c.num_agents = 2
+    fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="one ant")
+    c = cfg(); c.device = 0 if device < 0 else -1                    # the other library's device
+    fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)))
+    if device >= 0:
+        c = cfg(); c.device = 4096
+        fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="out of range")
+    assert not h.value, "a failed mms_create must not hand out a handle"
+
+    # ---- null handles ----
+    t = MmsTensor()
+    fails(L.mms_get_tensor(None, b"obs", ctypes.byref(t)))
+    for fn, args in ((L.mms_step, (None,)), (L.mms_post_step, (None,)), (L.mms_reset_all, (None,)), (L.mms_bind_obs_out, (None,)),
+                     (L.mms_bind_actions, (None,)), (L.mms_set_dr, (1,)), (L.mms_set_obs_outputs, (1, 1)), (L.mms_bind_rollout_out, (None, None))):
+        fails(fn(None, *args), contains="null handle")
+    fails(L.mms_set_state(None, b"obs", None, 1, None, 0, None))
+    assert L.mms_destroy(None) == 0                                  # documented no-op
+
+    # ---- a live engine ----
+    h = vp()
+    assert L.mms_create(ctypes.byref(cfg()), ctypes.byref(h)) == 0, _lib.last_error(None, L)
+    try:
+        fails(L.mms_get_tensor(h, b"no_such_buffer", ctypes.byref(t)), h, "no_such_buffer")
+        fails(L.mms_get_tensor(h, None, ctypes.byref(t)), h, "null")
+        fails(L.mms_get_tensor(h, b"obs", None), h, "null")
+        assert L.mms_get_tensor(h, b"progress", ctypes.byref(t)) == 0 and t.ndim == 1 and t.shape[0] == 8
+        rows = np.full((3, 1), 7, np.int64)
+        src = rows.ctypes.data_as(vp)
+        fails(L.mms_set_state(h, b"no_such_buffer", src, 1, None, 0, None), h, "no_such_buffer")
+        fails(L.mms_set_state(h, b"progress", None, 1, None, 0, None), h, "null")
+        ids = (ctypes.c_int64 * 3)(1, 8, 2)                          # 8 is out of range; row 1 must NOT have been written
+        fails(L.mms_set_state(h, b"progress", src, 1, ids, 3, None), h, "out of range")
+        ids = (ctypes.c_int64 * 3)(1, -1, 2)
+        fails(L.mms_set_state(h, b"progress", src, 1, ids, 3, None), h, "out of range")
+        back = np.zeros(8, np.int64)
+        if device < 0:
+            ctypes.memmove(back.ctypes.data, t.ptr, 64)
+        else:
+            import torch
+            from massive_marl_benchmark_amd.engine import _DevicePtr
+            back = torch.as_tensor(_DevicePtr(t.ptr, [8], "<i8", None), device="cuda:%d" % device).cpu().numpy()
+        assert (back != 7).all(), "a failed mms_set_state wrote rows"
+        ids = (ctypes.c_int64 * 3)(1, 5, 2)
+        assert L.mms_set_state(h, b"progress", src, 1, ids, 3, None) == 0
+        fails(L.mms_set_state(h, b"progress", src, 1, (ctypes.c_int64 * 3)(0, 1, 2), -1, None), h, "negative")
+    finally:
+        assert L.mms_destroy(h) == 0
+    c = cfg("MultiIngenuity")
+    h = vp()
+    assert L.mms_create(ctypes.byref(c), ctypes.byref(h)) == 0
+    fails(L.mms_set_dr(h, 1), h, "helicopter")
+    assert L.mms_destroy(h) == 0
+
+    # ---- the policy / rollout operators (no handle: the message is mms_last_error(NULL)) ----
+    z = (ctypes.c_float * 64)()
+    zp = ctypes.cast(z, vp)
+    one = (vp * 1)(zp)
+    fails(L.mms_linear2_act(device, 8, 8, 6, zp, zp, zp, zp, None, None, None, None, 1, None), contains="multiple of 4")
+    fails(L.mms_linear2_act(device, 8, 8, 8, zp, zp, zp, zp, zp, None, None, None, 1, None), contains="second problem")
+    fails(L.mms_linear2_act(device, 8, 8, 8, zp, zp, zp, zp, None, None, None, None, 9, None), contains="act")
+    fails(L.mms_linear_group_act(device, 0, 8, 8, 8, one, one, one, one, 1, None, None, None, None), contains="groups")
+    fails(L.mms_linear_group_act(device, 33, 8, 8, 8, one, one, one, one, 1, None, None, None, None), contains="groups")
+    fails(L.mms_linear_group_act(device, 1, 8, 8, 8, one, (vp * 1)(None), one, one, 1, None, None, None, None), contains="null")
+    fails(L.mms_linear_group_act_split(device, 1, 100, 128, 32, one, one, one, one, 1, 0, None), contains="128")
+    fails(L.mms_split_planes(device, 8, 8, 4, zp, zp, None))
+    fails(L.mms_split_planes(device, 8, 8, 8, None, zp, None))
+    fails(L.mms_layernorm_group(device, 0, 8, 8, 8, 8, one, one, one, one, 1e-5, None), contains="groups")
+    fails(L.mms_row_stats_group(device, 1, 8, 0, 8, one, one, 1e-5, None))
+    fails(L.mms_marl_heads_act(device, 1, 8, 8, one, one, one, one, one, (ctypes.c_int32 * 1)(17), None, one, None, None, None, 0, 0, 1e-5, None))
+    other = 0 if device < 0 else -1
+    fails(L.mms_gae_ppo(other, zp, zp, zp, zp, zp, zp, zp, 1, 1, 0.9, 0.9, None))       # the other library's device
+    return n_checked[0]

@@ -48,6 +48,29 @@ def test_never_a_fallback():
     assert _lib.lib_cpu().mms_marl_views(0, ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(z.data_ptr()), 0, 2, 1, 0, None) != 0
 
 
+def test_abi_error_paths_cpu_build():
+    """SURVEY 8b's status-code contract on the CPU build: bad task id, num_agents > 126, unknown tensor name, env id out of range (and
+    nothing written), null pointers, the other library's device ... each returns non-zero with a non-empty mms_last_error
+    (tests/abi_errors.py; the same list runs on the HIP build in tests/test_gpu_parity.py).  The Python boundary on top of it: a
+    VecTask whose clip_observations disagrees with the engine's raises."""
+    import abi_errors
+    assert abi_errors.check_abi_error_paths(_lib.lib_cpu(), -1) >= 40
+    from massive_marl_benchmark_amd.tasks.agent_base.vec_task import VecTaskPython
+    from massive_marl_benchmark_amd.tasks.one_ant import OneAnt
+    cfg = default_cfg("OneAnt")
+    cfg["env"]["numEnvs"] = 4
+    task = OneAnt(cfg, None, "physx", "cpu", 0, True)
+    with pytest.raises(ValueError, match="clip_obs"):
+        VecTaskPython(task, "cpu", 7.0, 1.0)                          # the engine was created with clip_observations 5.0
+    with pytest.raises(ValueError, match="clip_obs"):
+        VecTaskPython(task, "cpu", 5.0, 0.5)
+    with pytest.raises(_lib.MmsError, match="no_such"):
+        task.engine.tensor("no_such")
+    with pytest.raises(_lib.MmsError, match="out of range"):
+        task.engine.set_state("progress", np.zeros((1,), np.int64), env_ids=[4])
+    task.engine.close()
+
+
 def test_package_never_imports_the_oracle():
     """The oracle is the checker: no file of the product package may import, load or name it."""
     pkg = os.path.join(ROOT, "massive_marl_benchmark_amd")

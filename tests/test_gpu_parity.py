@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import parity
-from conftest import angle_close, load_golden, random_dr_params, shove_ants_into_box
+from conftest import ROOT, angle_close, load_golden, random_dr_params, shove_ants_into_box
 
 pytestmark = pytest.mark.gpu
 
@@ -150,10 +150,18 @@ def test_domain_randomised_physics_parity(torch_cuda, task, n):
 @pytest.mark.parametrize("task,n", [("TenAnt", 8), ("OneAnt", 9)])
 def test_box_ground_friction_parity(torch_cuda, task, n):
     """cfg env.boxGroundFriction = 0.5: the friction branch of the box phase (27-value corner reduction + 6x6 solve) against the
-    oracle while ants push the box, and the frictionless branch (`boxGroundFriction: 0`) beside it."""
+    oracle while ants push the box, and the frictionless branch (`boxGroundFriction: 0`) beside it.
+
+    What friction means physically is asserted on the KERNEL's own state in a coast phase behind the push: the ants are lifted
+    away from the box (no contact any more), and from then on a box on mu = 0.5 ground decelerates at mu g = 4.9 m/s^2 and rests
+    within a few steps, while on mu = 0 it keeps its horizontal speed to rounding.  (During the push itself "mu = 0.5 is slower"
+    does NOT hold and round 2 was right to drop it: with ant-box friction 0.75 (the `average` rule) the ants drag the box
+    sideways while it is pinned against ground friction, and the peak corner speed came out 0.655 m/s on mu = 0.5 against
+    0.510 m/s on mu = 0 -- the mechanism is pinned by tests/test_oracle_physics.py::test_ant_box_friction_drags_the_box_sideways
+    and ::test_box_ground_friction_option; the push-phase peak speeds are recorded in the margins file.)"""
     torch = torch_cuda
     from massive_marl_benchmark_amd.model import default_cfg
-    speeds = {}
+    push_speed, coast = {}, {}
     for mu in (0.5, 0.0):
         cfg = default_cfg(task)
         cfg["env"]["boxGroundFriction"] = mu
@@ -169,9 +177,37 @@ def test_box_ground_friction_parity(torch_cuda, task, n):
             act = rng.uniform(-1, 1, (n, ora.num_actions)).astype(np.float32)
             drive(torch, eng, ora, tf, act, "%s box friction %.1f step %d" % (task, mu, t))
         tf.finish("gpu/box_ground_friction/%s/mu%.1f" % (task, mu))
-        speeds[mu] = float(np.abs(ora.tensor("root_states").reshape(n, A + 1, 13)[:, A, 7:9]).max())
+        push_speed[mu] = float(np.abs(ora.tensor("root_states").reshape(n, A + 1, 13)[:, A, 7:9]).max())
+        # coast phase on the engine alone: ants lifted 3 m up and frozen far from the box, the box given a known slide
+        roots = ora.tensor("root_states").reshape(n, A + 1, 13).copy()
+        roots[:, :A, 1] += 6.0
+        roots[:, :A, 2] = 3.0
+        roots[:, :A, 7:13] = 0.0
+        roots[:, A, 7:13] = 0.0
+        roots[:, A, 3:7] = (0.0, 0.0, 0.0, 1.0)
+        roots[:, A, 2] = 0.49918                                                                # resting on the compliant ground (half height 0.5)
+        roots[:, A, 7] = 0.6                                                                    # m/s along x
+        ora.tensor("root_states")[...] = roots.reshape(ora.tensor("root_states").shape)
+        ora.tensor("reset")[...] = 0
+        ora.tensor("progress")[...] = 1
+        push_state(torch, eng, ora)
+        vx = []
+        for t in range(12):
+            eng.tensor("actions").zero_()
+            eng.tensor("reset").zero_()                           # (falling ants may flag a reset: keep the box where it slides)
+            eng.step()
+            torch.cuda.synchronize()
+            vx.append(to_np(eng.tensor("root_states")).reshape(n, A + 1, 13)[:, A, 7].copy())
+        coast[mu] = np.stack(vx)                                  # [steps, n]
         eng.close()
-    assert speeds[0.5] != speeds[0.0]                    # the option reaches the kernel (what friction does: tests/test_oracle_physics.py)
+    dt = 0.0166
+    decel = (0.6 - coast[0.5][2]) / (3 * dt)                      # over the first three steps, before it rests
+    assert np.all(np.abs(decel - 0.5 * 9.81) < 0.6), decel        # Coulomb: mu g (the regularised law's normal-force estimate: +-10 %)
+    assert np.all(np.abs(coast[0.5][-1]) < 0.03)                  # ... and at rest (creep below 3 cm/s) after 12 steps = 0.2 s > 0.6 / 4.9
+    assert np.all(np.abs(coast[0.0][-1] - 0.6) < 1e-3)            # frictionless: keeps its speed
+    parity.record("gpu/box_ground_friction/%s/physics" % task, push_phase_peak_speed_mu05=push_speed[0.5], push_phase_peak_speed_mu0=push_speed[0.0],
+                  coast_decel_mu05=float(decel.mean()), coast_final_speed_mu05=float(np.abs(coast[0.5][-1]).max()),
+                  coast_final_speed_mu0=float(coast[0.0][-1].mean()))
 
 
 @pytest.mark.parametrize("task,n", [("TenAnt", 7), ("OneAnt", 5)])
@@ -1115,8 +1151,9 @@ def test_split_layers_error(torch_cuda):
     """mms_linear_group_act_split (fp32 operands as three bf16 planes, six bf16 MFMA products, fp32 accumulation) against the float64
     product, NEXT TO the exact-fp32 MFMA kernel (mms_linear2_act) on the same inputs: the split kernel's error must not be larger --
     that is what makes it the same fp32 arithmetic on a faster pipe and not a narrower precision.  Gates: every element within the
-    fp32 kernel's own per-element bound (5e-7 of sum |x||w| + |b|, test_linear2_act_kernel), rms error <= 1.02 x the fp32 kernel's
-    rms error on every shape (measured 0.83-0.85 x), worst error <= 1.25 x its worst error.  Shapes: the PPO policy's three hidden
+    fp32 kernel's own per-element bound (5e-7 of sum |x||w| + |b|, test_linear2_act_kernel), rms error <= 0.5 x the fp32 kernel's
+    rms error on every shape (measured 0.32 x: the leading accumulator rounds once per 32 k, the fp32 MFMA chain 32 times), worst
+    error <= 0.8 x its worst error (measured 0.35-0.42 x), mean error not above the fp32 kernel's own.  Shapes: the PPO policy's three hidden
     layers at 4096 rows (both tilings: 256 x 128 and 128 x 128 blocks), one and two networks, all four epilogues, planes-out and
     fp32-out; the P32 output of one launch is the input of the next."""
     torch = torch_cuda
@@ -1161,7 +1198,10 @@ def test_split_layers_error(torch_cuda):
         max_ratio = float(es.abs().max() / ef.abs().max())
         margins["%dx%dx%d" % (M, N, K)] = {"rms_ratio": rms_ratio, "max_ratio": max_ratio}
         if K >= 100:                                                 # (tiny K: both errors are a few ulps of single roundings)
-            assert rms_ratio <= 1.02 and max_ratio <= 1.25, (M, N, K, rms_ratio, max_ratio)
+            assert rms_ratio <= 0.5 and max_ratio <= 0.8, (M, N, K, rms_ratio, max_ratio)
+            # no bias of its own: the mean error stays at the exact-fp32 kernel's (both carry the epilogue's ~1e-9 rms(Y)), far below
+            # the -5e-8 rms(Y) a single accumulator for all six products shows
+            assert abs(float(es.mean())) <= max(2.0 * abs(float(ef.mean())), 0.02 * float(es.pow(2).mean().sqrt())), "biased"
         if planes_out and N % 128 == 0 and act == 1:                 # chained: this layer's planes feed the next split layer unchanged
             w2 = [torch.randn(128, N, device="cuda") / N ** 0.5 for _ in range(G)]
             w2p = [torch.empty(_p32_bytes(128, N), dtype=torch.uint8, device="cuda") for _ in range(G)]
@@ -1217,6 +1257,62 @@ def test_actor_critic_split_layers(torch_cuda):
         with torch.no_grad():                                        # "optimizer step": in place, the version counters move
             for q in ac.parameters():
                 q.add_(0.01 * torch.randn_like(q))
+
+
+def test_abi_error_paths_and_indexed_set_state(torch_cuda):
+    """The status-code contract of include/mms.h on the HIP build (the list of tests/abi_errors.py, as on the CPU build), and
+    mms_set_state with more than 16 env ids: one scatter launch (the reference's indexed setters take thousands of ids,
+    ten_ant.py:867-875), from a host array and from a device tensor, equal to the per-row result."""
+    torch = torch_cuda
+    import abi_errors
+    from massive_marl_benchmark_amd import _lib
+    from massive_marl_benchmark_amd.engine import Engine
+    assert abi_errors.check_abi_error_paths(_lib.lib(), 0) >= 40
+    n = 4096
+    eng = Engine("TenAnt", num_envs=n, device=0, seed=1)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randperm(n, generator=g)[:1500].tolist()
+    rows = torch.randn(1500, 11 * 13, generator=g)
+    want = eng.tensor("root_states").clone().view(n, -1)
+    want[ids] = rows.cuda()
+    eng.set_state("root_states", rows.numpy(), env_ids=ids)          # host source
+    torch.cuda.synchronize()
+    assert torch.equal(eng.tensor("root_states").view(n, -1), want)
+    rows2 = torch.randn(1500, 80 * 2, generator=g).cuda()
+    want2 = eng.tensor("dof_state").clone().view(n, -1)
+    want2[ids] = rows2
+    eng.set_state("dof_state", rows2, env_ids=ids)                   # device source
+    torch.cuda.synchronize()
+    assert torch.equal(eng.tensor("dof_state").view(n, -1), want2)
+    prog = torch.arange(20, dtype=torch.int64)
+    eng.set_state("progress", prog.numpy(), env_ids=list(range(100, 120)))      # int64 rows of one element
+    torch.cuda.synchronize()
+    assert torch.equal(eng.tensor("progress")[100:120].cpu(), prog)
+    with pytest.raises(_lib.MmsError, match="out of range"):
+        eng.set_state("progress", prog.numpy(), env_ids=list(range(100, 119)) + [n])
+    assert torch.equal(eng.tensor("progress")[100:120].cpu(), prog)
+    eng.close()
+
+
+def test_bench_under_torchrun_single_rank(torch_cuda):
+    """bench.py launched the way the driver launches the multi-GPU runs -- `python -m torch.distributed.run --nproc-per-node 1
+    --master-addr 127.0.0.1 ... bench.py --gpus 1` as a fresh child process -- takes the RCCL path (init_process_group("nccl"),
+    barrier, all_reduce(MAX) of the timings) at world size 1 and prints one well-formed JSON line.  A rehearsal of the control
+    flow only: no scaling figure can come from one GPU."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MMS_BENCH_TRACE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "8", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 16 and out["warmup"] == 8 and out["scaling"] == "weak" and out["value"] > 1e6
+    assert out["config"]["distributed"] == {"backend": "nccl", "world_size": 1}
+    assert out["roofline"]["frac"] > 0 and out["config"]["finite"]
 
 
 def test_fused_act_and_bound_rollout(torch_cuda):
