@@ -31,7 +31,8 @@
  *   ActorCritic.act sampling tail + RolloutStorage.add_transitions       mms_ppo_act, mms_ppo_heads_act,
  *     (algorithms/rl/ppo/module.py:73-87; storage.py:33-47)              mms_bind_rollout_out
  *   ActorCritic hidden layers (module.py:27-52)                          mms_linear2_act, mms_linear_group_act_split,
- *                                                                        mms_split_planes
+ *                                                                        mms_split_planes(_group), mms_row_stats_chan_group,
+ *                                                                        mms_marl_heads_finish
  *   Actor / Critic forward of every MAPPO / HAPPO agent                  mms_linear_group_act, mms_layernorm_group,
  *     (algorithms/marl/actor_critic.py:43-69, 137-155; runner.py:186-216)  mms_row_stats_group, mms_marl_heads_act
  *
@@ -313,10 +314,36 @@ int mms_marl_heads_act(int device, int32_t groups, int64_t M, int32_t H, const f
  * the observation once per env step; hidden activations are left in P32 by the layer that produces them (out_planes below). */
 int mms_split_planes(int device, int64_t rows, int32_t K, int32_t x_pitch, const float* x, void* planes, void* hip_stream);
 
+/* The same for `groups` matrices of one shape in one launch (x and planes: HOST arrays of device pointers).  Rows need not be 16-byte
+ * aligned here (agent k's rows of an [M, agents, 46] observation block): unaligned sources take scalar loads. */
+int mms_split_planes_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch, const float* const* x, void* const* planes,
+                           void* hip_stream);
+
 /* y_g = act(x_g @ w_g^T + b_g), g < groups, as mms_linear_group_act, with x_g [M, K] and w_g [N, K] given as P32 planes and b_g [N] f32.
- * out_planes != 0: y_g is left as P32 planes of [M, N] (the next split layer's x); 0: y_g [M, N] f32.  M and N multiples of 128. */
+ * M and N multiples of 128.  out_mode 0: y_g [M, N] f32; 1: y_g left as P32 planes of [M, N] (the next split layer's x); 2: no y_g --
+ * only the output head's partial dot products (below).
+ * LayerNorm folds (ln_s, ln_stat_in, ln_part_out: all NULL or all given; act must be ELU): as mms_linear_group_act's, except that
+ *   ln_part_out[g] [N/64, M, 2] receives per row and 64-column slot (sum, sum of squared deviations FROM THE SLOT'S OWN MEAN) -- the
+ *   two-pass form, free of E[x^2] - mean^2 cancellation; mms_row_stats_chan_group combines the slots (Chan's formula).
+ * out_mode 2 (needs the folds): head_w[g] [head_dim, N] f32 = the output head's weight with the last LayerNorm's gamma folded in,
+ *   head_dim <= 16; head_part[g] [N/64, M, 16] receives sum over the slot's columns of y[r, n] head_w[j, n]: the head of every network
+ *   is finished by mms_marl_heads_finish without the activations ever being written. */
 int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
-                               const float* const* b, void* const* y, int32_t act, int32_t out_planes, void* hip_stream);
+                               const float* const* b, void* const* y, int32_t act, int32_t out_mode, const float* const* ln_s,
+                               const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
+                               int32_t head_dim, void* hip_stream);
+
+/* stat_g[r] = (mean, 1 / sqrt(var + eps)) of row r from mms_linear_group_act_split's ln_part_out (`slots` = N / 64 slots of 64). */
+int mms_row_stats_chan_group(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part, float* const* stat, float eps,
+                             void* hip_stream);
+
+/* The output heads behind an out_mode-2 layer: mean_gj[r] = rstd_r (sum_slots head_part[g][slot, r, j] - mean_r hs[g][j]) + hc[g][j] with
+ * (mean_r, rstd_r) from part[g] (the last hidden layer's ln_part_out), hs = head_w 1 and hc = w beta + b (both [A[g]]); then exactly
+ * mms_marl_heads_act's sampling: std / out / logp / out_pitch / counters / seed / row_offset have the same meaning. */
+int mms_marl_heads_finish(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part, const float* const* head_part,
+                          const float* const* hs, const float* const* hc, const int32_t* A, const float* const* std, float* const* out,
+                          float* const* logp, const int32_t* out_pitch, int64_t* const* counters, uint64_t seed, int64_t row_offset, float eps,
+                          void* hip_stream);
 
 const char* mms_last_error(mms_handle h);   /* h may be NULL: error of the last failed mms_create */
 int mms_abi_version(void);

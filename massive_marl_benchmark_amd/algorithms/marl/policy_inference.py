@@ -82,7 +82,7 @@ def _critic_halves(table, n):
 
 
 class GroupedPolicyInference:
-    def __init__(self, actors, critics, seed=0, row_offset=0, fold_layernorm=True):
+    def __init__(self, actors, critics, seed=0, row_offset=0, fold_layernorm=True, split_layers=True):
         if len(actors) != len(critics) or not actors:
             raise ValueError("one actor and one critic per agent")
         self._chunks = None
@@ -92,7 +92,7 @@ class GroupedPolicyInference:
             self.n = len(actors)
             self._ranges = [(lo, min(lo + 16, self.n)) for lo in range(0, self.n, 16)]
             self._chunks = [GroupedPolicyInference(actors[lo:hi], critics[lo:hi], seed=int(seed) + lo, row_offset=row_offset,
-                                                   fold_layernorm=fold_layernorm) for lo, hi in self._ranges]
+                                                   fold_layernorm=fold_layernorm, split_layers=split_layers) for lo, hi in self._ranges]
             return
         for m in list(actors) + list(critics):
             if getattr(m, "_use_recurrent_policy", False) or getattr(m, "_use_naive_recurrent_policy", False):
@@ -105,6 +105,11 @@ class GroupedPolicyInference:
         # The LayerNorms BETWEEN the hidden layers folded into the layers on either side (mms.h: ln_part_out / ln_stat_in): the
         # normalised activations are never written.  Used when the shapes allow (batch and hidden size multiples of 128).
         self.fold_layernorm = bool(fold_layernorm)
+        # ... and, on top of the folds, every layer on the bf16 matrix pipe with fp32 operands carried as three bf16 planes
+        # (csrc/split_kernels.hip: the same fp32 product, a third of the exact-fp32 MFMA kernel's error, ~1.8 x its rate), the actors'
+        # feature LayerNorm folded like the critics', and the output heads finished from per-slot partial dot products that the LAST
+        # hidden layer's epilogue leaves (mms_marl_heads_finish): the last activations are never written or re-read.
+        self.split_layers = bool(split_layers)
         self.a_blocks = [_blocks(a.base) for a in self.actors]
         self.c_blocks = [_blocks(c.base) for c in self.critics]
         depth = {len(b) for b in self.a_blocks + self.c_blocks}
@@ -174,7 +179,47 @@ class GroupedPolicyInference:
             bias = torch.stack([d(b[0][0].bias) for b in self.c_blocks])
             Wt = (W * gam[:, None, :]).contiguous()
             self._fold_c1 = (Wt, Wt.sum(-1).contiguous(), (torch.einsum("gnk,gk->gn", W, bet) + bias).contiguous())
+        self._refresh_split()
         self._bind()
+
+    def _refresh_split(self):
+        """Derived copies of the split path: the actors' first layer folded with their feature LayerNorm, the output heads folded with
+        the last LayerNorm, and the P32 planes of every (folded) weight matrix."""
+        self._sp = None
+        H, n, d = self.hidden, self.n, (lambda t: t.detach())
+        if not (self.split_layers and self.fold_layernorm and self._fold_c1 is not None and H % 128 == 0):
+            return
+        L, idx, stream = _lib.for_device(self.device)
+        W = torch.stack([d(b[0][0].weight) for b in self.a_blocks])
+        gam = torch.stack([d(a.base.feature_norm.weight) for a in self.actors])
+        bet = torch.stack([d(a.base.feature_norm.bias) for a in self.actors])
+        bias = torch.stack([d(b[0][0].bias) for b in self.a_blocks])
+        Wt = (W * gam[:, None, :]).contiguous()
+        fold_a1 = (Wt, Wt.sum(-1).contiguous(), (torch.einsum("gnk,gk->gn", W, bet) + bias).contiguous())
+        last = self.depth - 1
+        both = self.a_blocks + self.c_blocks
+        A = self.act_dim
+        hw = torch.zeros(2 * n, A, H, device=self.device)                              # critics: row 0 = v_out, the rest zero
+        hb = torch.zeros(2 * n, A, device=self.device)
+        for i, a in enumerate(self.actors):
+            hw[i], hb[i] = d(a.act.action_out.fc_mean.weight), d(a.act.action_out.fc_mean.bias)
+        for i, c in enumerate(self.critics):
+            hw[n + i, :1], hb[n + i, :1] = d(c.v_out.weight), d(c.v_out.bias)
+        g_last = torch.stack([d(b[last][1].weight) for b in both])
+        b_last = torch.stack([d(b[last][1].bias) for b in both])
+        hwt = (hw * g_last[:, None, :]).contiguous()
+        heads = (hwt, hwt.sum(-1).contiguous(), (torch.einsum("gjk,gk->gj", hw, b_last) + hb).contiguous())
+
+        def planes(Wg):                                                                 # [G, N, K] -> G P32 plane tensors
+            G, N, K = Wg.shape
+            out = [torch.empty(N * ((K + 31) // 32) * 192, dtype=torch.uint8, device=self.device) for _ in range(G)]
+            for lo in range(0, G, 32):
+                src, dst = [Wg[g] for g in range(lo, min(lo + 32, G))], out[lo:lo + 32]
+                _lib.check(L.mms_split_planes_group(idx, len(src), N, K, 0, _ptrs(src), (ctypes.c_void_p * len(dst))(*[t.data_ptr() for t in dst]), stream),
+                           None, "mms_split_planes_group", L)
+            return out
+        self._sp = {"a1": fold_a1, "heads": heads, "w_a1": planes(fold_a1[0]), "w_c1": planes(self._fold_c1[0]),
+                    "w": {l: planes(self._fold[l][0]) for l in self._fold}}
 
     def _param_versions(self):
         """(data_ptr, version) of every source parameter: what the derived copies of refresh() were built from"""
@@ -222,6 +267,14 @@ class GroupedPolicyInference:
         self.p["hb"] = arr([d(m.bias) for m in heads] + [d(m.bias) for m in vouts])
         self.p["std"] = arr(self._std + [None] * self.n)
         self.p["std_none"] = arr([None] * (2 * self.n))
+        if self._sp is not None:
+            sp = self._sp
+            up = lambda ts: (self._keep.append(ts), (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]))[1]
+            self.p["sw_a1"], self.p["sw_c1"] = up(sp["w_a1"]), up(sp["w_c1"])
+            self.p["fs1_a"], self.p["fc1_a"] = arr(list(sp["a1"][1].unbind(0))), arr(list(sp["a1"][2].unbind(0)))
+            for l, pl in sp["w"].items():
+                self.p["sw%d" % l] = up(pl)
+            self.p["hwt"], self.p["hs"], self.p["hc"] = arr(list(sp["heads"][0].unbind(0))), arr(list(sp["heads"][1].unbind(0))), arr(list(sp["heads"][2].unbind(0)))
         self._A = (ctypes.c_int32 * (2 * self.n))(*([self.act_dim] * self.n + [1] * self.n))
         self._A1 = (ctypes.c_int32 * self.n)(*([1] * self.n))
         _critic_halves(self.p, self.n)
@@ -253,8 +306,80 @@ class GroupedPolicyInference:
             "stat_c": _ptrs(ub(self.stat_c)), "stat_c0": _ptrs([self.stat_c[0]] * n),
             "part": _ptrs(ub(self.part)), "part_a": _ptrs(ub(self.part[:n])), "part_c": _ptrs(ub(self.part[n:])), "stat": _ptrs(ub(self.stat)),
         }
+        if self._sp is not None and M % 128 == 0:
+            u8 = lambda g, rows, K: [torch.empty(rows * ((K + 31) // 32) * 192, dtype=torch.uint8, device=dev) for _ in range(g)]
+            self.sx_a, self.sx_c = u8(n, M, self.obs_dim), u8(n, M, self.sobs_dim)
+            self.sh = [u8(2 * n, M, H), u8(2 * n, M, H)]
+            self.stat_a = z(n, M, 2)
+            self.head_part = z(2 * n, max(1, H // 64), M, 16)
+            up = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            self.q.update({"sx_a": up(self.sx_a), "sx_c": up(self.sx_c), "sx_c0": up([self.sx_c[0]] * n), "sh0": up(self.sh[0]), "sh1": up(self.sh[1]),
+                           "sh0_a": up(self.sh[0][:n]), "sh0_c": up(self.sh[0][n:]), "stat_a": _ptrs(ub(self.stat_a)),
+                           "hpart": _ptrs(ub(self.head_part)), "hpart_a": _ptrs(ub(self.head_part[:n])), "hpart_c": _ptrs(ub(self.head_part[n:]))})
         _critic_halves(self.q, n)
         self._M = M
+
+    # -- the split path ---------------------------------------------------------------------------------------------------------
+    def _split_applies(self, M, sobs_pitch):
+        return (self._sp is not None and self.split_layers and self.fold_layernorm and M % 128 == 0 and self.hidden % 128 == 0
+                and sobs_pitch == self.sobs_dim and self.sobs_dim >= 8)
+
+    def _forward_split(self, L, idx, stream, M, obs_p, obs_pitch, sobs_p, with_actors, std_p, out_p, logp_p, pitch_p, cnt_p):
+        """Every layer through mms_linear_group_act_split with all LayerNorms folded and the heads finished from the last layer's
+        partials: split + row moments of the raw observations, fc1 of the actors (K = obs) and of the critics (K = share_obs), the
+        H x H layers of all networks, mms_marl_heads_finish.  with_actors = False: the critics alone (get_values)."""
+        n, H, p, q = self.n, self.hidden, self.p, self.q
+        chk = lambda rc, what: _lib.check(rc, None, what, L)
+        slots, A, depth = H // 64, self.act_dim, self.depth
+        sfx = "" if with_actors else "/c"
+        G = 2 * n if with_actors else n
+        last_mode = lambda l: 2 if l == depth - 1 else 1
+        heads = lambda l, key_w, key_p: (p[key_w], q[key_p], A) if l == depth - 1 else (None, None, 0)
+        if with_actors:
+            chk(L.mms_split_planes_group(idx, n, M, self.obs_dim, obs_pitch, obs_p, q["sx_a"], stream), "mms_split_planes_group")
+            chk(L.mms_row_moments_group(idx, n, M, self.obs_dim, obs_pitch, obs_p, q["stat_a"], self.eps, stream), "mms_row_moments_group")
+        shared_rows = len({int(v) for v in sobs_p}) == 1                     # one centralised observation for all critics: one pass
+        gs = 1 if shared_rows else n
+        chk(L.mms_split_planes_group(idx, gs, M, self.sobs_dim, self.sobs_dim, sobs_p, q["sx_c"], stream), "mms_split_planes_group")
+        chk(L.mms_row_moments_group(idx, gs, M, self.sobs_dim, self.sobs_dim, sobs_p, q["stat_c"], self.eps, stream), "mms_row_moments_group")
+        if with_actors:
+            hw, hp, hd = heads(0, "hwt", "hpart_a")
+            hw = None if hw is None else (ctypes.c_void_p * n)(*list(hw)[:n])
+            chk(L.mms_linear_group_act_split(idx, n, M, H, self.obs_dim, q["sx_a"], p["sw_a1"], p["fc1_a"], q["sh0_a"], 1, last_mode(0), p["fs1_a"],
+                                             q["stat_a"], q["part_a"], hw, hp, hd, stream), "mms_linear_group_act_split")
+        hw, hp, hd = heads(0, "hwt/c", "hpart_c")
+        chk(L.mms_linear_group_act_split(idx, n, M, H, self.sobs_dim, q["sx_c0"] if shared_rows else q["sx_c"], p["sw_c1"], p["fc1_c"], q["sh0_c"], 1,
+                                         last_mode(0), p["fs1_c"], q["stat_c0"] if shared_rows else q["stat_c"], q["part_c"], hw, hp, hd, stream),
+            "mms_linear_group_act_split")
+        cur = 0
+        for l in range(1, depth):
+            chk(L.mms_row_stats_chan_group(idx, G, M, slots, q["part" + sfx], q["stat" + sfx], self.eps, stream), "mms_row_stats_chan_group")
+            hw, hp, hd = heads(l, "hwt" + sfx, "hpart" + sfx)
+            chk(L.mms_linear_group_act_split(idx, G, M, H, H, q["sh%d%s" % (cur, sfx)], p["sw%d%s" % (l, sfx)], p["fc%d%s" % (l, sfx)],
+                                             q["sh%d%s" % (1 - cur, sfx)], 1, last_mode(l), p["fs%d%s" % (l, sfx)], q["stat" + sfx], q["part" + sfx],
+                                             hw, hp, hd, stream), "mms_linear_group_act_split")
+            cur = 1 - cur
+        A_arr = self._A if with_actors else self._A1
+        chk(L.mms_marl_heads_finish(idx, G, M, slots, q["part" + sfx], q["hpart" + sfx], p["hs" + sfx], p["hc" + sfx], A_arr, std_p, out_p, logp_p,
+                                    pitch_p, cnt_p, self.seed, self.row_offset, self.eps, stream), "mms_marl_heads_finish")
+
+    def _out_ptrs(self, out):
+        """(values, actions, logp lists, output / log-prob pointer arrays over the 2n networks, pitch array or None)"""
+        n, q = self.n, self.q
+        if out is None:
+            return list(self.values.unbind(0)), list(self.actions.unbind(0)), list(self.logp.unbind(0)), q["out"], q["logp"], None
+        values = list(out[0])
+        actions = list(self.actions.unbind(0)) if out[1] is None else list(out[1])      # (None: scratch -- values_into)
+        logp = list(self.logp.unbind(0)) if out[2] is None else list(out[2])
+        ap, a_pitch = _row_ptrs(actions)
+        lp, l_pitch = _row_ptrs(logp)
+        vp, v_pitch = _row_ptrs(values)
+        if a_pitch != l_pitch:
+            raise ValueError("GroupedPolicyInference: action and log-prob destinations must share one row pitch")
+        out_p = (ctypes.c_void_p * (2 * n))(*(list(ap) + list(vp)))
+        logp_p = (ctypes.c_void_p * (2 * n))(*(list(lp) + [None] * n))
+        pitch = (ctypes.c_int32 * (2 * n))(*([a_pitch] * n + [v_pitch] * n))
+        return values, actions, logp, out_p, logp_p, pitch
 
     # -- inference ----------------------------------------------------------------------------------------------------------------
     def get_actions(self, share_obs, obs, deterministic=False, out=None):
@@ -287,6 +412,10 @@ class GroupedPolicyInference:
         obs_f, sobs_f = [f32(t) for t in obs], [f32(t) for t in share_obs]     # (held until the launches below have been issued)
         obs_p, obs_pitch = _row_ptrs(obs_f)
         sobs_p, sobs_pitch = _row_ptrs(sobs_f)
+        if self._split_applies(M, sobs_pitch):
+            values, actions, logp, out_p, logp_p, pitch = self._out_ptrs(out)
+            self._forward_split(L, idx, stream, M, obs_p, obs_pitch, sobs_p, True, p["std_none"] if deterministic else p["std"], out_p, logp_p, pitch, q["cnt"])
+            return values, actions, (None if deterministic else logp)
         chk(L.mms_layernorm_group(idx, n, M, self.obs_dim, self.kp_a, obs_pitch, obs_p, p["fn_a_g"], p["fn_a_b"], q["x_a"], self.eps, stream), "mms_layernorm_group")
         H = self.hidden
         fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0 and self.kp_a >= 8
@@ -316,21 +445,7 @@ class GroupedPolicyInference:
             if l + 1 < self.depth and not fold:                     # (the last LayerNorm runs inside the heads kernel)
                 chk(L.mms_layernorm_group(idx, 2 * n, M, H, H, H, q["h%d" % cur], p["ln%d_g" % l], p["ln%d_b" % l], q["h%d" % cur], self.eps, stream), "mms_layernorm_group")
         last = self.depth - 1
-        if out is None:
-            values, actions, logp = list(self.values.unbind(0)), list(self.actions.unbind(0)), list(self.logp.unbind(0))
-            out_p, logp_p, pitch = q["out"], q["logp"], None
-        else:
-            values = list(out[0])
-            actions = list(self.actions.unbind(0)) if out[1] is None else list(out[1])      # (None: scratch -- values_into)
-            logp = list(self.logp.unbind(0)) if out[2] is None else list(out[2])
-            ap, a_pitch = _row_ptrs(actions)
-            lp, l_pitch = _row_ptrs(logp)
-            vp, v_pitch = _row_ptrs(values)
-            if a_pitch != l_pitch:
-                raise ValueError("GroupedPolicyInference: action and log-prob destinations must share one row pitch")
-            out_p = (ctypes.c_void_p * (2 * n))(*(list(ap) + list(vp)))
-            logp_p = (ctypes.c_void_p * (2 * n))(*(list(lp) + [None] * n))
-            pitch = (ctypes.c_int32 * (2 * n))(*([a_pitch] * n + [v_pitch] * n))
+        values, actions, logp, out_p, logp_p, pitch = self._out_ptrs(out)
         chk(L.mms_marl_heads_act(idx, 2 * n, M, H, q["h%d" % cur], p["ln%d_g" % last], p["ln%d_b" % last], p["hw"], p["hb"], self._A,
                                  p["std_none"] if deterministic else p["std"], out_p, logp_p, pitch, q["cnt"], self.seed, self.row_offset, self.eps, stream),
             "mms_marl_heads_act")
@@ -390,6 +505,11 @@ class GroupedPolicyInference:
         sobs_f = [f32(t) for t in share_obs]                                  # (held until the launches below have been issued)
         sobs_p, sobs_pitch = _row_ptrs(sobs_f)
         H = self.hidden
+        if self._split_applies(M, sobs_pitch):
+            values = list(self.values.unbind(0)) if out is None else list(out)
+            vp, v_pitch = _row_ptrs(values)
+            self._forward_split(L, idx, stream, M, None, 0, sobs_p, False, None, vp, None, (ctypes.c_int32 * n)(*([v_pitch] * n)), None)
+            return values
         fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0
         fold_c1 = fold and self._fold_c1 is not None and sobs_pitch == self.sobs_dim and self.sobs_dim >= 8
         slots = H // 64

@@ -165,7 +165,7 @@ class ActorCritic(nn.Module):
             out = bufs["out"] if last else bufs["h"][li]
             wp = [self._weight_planes(l, L, idx, stream) for l in lins]
             _lib.check(L.mms_linear_group_act_split(idx, G, M, lins[0].out_features, lins[0].in_features, arr(cur), arr(wp),
-                                                    arr([l.bias.detach() for l in lins]), arr(out), 1, 0 if last else 1, stream),
+                                                    arr([l.bias.detach() for l in lins]), arr(out), 1, 0 if last else 1, None, None, None, None, None, 0, stream),
                        None, "mms_linear_group_act_split", L)
             cur = out
         return bufs["out"]

@@ -434,17 +434,43 @@ MMS_API int mms_split_planes(int device, int64_t rows, int32_t K, int32_t x_pitc
     return 0;
 }
 
+MMS_API int mms_split_planes_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch, const float* const* x, void* const* planes, void*) {
+    if (cpu_only(device)) return 1;
+    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_split_planes_group: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
+    if (!x || !planes) { g_error = "mms_split_planes_group: bad arguments (x_pitch >= K)"; return 1; }
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !planes[g]) { g_error = "mms_split_planes_group: null or misaligned pointer in a group (planes 16-byte aligned)"; return 1; }
+        if (mms_split_planes(device, rows, K, x_pitch, x[g], planes[g], nullptr)) return 1;
+    }
+    return 0;
+}
+
 MMS_API int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
-                                       const float* const* b, void* const* y, int32_t act, int32_t out_planes, void*) {
+                                       const float* const* b, void* const* y, int32_t act, int32_t out_mode, const float* const* ln_s,
+                                       const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
+                                       int32_t head_dim, void*) {
     if (cpu_only(device)) return 1;
     if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_linear_group_act_split: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
-    if (!x || !w || !b || !y || M < 0 || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3) {
-        g_error = "mms_linear_group_act_split: bad arguments (M and N multiples of 128, act 0..3)";
+    if (!x || !w || !b || M < 0 || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3 || out_mode < 0 || out_mode > 2 || (out_mode != 2 && !y)) {
+        g_error = "mms_linear_group_act_split: bad arguments (M and N multiples of 128, act 0..3, out_mode 0..2)";
         return 1;
     }
-    const int KC = (K + 31) / 32, NC = N / 32;
+    const bool ln = ln_s || ln_stat_in || ln_part_out;
+    if (ln && (!ln_s || !ln_stat_in || !ln_part_out || act != 1 || out_mode == 0)) {
+        g_error = "mms_linear_group_act_split: the LayerNorm folds come together (ln_s, ln_stat_in, ln_part_out), with act = ELU and out_mode 1 or 2";
+        return 1;
+    }
+    if (out_mode == 2 && (!ln || !head_w || !head_part || head_dim < 1 || head_dim > 16)) {
+        g_error = "mms_linear_group_act_split: out_mode 2 needs the LayerNorm folds, head_w, head_part and 1 <= head_dim <= 16";
+        return 1;
+    }
+    const int KC = (K + 31) / 32, NC = N / 32, slots = N / 64;
     for (int g = 0; g < groups; g++) {
-        if (!x[g] || !w[g] || !b[g] || !y[g]) { g_error = "mms_linear_group_act_split: null pointer in a group"; return 1; }
+        if (!x[g] || !w[g] || !b[g] || (out_mode != 2 && !y[g]) || (ln && (!ln_s[g] || !ln_stat_in[g] || !ln_part_out[g])) ||
+            (out_mode == 2 && (!head_w[g] || !head_part[g]))) {
+            g_error = "mms_linear_group_act_split: null pointer in a group";
+            return 1;
+        }
         const uint16_t* xp = (const uint16_t*)x[g];
         const uint16_t* wp = (const uint16_t*)w[g];
         std::vector<float> wf((size_t)N * KC * 32);
@@ -452,20 +478,101 @@ MMS_API int mms_linear_group_act_split(int device, int32_t groups, int64_t M, in
             for (int k = 0; k < KC * 32; k++) wf[n * KC * 32 + k] = join3(wp + (n * KC + k / 32) * 96, k % 32);
 #pragma omp parallel for schedule(static)
         for (int64_t m = 0; m < M; m++) {
-            std::vector<float> xr((size_t)KC * 32);
+            std::vector<float> xr((size_t)KC * 32), row((size_t)N);
             for (int k = 0; k < KC * 32; k++) xr[k] = join3(xp + (m * KC + k / 32) * 96, k % 32);
             for (int n = 0; n < N; n++) {
                 float s = 0.f;
                 const float* wr = wf.data() + (size_t)n * KC * 32;
                 for (int k = 0; k < KC * 32; k++) s = fmaf(xr[k], wr[k], s);
-                const float v = act_fn(s + b[g][n], act);
-                if (out_planes) {
-                    uint16_t* c = (uint16_t*)y[g] + (m * NC + n / 32) * 96 + n % 32;
-                    split3(v, c, c + 32, c + 64);
-                } else {
-                    ((float*)y[g])[m * N + n] = v;
-                }
+                if (ln) s = ln_stat_in[g][2 * m + 1] * (s - ln_stat_in[g][2 * m] * ln_s[g][n]);
+                row[n] = act_fn(s + b[g][n], act);
             }
+            if (ln)
+                for (int sl = 0; sl < slots; sl++) {                                    // (sum, M2 about the slot mean) per 64 columns
+                    float sum = 0.f, m2 = 0.f;
+                    for (int n = 64 * sl; n < 64 * sl + 64; n++) sum += row[n];
+                    const float mean = sum * (1.f / 64.f);
+                    for (int n = 64 * sl; n < 64 * sl + 64; n++) m2 += (row[n] - mean) * (row[n] - mean);
+                    ln_part_out[g][((size_t)sl * M + m) * 2 + 0] = sum;
+                    ln_part_out[g][((size_t)sl * M + m) * 2 + 1] = m2;
+                }
+            if (out_mode == 2) {
+                for (int sl = 0; sl < slots; sl++)
+                    for (int j = 0; j < head_dim; j++) {
+                        float p = 0.f;
+                        for (int n = 64 * sl; n < 64 * sl + 64; n++) p += row[n] * head_w[g][(size_t)j * N + n];
+                        head_part[g][((size_t)sl * M + m) * 16 + j] = p;
+                    }
+            } else if (out_mode == 1) {
+                for (int n = 0; n < N; n++) {
+                    uint16_t* c = (uint16_t*)y[g] + (m * NC + n / 32) * 96 + n % 32;
+                    split3(row[n], c, c + 32, c + 64);
+                }
+            } else {
+                memcpy((float*)y[g] + m * N, row.data(), (size_t)N * 4);
+            }
+        }
+    }
+    return 0;
+}
+
+static void chan_combine(const float* part, int64_t M, int64_t row, int slots, float& mean, float& m2) {
+    float sum = 0.f;
+    for (int k = 0; k < slots; k++) sum += part[((size_t)k * M + row) * 2];
+    mean = sum / (64.f * (float)slots);
+    m2 = 0.f;
+    for (int k = 0; k < slots; k++) {
+        const float d = part[((size_t)k * M + row) * 2] * (1.f / 64.f) - mean;
+        m2 += part[((size_t)k * M + row) * 2 + 1] + 64.f * d * d;
+    }
+}
+
+MMS_API int mms_row_stats_chan_group(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part, float* const* stat, float eps, void*) {
+    if (cpu_only(device)) return 1;
+    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_row_stats_chan_group: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
+    if (!part || !stat || M < 0 || slots < 1) { g_error = "mms_row_stats_chan_group: bad arguments"; return 1; }
+    for (int g = 0; g < groups; g++) {
+        if (!part[g] || !stat[g]) { g_error = "mms_row_stats_chan_group: null pointer in a group"; return 1; }
+        for (int64_t r = 0; r < M; r++) {
+            float mean, m2;
+            chan_combine(part[g], M, r, slots, mean, m2);
+            stat[g][2 * r] = mean;
+            stat[g][2 * r + 1] = 1.0f / sqrtf(m2 / (64.f * (float)slots) + eps);
+        }
+    }
+    return 0;
+}
+
+MMS_API int mms_marl_heads_finish(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part, const float* const* head_part,
+                                  const float* const* hs, const float* const* hc, const int32_t* A, const float* const* std, float* const* out,
+                                  float* const* logp, const int32_t* out_pitch, int64_t* const* counters, uint64_t seed, int64_t row_offset, float eps, void*) {
+    if (cpu_only(device)) return 1;
+    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_marl_heads_finish: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
+    if (!part || !head_part || !hs || !hc || !A || !out || M < 0 || slots < 1) { g_error = "mms_marl_heads_finish: bad arguments"; return 1; }
+    for (int g = 0; g < groups; g++) {
+        if (!part[g] || !head_part[g] || !hs[g] || !hc[g] || !out[g] || A[g] < 1 || A[g] > 16) {
+            g_error = "mms_marl_heads_finish: null pointer or output width outside 1..16 in a group";
+            return 1;
+        }
+        const int pitch = out_pitch ? out_pitch[g] : A[g];
+        if (pitch < A[g]) { g_error = "mms_marl_heads_finish: out_pitch below the output width"; return 1; }
+        const float* sd = std ? std[g] : nullptr;
+        int64_t* cnt = (sd && counters) ? counters[g] : nullptr;
+        for (int64_t r = 0; r < M; r++) {
+            float mean, m2;
+            chan_combine(part[g], M, r, slots, mean, m2);
+            const float rstd = 1.0f / sqrtf(m2 / (64.f * (float)slots) + eps);
+            const int64_t c = cnt ? cnt[r] : 0;
+            for (int j = 0; j < A[g]; j++) {
+                float dot = 0.f;
+                for (int k = 0; k < slots; k++) dot += head_part[g][((size_t)k * M + r) * 16 + j];
+                const float mu = rstd * (dot - mean * hs[g][j]) + hc[g][j];
+                if (!sd) { out[g][r * pitch + j] = mu; continue; }
+                const float z = mms::rand_normal(seed + (uint64_t)g, (uint64_t)(row_offset + r), (uint64_t)c, (uint32_t)j);
+                out[g][r * pitch + j] = mu + sd[j] * z;
+                if (logp && logp[g]) logp[g][r * pitch + j] = -0.5f * z * z - logf(sd[j]) - 0.9189385332046727f;
+            }
+            if (cnt) cnt[r] = c + 1;
         }
     }
     return 0;

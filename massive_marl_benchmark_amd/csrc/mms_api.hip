@@ -484,26 +484,105 @@ __attribute__((visibility("default"))) int mms_split_planes(int device, int64_t 
     return 0;
 }
 
+__attribute__((visibility("default"))) int mms_split_planes_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch,
+                                                                  const float* const* x, void* const* planes, void* s) {
+    MMS_DEV(device)
+    if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_split_planes_group: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
+    if (x_pitch == 0) x_pitch = K;
+    if (!x || !planes || rows < 0 || K <= 0 || x_pitch < K) { g_create_error = "mms_split_planes_group: bad arguments (x_pitch >= K)"; return 1; }
+    mms::SplitPlanesArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !planes[g] || (reinterpret_cast<uintptr_t>(planes[g]) & 15) != 0 || (reinterpret_cast<uintptr_t>(x[g]) & 3) != 0) {
+            g_create_error = "mms_split_planes_group: null or misaligned pointer in a group (planes 16-byte aligned)";
+            return 1;
+        }
+        a.x[g] = x[g]; a.planes[g] = planes[g];
+    }
+    a.rows = rows; a.K = K; a.x_pitch = x_pitch;
+    MMS_FREE(mms::launch_split_planes_group(a, groups, (hipStream_t)s));
+    return 0;
+}
+
 __attribute__((visibility("default"))) int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x,
                                                                       const void* const* w, const float* const* b, void* const* y, int32_t act,
-                                                                      int32_t out_planes, void* s) {
+                                                                      int32_t out_mode, const float* const* ln_s, const float* const* ln_stat_in,
+                                                                      float* const* ln_part_out, const float* const* head_w, float* const* head_part,
+                                                                      int32_t head_dim, void* s) {
     MMS_DEV(device)
     if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_linear_group_act_split: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
-    if (!x || !w || !b || !y || M < 0 || M > 0x7fffffff || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3) {
-        g_create_error = "mms_linear_group_act_split: bad arguments (M and N multiples of 128, act 0..3)";
+    if (!x || !w || !b || M < 0 || M > 0x7fffffff || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3 || out_mode < 0 || out_mode > 2 ||
+        (out_mode != 2 && !y)) {
+        g_create_error = "mms_linear_group_act_split: bad arguments (M and N multiples of 128, act 0..3, out_mode 0..2)";
+        return 1;
+    }
+    const bool ln = ln_s || ln_stat_in || ln_part_out;
+    if (ln && (!ln_s || !ln_stat_in || !ln_part_out || act != 1 || out_mode == 0)) {
+        g_create_error = "mms_linear_group_act_split: the LayerNorm folds come together (ln_s, ln_stat_in, ln_part_out), with act = ELU and out_mode 1 or 2";
+        return 1;
+    }
+    if (out_mode == 2 && (!ln || !head_w || !head_part || head_dim < 1 || head_dim > 16)) {
+        g_create_error = "mms_linear_group_act_split: out_mode 2 needs the LayerNorm folds, head_w, head_part and 1 <= head_dim <= 16";
         return 1;
     }
     mms::SplitLinearArgs a = {};
     for (int g = 0; g < groups; g++) {
-        if (!x[g] || !w[g] || !b[g] || !y[g]) { g_create_error = "mms_linear_group_act_split: null pointer in a group"; return 1; }
-        if (((reinterpret_cast<uintptr_t>(x[g]) | reinterpret_cast<uintptr_t>(w[g]) | reinterpret_cast<uintptr_t>(y[g]) | reinterpret_cast<uintptr_t>(b[g])) & 15) != 0) {
-            g_create_error = "mms_linear_group_act_split: operands must be 16-byte aligned";
+        if (!x[g] || !w[g] || !b[g] || (out_mode != 2 && !y[g]) || (ln && (!ln_s[g] || !ln_stat_in[g] || !ln_part_out[g])) ||
+            (out_mode == 2 && (!head_w[g] || !head_part[g]))) {
+            g_create_error = "mms_linear_group_act_split: null pointer in a group";
             return 1;
         }
-        a.x[g] = x[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.y[g] = y[g];
+        uintptr_t bits = reinterpret_cast<uintptr_t>(x[g]) | reinterpret_cast<uintptr_t>(w[g]) | reinterpret_cast<uintptr_t>(b[g]);
+        if (out_mode != 2) bits |= reinterpret_cast<uintptr_t>(y[g]);
+        if (ln) bits |= reinterpret_cast<uintptr_t>(ln_s[g]) | (reinterpret_cast<uintptr_t>(ln_stat_in[g]) << 1) | (reinterpret_cast<uintptr_t>(ln_part_out[g]) << 1);
+        if ((bits & 15) != 0) { g_create_error = "mms_linear_group_act_split: operands must be 16-byte aligned"; return 1; }
+        a.x[g] = x[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.y[g] = out_mode != 2 ? y[g] : nullptr;
+        if (ln) { a.s[g] = ln_s[g]; a.stat_in[g] = ln_stat_in[g]; a.part_out[g] = ln_part_out[g]; }
+        if (out_mode == 2) { a.head_w[g] = head_w[g]; a.head_part[g] = head_part[g]; }
     }
-    a.M = (int)M; a.N = N; a.KC = (K + 31) / 32; a.act = act; a.out_planes = out_planes ? 1 : 0;
+    a.M = (int)M; a.N = N; a.KC = (K + 31) / 32; a.act = act; a.out_mode = out_mode; a.head_dim = out_mode == 2 ? head_dim : 0;
     MMS_FREE(mms::launch_linear_split(a, groups, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_row_stats_chan_group(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part,
+                                                                    float* const* stat, float eps, void* s) {
+    MMS_DEV(device)
+    if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_row_stats_chan_group: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
+    if (!part || !stat || M < 0 || slots < 1) { g_create_error = "mms_row_stats_chan_group: bad arguments"; return 1; }
+    mms::RowStatsArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!part[g] || !stat[g]) { g_create_error = "mms_row_stats_chan_group: null pointer in a group"; return 1; }
+        a.part[g] = part[g]; a.stat[g] = stat[g];
+    }
+    a.M = M; a.slots = slots; a.width = 64 * slots; a.eps = eps;
+    MMS_FREE(mms::launch_row_stats_chan(a, groups, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_marl_heads_finish(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part,
+                                                                 const float* const* head_part, const float* const* hs, const float* const* hc,
+                                                                 const int32_t* A, const float* const* std, float* const* out, float* const* logp,
+                                                                 const int32_t* out_pitch, int64_t* const* counters, uint64_t seed, int64_t row_offset,
+                                                                 float eps, void* s) {
+    MMS_DEV(device)
+    if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_marl_heads_finish: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
+    if (!part || !head_part || !hs || !hc || !A || !out || M < 0 || slots < 1) { g_create_error = "mms_marl_heads_finish: bad arguments"; return 1; }
+    mms::HeadsFinishArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!part[g] || !head_part[g] || !hs[g] || !hc[g] || !out[g] || A[g] < 1 || A[g] > 16) {
+            g_create_error = "mms_marl_heads_finish: null pointer or output width outside 1..16 in a group";
+            return 1;
+        }
+        a.part[g] = part[g]; a.head_part[g] = head_part[g]; a.hs[g] = hs[g]; a.hc[g] = hc[g]; a.out[g] = out[g];
+        a.std[g] = std ? std[g] : nullptr;
+        a.logp[g] = logp ? logp[g] : nullptr;
+        a.counters[g] = counters ? counters[g] : nullptr;
+        a.A[g] = A[g];
+        a.out_pitch[g] = out_pitch ? out_pitch[g] : A[g];
+        if (a.out_pitch[g] < A[g]) { g_create_error = "mms_marl_heads_finish: out_pitch below the output width"; return 1; }
+    }
+    a.seed = seed; a.M = M; a.row_offset = row_offset; a.slots = slots; a.width = 64 * slots; a.eps = eps;
+    MMS_FREE(mms::launch_marl_heads_finish(a, groups, (hipStream_t)s));
     return 0;
 }
 

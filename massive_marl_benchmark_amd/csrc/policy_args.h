@@ -80,10 +80,53 @@ struct SplitLinearArgs {
     void* y[kMaxGroups];
     int M, N, KC;       // KC = ceil(K / 32) chunks per row
     int act;            // as LinearArgs::act
-    int out_planes;
+    int out_mode;       // 0: y_g f32 [M, N]; 1: y_g P32 planes; 2: no y_g, only head_part (needs the LayerNorm folds)
+    // LayerNorm folds (all NULL: none; given: all three, act = ELU) -- the meaning of LinearArgs::s / stat_in, and
+    //   part_out[g][(slot * M + row) * 2 + {0, 1}] = (sum, sum of squared deviations from the slot's own mean) of the row's 64
+    //   activations in slot = column / 64 (launch_row_stats_chan combines the slots; two-pass form: no cancellation)
+    const float* s[kMaxGroups];
+    const float* stat_in[kMaxGroups];
+    float* part_out[kMaxGroups];
+    // out_mode 2: head_w[g] [head_dim, N] f32 (the output head's weight, the last LayerNorm's gamma folded in);
+    //   head_part[g][(slot * M + row) * 16 + j] = sum over the slot's 64 columns of y[row, n] head_w[j, n], j < head_dim <= 16
+    const float* head_w[kMaxGroups];
+    float* head_part[kMaxGroups];
+    int head_dim;
+    int tiles;          // (set by the launcher) output tiles of the launch: the persistent grid walks them
+};
+
+// The finish of an output head whose dot products a split layer left as per-slot partials (SplitLinearArgs::head_part), with the last
+// LayerNorm folded: dot_j = sum over slots of head_part, (mean, rstd) of the row from the slots' (sum, M2) pairs (part), and
+// out[r, j] = rstd (dot_j - mean hs[j]) + hc[j]   (hs = head_w 1, hc = w beta + b), then the Gaussian sample exactly as HeadsArgs.
+struct HeadsFinishArgs {
+    const float* part[kMaxGroups];          // [slots, M, 2]
+    const float* head_part[kMaxGroups];     // [slots, M, 16]
+    const float* hs[kMaxGroups];            // [A_g]
+    const float* hc[kMaxGroups];            // [A_g]
+    const float* std[kMaxGroups];
+    float* out[kMaxGroups];
+    float* logp[kMaxGroups];
+    int64_t* counters[kMaxGroups];
+    int A[kMaxGroups];
+    int out_pitch[kMaxGroups];
+    uint64_t seed;
+    int64_t M, row_offset;
+    int slots, width;                       // width = slots * 64 = the hidden size
+    float eps;
+};
+
+// P32 planes of `groups` matrices of the same shape in one launch (x_g rows at pitch x_pitch floats)
+struct SplitPlanesArgs {
+    const float* x[kMaxGroups];
+    void* planes[kMaxGroups];
+    int64_t rows;
+    int K, x_pitch;
 };
 
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
+hipError_t launch_row_stats_chan(const RowStatsArgs& a, int groups, hipStream_t s);
+hipError_t launch_marl_heads_finish(const HeadsFinishArgs& a, int groups, hipStream_t s);
+hipError_t launch_split_planes_group(const SplitPlanesArgs& a, int groups, hipStream_t s);
 hipError_t launch_linear_split(const SplitLinearArgs& a, int groups, hipStream_t s);
 hipError_t launch_split_planes(const float* x, void* planes, int64_t rows, int K, int x_pitch, hipStream_t s);
 hipError_t launch_row_stats(const RowStatsArgs& a, int groups, hipStream_t s);

@@ -589,6 +589,65 @@ __global__ void __launch_bounds__(256) row_stats_kernel(RowStatsArgs a) {
     reinterpret_cast<float2*>(a.stat[g])[row] = make_float2(mean, 1.0f / sqrtf(var + a.eps));
 }
 
+// The same from slot partials in the two-pass form the split layers leave: (sum, M2 about the slot's own mean) of 64 activations per
+// slot, combined with Chan's formula -- no E[x^2] - mean^2 cancellation however large the row's mean is against its spread.
+__device__ __forceinline__ void chan_combine(const float2* part, int64_t M, int64_t row, int slots, float& mean, float& m2) {
+    float sum = 0.f;
+    for (int k = 0; k < slots; k++) sum += part[(size_t)k * M + row].x;
+    mean = sum / (64.f * (float)slots);
+    m2 = 0.f;
+    for (int k = 0; k < slots; k++) {
+        const float2 p = part[(size_t)k * M + row];
+        const float d = p.x * (1.f / 64.f) - mean;
+        m2 += p.y + 64.f * d * d;
+    }
+}
+
+__global__ void __launch_bounds__(256) row_stats_chan_kernel(RowStatsArgs a) {
+    const int g = blockIdx.y;
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.M) return;
+    float mean, m2;
+    chan_combine(reinterpret_cast<const float2*>(a.part[g]), a.M, row, a.slots, mean, m2);
+    reinterpret_cast<float2*>(a.stat[g])[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)a.width + a.eps));
+}
+
+hipError_t launch_row_stats_chan(const RowStatsArgs& a, int groups, hipStream_t s) {
+    if (a.M == 0 || groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(row_stats_chan_kernel, dim3((unsigned)((a.M + 255) / 256), groups), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// thread = (row, network): finishes the output head of the last split layer (HeadsFinishArgs) and samples as marl_heads_kernel does
+__global__ void __launch_bounds__(256) marl_heads_finish_kernel(HeadsFinishArgs a) {
+    const int g = blockIdx.y;
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.M) return;
+    float mean, m2;
+    chan_combine(reinterpret_cast<const float2*>(a.part[g]), a.M, row, a.slots, mean, m2);
+    const float rstd = 1.0f / sqrtf(m2 / (float)a.width + a.eps);
+    const int A = a.A[g];
+    float* out = a.out[g] + row * a.out_pitch[g];
+    const int64_t c = (a.std[g] && a.counters[g]) ? a.counters[g][row] : 0;
+    for (int j = 0; j < A; j++) {
+        float dot = 0.f;
+        for (int k = 0; k < a.slots; k++) dot += a.head_part[g][((size_t)k * a.M + row) * 16 + j];
+        const float mu = rstd * (dot - mean * a.hs[g][j]) + a.hc[g][j];
+        if (a.std[g] == nullptr) { out[j] = mu; continue; }
+        const float sd = a.std[g][j];
+        const float z = rand_normal(a.seed + (uint64_t)g, (uint64_t)(a.row_offset + row), (uint64_t)c, (uint32_t)j);
+        out[j] = mu + sd * z;
+        if (a.logp[g]) a.logp[g][row * a.out_pitch[g] + j] = -0.5f * z * z - logf(sd) - 0.9189385332046727f;
+    }
+    if (a.std[g] && a.counters[g]) a.counters[g][row] = c + 1;
+}
+
+hipError_t launch_marl_heads_finish(const HeadsFinishArgs& a, int groups, hipStream_t s) {
+    if (a.M == 0 || groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(marl_heads_finish_kernel, dim3((unsigned)((a.M + 255) / 256), groups), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_row_stats(const RowStatsArgs& a, int groups, hipStream_t s) {
     if (a.M == 0 || groups == 0) return hipSuccess;
     hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((a.M + 255) / 256), groups), dim3(256), 0, s, a);

@@ -103,7 +103,7 @@ def check_abi_error_paths(L, device):
     fails(L.mms_linear_group_act(device, 0, 8, 8, 8, one, one, one, one, 1, None, None, None, None), contains="groups")
     fails(L.mms_linear_group_act(device, 33, 8, 8, 8, one, one, one, one, 1, None, None, None, None), contains="groups")
     fails(L.mms_linear_group_act(device, 1, 8, 8, 8, one, (vp * 1)(None), one, one, 1, None, None, None, None), contains="null")
-    fails(L.mms_linear_group_act_split(device, 1, 100, 128, 32, one, one, one, one, 1, 0, None), contains="128")
+    fails(L.mms_linear_group_act_split(device, 1, 100, 128, 32, one, one, one, one, 1, 0, None, None, None, None, None, 0, None), contains="128")
     fails(L.mms_split_planes(device, 8, 8, 4, zp, zp, None))
     fails(L.mms_split_planes(device, 8, 8, 8, None, zp, None))
     fails(L.mms_layernorm_group(device, 0, 8, 8, 8, 8, one, one, one, one, 1e-5, None), contains="groups")

@@ -300,12 +300,12 @@ def test_split_operand_layers_on_cpu_build():
         assert L.mms_split_planes(-1, M, K, 0, p(x[g]), p(xp[g]), None) == 0 and L.mms_split_planes(-1, N, K, 0, p(w[g]), p(wp[g]), None) == 0
     for planes_out in (1, 0):
         ys = [torch.empty(nbytes(M, N) if planes_out else M * N * 4, dtype=torch.uint8) for _ in range(2)]
-        assert L.mms_linear_group_act_split(-1, 2, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), 1, planes_out, None) == 0, _lib.last_error(None, L)
+        assert L.mms_linear_group_act_split(-1, 2, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), 1, planes_out, None, None, None, None, None, 0, None) == 0, _lib.last_error(None, L)
         for g in range(2):
             out = join(ys[g], M, N)[0] if planes_out else ys[g].view(torch.float32).view(M, N)
             ref = torch.nn.functional.elu(torch.nn.functional.linear(x[g].double(), w[g].double(), b[g].double()))
             assert float((out.double() - ref).abs().max()) < 2e-6
-    assert L.mms_linear_group_act_split(-1, 1, 100, 128, 32, arr(xp[:1]), arr(wp[:1]), arr(b[:1]), arr(ys[:1]), 1, 0, None) != 0
+    assert L.mms_linear_group_act_split(-1, 1, 100, 128, 32, arr(xp[:1]), arr(wp[:1]), arr(b[:1]), arr(ys[:1]), 1, 0, None, None, None, None, None, 0, None) != 0
     assert "multiples of 128" in _lib.last_error(None, L)
     # the module on the CPU build
     from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic

@@ -1178,7 +1178,7 @@ def test_split_layers_error(torch_cuda):
             _lib.check(L.mms_split_planes(0, M, K, 0, p(x[g]), p(xp[g]), stream), None, "split x")
             _lib.check(L.mms_split_planes(0, N, K, 0, p(w[g]), p(wp[g]), stream), None, "split w")
         ys = [torch.full((_p32_bytes(M, N) if planes_out else M * N * 4,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(G)]
-        rc = L.mms_linear_group_act_split(0, G, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), act, planes_out, stream)
+        rc = L.mms_linear_group_act_split(0, G, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), act, planes_out, None, None, None, None, None, 0, stream)
         assert rc == 0, _lib.last_error(None)
         y32 = [torch.empty(M, N, device="cuda") for _ in range(G)]
         for g in range(G):
@@ -1209,7 +1209,7 @@ def test_split_layers_error(torch_cuda):
                 _lib.check(L.mms_split_planes(0, 128, N, 0, p(w2[g]), p(w2p[g]), stream), None, "split w2")
             y2 = [torch.empty(M, 128, device="cuda") for _ in range(G)]
             b2 = [torch.zeros(128, device="cuda") for _ in range(G)]
-            assert L.mms_linear_group_act_split(0, G, M, 128, N, arr(ys), arr(w2p), arr(b2), arr(y2), 0, 0, stream) == 0
+            assert L.mms_linear_group_act_split(0, G, M, 128, N, arr(ys), arr(w2p), arr(b2), arr(y2), 0, 0, None, None, None, None, None, 0, stream) == 0
             torch.cuda.synchronize()
             for g in range(G):
                 h = _planes_to_f32(torch, ys[g], M, N)[0]
@@ -1220,10 +1220,10 @@ def test_split_layers_error(torch_cuda):
     z = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
     zb = torch.zeros(256, device="cuda")
     one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
-    assert L.mms_linear_group_act_split(0, 1, 100, 128, 32, one(z), one(z), one(zb), one(z), 1, 0, stream) != 0
-    assert L.mms_linear_group_act_split(0, 1, 128, 100, 32, one(z), one(z), one(zb), one(z), 1, 0, stream) != 0
-    assert L.mms_linear_group_act_split(0, 0, 128, 128, 32, one(z), one(z), one(zb), one(z), 1, 0, stream) != 0
-    assert L.mms_linear_group_act_split(0, 1, 128, 128, 32, one(z), (ctypes.c_void_p * 1)(None), one(zb), one(z), 1, 0, stream) != 0
+    assert L.mms_linear_group_act_split(0, 1, 100, 128, 32, one(z), one(z), one(zb), one(z), 1, 0, None, None, None, None, None, 0, stream) != 0
+    assert L.mms_linear_group_act_split(0, 1, 128, 100, 32, one(z), one(z), one(zb), one(z), 1, 0, None, None, None, None, None, 0, stream) != 0
+    assert L.mms_linear_group_act_split(0, 0, 128, 128, 32, one(z), one(z), one(zb), one(z), 1, 0, None, None, None, None, None, 0, stream) != 0
+    assert L.mms_linear_group_act_split(0, 1, 128, 128, 32, one(z), (ctypes.c_void_p * 1)(None), one(zb), one(z), 1, 0, None, None, None, None, None, 0, stream) != 0
     assert "null pointer" in _lib.last_error(None)
 
 

@@ -27,7 +27,7 @@ for N, planes in ((1024, 1), (512, 0), (1024, 0)):
         b = [torch.zeros(N, device="cuda") for _ in range(2)]
         y = [torch.empty(nb(M, N) if planes else M * N * 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
         px, pw, pb, py = arr(xp), arr(wp), arr(b), arr(y)
-        fn = lambda: L.mms_linear_group_act_split(d, 2, M, N, K, px, pw, pb, py, 1, planes, stream)
+        fn = lambda: L.mms_linear_group_act_split(d, 2, M, N, K, px, pw, pb, py, 1, planes, None, None, None, None, None, 0, stream)
         for _ in range(10):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

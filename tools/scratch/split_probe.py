@@ -67,7 +67,7 @@ def main():
         px, pw, pb, py = ptrs(xp), ptrs(wp), ptrs(bs), ptrs(ysp)
 
         def runsp():
-            _lib.check(L.mms_linear_group_act_split(d, 2, M, N, K, px, pw, pb, py, 1, out_planes, stream), what="split layer", L=L)
+            _lib.check(L.mms_linear_group_act_split(d, 2, M, N, K, px, pw, pb, py, 1, out_planes, None, None, None, None, None, 0, stream), what="split layer", L=L)
         run32()
         runsp()
         if dev.type == "cuda":
