@@ -629,15 +629,31 @@ __global__ void __launch_bounds__(256) marl_heads_finish_kernel(HeadsFinishArgs 
     const int A = a.A[g];
     float* out = a.out[g] + row * a.out_pitch[g];
     const int64_t c = (a.std[g] && a.counters[g]) ? a.counters[g][row] : 0;
-    for (int j = 0; j < A; j++) {
-        float dot = 0.f;
-        for (int k = 0; k < a.slots; k++) dot += a.head_part[g][((size_t)k * a.M + row) * 16 + j];
-        const float mu = rstd * (dot - mean * a.hs[g][j]) + a.hc[g][j];
-        if (a.std[g] == nullptr) { out[j] = mu; continue; }
-        const float sd = a.std[g][j];
-        const float z = rand_normal(a.seed + (uint64_t)g, (uint64_t)(a.row_offset + row), (uint64_t)c, (uint32_t)j);
-        out[j] = mu + sd * z;
-        if (a.logp[g]) a.logp[g][row * a.out_pitch[g] + j] = -0.5f * z * z - logf(sd) - 0.9189385332046727f;
+    float dots[16];                                                      // a row's partials of one slot are 64 contiguous bytes: 16-byte loads
+#pragma unroll
+    for (int j = 0; j < 16; j++) dots[j] = 0.f;
+    const float4* hp = reinterpret_cast<const float4*>(a.head_part[g]);
+    for (int k = 0; k < a.slots; k++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (4 * q < A) {
+                const float4 v = hp[((size_t)k * a.M + row) * 4 + q];
+                dots[4 * q] += v.x; dots[4 * q + 1] += v.y; dots[4 * q + 2] += v.z; dots[4 * q + 3] += v.w;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (j < A) {
+            const float mu = rstd * (dots[j] - mean * a.hs[g][j]) + a.hc[g][j];
+            if (a.std[g] == nullptr) {
+                out[j] = mu;
+            } else {
+                const float sd = a.std[g][j];
+                const float z = rand_normal(a.seed + (uint64_t)g, (uint64_t)(a.row_offset + row), (uint64_t)c, (uint32_t)j);
+                out[j] = mu + sd * z;
+                if (a.logp[g]) a.logp[g][row * a.out_pitch[g] + j] = -0.5f * z * z - logf(sd) - 0.9189385332046727f;
+            }
+        }
     }
     if (a.std[g] && a.counters[g]) a.counters[g][row] = c + 1;
 }
