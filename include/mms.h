@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define MMS_ABI_VERSION 2
+#define MMS_ABI_VERSION 3
 #define MMS_DR_FLOATS 33       /* per-ant physical domain-randomisation block, see mms_set_dr */
 
 enum mms_task { MMS_TASK_TEN_ANT = 0, MMS_TASK_ONE_ANT = 1, MMS_TASK_MULTI_INGENUITY = 2 };
