@@ -161,6 +161,20 @@ static void host_ant_env(const mms_config* C, const HostBufs& b, int env, int do
         tt[0] = bgx; tt[1] = bgy; tt[2] = B.qx; tt[3] = B.qy; tt[4] = B.qz; tt[5] = B.qw; tt[6] = 0.f; tt[7] = 0.f;
         prev_env[4 * A] = bgx; prev_env[4 * A + 1] = bgy;
         tenant_reward_finish(C, A, s_red.data(), B.qx, B.qy, B.qz, B.qw, progress, rew, rs);
+    } else if (task == MMS_TASK_MULTI_ANT_CIRCLE) {
+        std::vector<CircleLaneOut> o(nl);
+        for (int t = 0; t < nl; t++) {
+            int ant = t >> 2;
+            o[t] = circle_obs_reward_lane(C, L[t], S[t], ant, t & 3, origin, act0[t], act1[t], prev_env[2 * ant], prev_env[2 * ant + 1], s_obs.data());
+        }
+        for (int q = 0; q < nl; q += 4) {
+            float e[4] = {o[q].ec, o[q + 1].ec, o[q + 2].ec, o[q + 3].ec}, l[4] = {o[q].lim, o[q + 1].lim, o[q + 2].lim, o[q + 3].lim},
+                  c[4] = {o[q].acost, o[q + 1].acost, o[q + 2].acost, o[q + 3].acost};
+            float* r = s_red.data() + RP_STRIDE * (q >> 2);
+            r[RP_ADR] = o[q].rk; r[RP_UP] = o[q].up; r[RP_EC] = quad4(e); r[RP_LIM] = quad4(l); r[RP_FALLEN] = o[q].fallen; r[RP_ACOST] = quad4(c);
+            prev_env[2 * (q >> 2)] = o[q].px; prev_env[2 * (q >> 2) + 1] = o[q].py;
+        }
+        circle_reward_finish(C, A, s_red.data(), progress, rew, rs);
     } else {
         float pot_in = prev_env[4];
         OneAntLaneOut o[4];

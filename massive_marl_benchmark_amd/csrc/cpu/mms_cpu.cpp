@@ -87,12 +87,14 @@ MMS_API int mms_create(const mms_config* cfg, mms_handle* out) {
     if (cfg->num_envs <= 0 || cfg->num_agents <= 0) return fail(nullptr, "mms_create: num_envs and num_agents must be positive");
     if (cfg->task == MMS_TASK_MULTI_INGENUITY && cfg->num_agents != 4) return fail(nullptr, "mms_create: MultiIngenuity has 4 helicopters per env");
     if (cfg->task == MMS_TASK_ONE_ANT && cfg->num_agents != 1) return fail(nullptr, "mms_create: OneAnt has one ant per env");
+    if (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE && cfg->num_agents != 2) return fail(nullptr, "mms_create: MultiAntCircle has two ants per env");
     if (cfg->task != MMS_TASK_MULTI_INGENUITY && cfg->num_agents > 126) return fail(nullptr, "mms_create: at most 126 ants per env");
     mms_engine* e = new mms_engine();
     e->cfg = *cfg;
     const int N = cfg->num_envs, A = cfg->num_agents;
     if (cfg->task == MMS_TASK_TEN_ANT) { e->actors = A + 1; e->dofs = 8 * A; e->num_actions = 8 * A; e->obs_dim = 38 * A + 8; e->prev_dim = 4 * A + 2; }
     else if (cfg->task == MMS_TASK_ONE_ANT) { e->actors = 2; e->dofs = 8; e->num_actions = 8; e->obs_dim = 60; e->prev_dim = 6; }
+    else if (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE) { e->actors = A + 1; e->dofs = 8 * A; e->num_actions = 8 * A; e->obs_dim = 38 * A; e->prev_dim = 2 * A; }
     else if (cfg->task == MMS_TASK_MULTI_INGENUITY) { e->actors = A; e->dofs = 4 * A; e->num_actions = 6 * A; e->obs_dim = 13 * A; e->prev_dim = 3 * A; }
     else { delete e; return fail(nullptr, "mms_create: unknown task"); }
     add_buffer(e, "actions", MMS_F32, {N, e->num_actions});
@@ -127,6 +129,9 @@ MMS_API int mms_create(const mms_config* cfg, mms_handle* out) {
             for (int k = 0; k < A; k++) {
                 float off = (A == 1) ? 0.f : (1.5f + 3.f * (float)(k / 2)) * ((k % 2 == 0) ? -1.f : 1.f);
                 r[13 * k + 0] = cfg->ant_start_x; r[13 * k + 1] = off; r[13 * k + 2] = cfg->ant_start_z;
+                if (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE) {                       // multi_ant_circle.py:216-219: (3, 0, 1) and (-3, 0, 1)
+                    r[13 * k + 0] = (k % 2 == 0) ? cfg->ant_start_x : -cfg->ant_start_x; r[13 * k + 1] = 0.f;
+                }
             }
             for (int j = 0; j < 3; j++) r[13 * A + j] = cfg->box_start[j];
         } else {
@@ -151,6 +156,8 @@ MMS_API int mms_create(const mms_config* cfg, mms_handle* out) {
         } else if (cfg->task == MMS_TASK_ONE_ANT) {
             pv[0] = r[0] + o[0]; pv[1] = r[1] + o[1]; pv[2] = r[13] + o[0]; pv[3] = r[14] + o[1];
             pv[4] = -4.f / cfg->dt; pv[5] = -4.f / cfg->dt;
+        } else if (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE) {
+            for (int k = 0; k < A; k++) { pv[2 * k] = r[13 * k] + o[0]; pv[2 * k + 1] = r[13 * k + 1] + o[1]; }   // multi_ant_circle.py:367-368
         }
     }
     memcpy(buf<float>(e, "root_states"), init, find(e, "root_states")->bytes);

@@ -129,6 +129,7 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
     if (cfg->device >= ndev) return fail(nullptr, "mms_create: device ordinal out of range");
     if (cfg->task == MMS_TASK_MULTI_INGENUITY && cfg->num_agents != 4) return fail(nullptr, "mms_create: MultiIngenuity has 4 helicopters per env");
     if (cfg->task == MMS_TASK_ONE_ANT && cfg->num_agents != 1) return fail(nullptr, "mms_create: OneAnt has one ant per env");
+    if (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE && cfg->num_agents != 2) return fail(nullptr, "mms_create: MultiAntCircle has two ants per env");
     if (cfg->task != MMS_TASK_MULTI_INGENUITY && ((4 * cfg->num_agents + 7) & ~7) + 8 > 512)
         return fail(nullptr, "mms_create: at most 126 ants per env");
     DeviceGuard guard(cfg->device);
@@ -139,6 +140,7 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
     const int N = cfg->num_envs, A = cfg->num_agents;
     if (cfg->task == MMS_TASK_TEN_ANT) { e->actors = A + 1; e->dofs = 8 * A; e->num_actions = 8 * A; e->obs_dim = 38 * A + 8; e->prev_dim = 4 * A + 2; }
     else if (cfg->task == MMS_TASK_ONE_ANT) { e->actors = 2; e->dofs = 8; e->num_actions = 8; e->obs_dim = 60; e->prev_dim = 6; }
+    else if (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE) { e->actors = A + 1; e->dofs = 8 * A; e->num_actions = 8 * A; e->obs_dim = 38 * A; e->prev_dim = 2 * A; }
     else if (cfg->task == MMS_TASK_MULTI_INGENUITY) { e->actors = A; e->dofs = 4 * A; e->num_actions = 6 * A; e->obs_dim = 13 * A; e->prev_dim = 3 * A; }
     else { delete e; return fail(nullptr, "mms_create: unknown task"); }
     int rc = 0;
@@ -174,6 +176,9 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
             for (int k = 0; k < A; k++) {                                        // ten_ant.py:339-358 / one_ant.py:234
                 float off = (A == 1) ? 0.f : (1.5f + 3.f * (float)(k / 2)) * ((k % 2 == 0) ? -1.f : 1.f);
                 r[13 * k + 0] = cfg->ant_start_x; r[13 * k + 1] = off; r[13 * k + 2] = cfg->ant_start_z;
+                if (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE) {                       // multi_ant_circle.py:216-219: (3, 0, 1) and (-3, 0, 1)
+                    r[13 * k + 0] = (k % 2 == 0) ? cfg->ant_start_x : -cfg->ant_start_x; r[13 * k + 1] = 0.f;
+                }
             }
             for (int j = 0; j < 3; j++) r[13 * A + j] = cfg->box_start[j];       // ten_ant.py:494-495
         } else {
@@ -202,6 +207,8 @@ __attribute__((visibility("default"))) int mms_create(const mms_config* cfg, mms
         } else if (cfg->task == MMS_TASK_ONE_ANT) {
             pv[0] = r[0] + o[0]; pv[1] = r[1] + o[1]; pv[2] = r[13] + o[0]; pv[3] = r[14] + o[1];
             pv[4] = -4.f / cfg->dt; pv[5] = -4.f / cfg->dt;                       // one_ant.py:143-144
+        } else if (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE) {
+            for (int k = 0; k < A; k++) { pv[2 * k] = r[13 * k] + o[0]; pv[2 * k + 1] = r[13 * k + 1] + o[1]; }   // multi_ant_circle.py:367-368
         }
     }
     hipError_t he = hipSuccess;

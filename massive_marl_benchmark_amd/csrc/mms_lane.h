@@ -1114,6 +1114,68 @@ MMS_HD void tenant_reward_finish(const mms_config* C, int A, const float* s_red,
     reset = rs;
 }
 
+// MultiAntCircle (multi_ant_circle.py:385-543; INTENDED semantics, see include/mms.h): the 38 observation entries per ant are
+// TenAnt's (target = origin); the per-ant reward pieces of one leg lane.  rk rides in the RP_ADR slot of the reduction scratch.
+MMS_HD float circle_angle(float a, float b) {                  // compute_angle (:385-398): degrees in [0, 360)
+    float deg = fabsf(atan2f(b, a) * 180.f / 3.141592653589793f);
+    return (b < 0.f) ? 360.f + (-1.f) * deg : deg;
+}
+struct CircleLaneOut { float rk, up, fallen, ec, lim, acost; float px, py; };
+MMS_HD CircleLaneOut circle_obs_reward_lane(const mms_config* C, const LegConst& L, const AntLane& S, int ant, int leg, V3 origin,
+                                            float act0, float act1, float pbx, float pby, float* s_obs) {
+    CircleLaneOut o;
+    V3 p = S.pos + origin;                                   // global frame
+    AntObsCore c = ant_obs_core(p, S.qx, S.qy, S.qz, S.qw, S.vel, S.ang);
+    float* row = s_obs + 38 * ant;
+    if (leg == 0) {
+        row[0] = p.x; row[1] = p.y; row[2] = p.z;
+        row[3] = c.vel_loc.x; row[4] = c.vel_loc.y; row[5] = c.vel_loc.z;
+        row[6] = c.angvel_loc.x; row[7] = c.angvel_loc.y; row[8] = c.angvel_loc.z;
+        row[9] = c.yaw; row[10] = c.roll; row[11] = c.angle_to_target; row[12] = c.up_proj; row[13] = c.heading_proj;
+    }
+    float act[2] = {act0, act1};
+    o.ec = 0.f; o.lim = 0.f; o.acost = 0.f;
+    for (int j = 0; j < 2; j++) {
+        float us = unscale1(S.q[j], L.lower[j], L.upper[j]);
+        float dv = S.qd[j] * C->dof_vel_scale;
+        row[14 + 2 * leg + j] = us;
+        row[22 + 2 * leg + j] = dv;
+        row[30 + 2 * leg + j] = act[j];
+        o.ec += fabsf(act[j] * dv);
+        o.lim += (us > 0.99f) ? 1.f : 0.f;
+        o.acost += act[j] * act[j];
+    }
+    float sgn = (ant % 2 == 0) ? 1.f : -1.f;                 // pos_2 = -obs_buf_2[:, :2] (:428); its cached position is not negated (:431)
+    float px = sgn * p.x, py = sgn * p.y;
+    float dist = sqrtf(px * px + py * py);
+    float ang = circle_angle(px, py), ang_before = circle_angle(pbx, pby);
+    bool on = (ang - ang_before > 0.f) && (dist >= 2.7f) && (dist <= 3.3f);
+    o.rk = (on ? 2.f : 0.f) + ((on ? 1.f : 0.f) - 1.f);
+    o.up = (c.up_proj > 0.93f) ? (0.f + C->up_weight) : 0.f;
+    o.fallen = (p.z < C->termination_height) ? 1.f : 0.f;
+    o.px = p.x; o.py = p.y;
+    return o;
+}
+MMS_HD void circle_reward_finish(const mms_config* C, int A, const float* s_red, int64_t progress, float& rew, int64_t& reset) {
+    float rk = 0.f, up = 0.f, ec = 0.f, acost = 0.f, lim = 0.f;
+    bool fallen = false;
+    for (int k = 0; k < A; k++) {
+        const float* r = s_red + RP_STRIDE * k;
+        rk = (k == 0) ? r[RP_ADR] : rk + r[RP_ADR];
+        up = (k == 0) ? r[RP_UP] : up + r[RP_UP];
+        ec = (k == 0) ? r[RP_EC] : ec + r[RP_EC];
+        acost = (k == 0) ? r[RP_ACOST] : acost + r[RP_ACOST];
+        lim += r[RP_LIM];
+        fallen = fallen || (r[RP_FALLEN] != 0.f);
+    }
+    float total = up + rk - C->actions_cost * acost - C->energy_cost * ec - lim * C->joints_at_limit_cost;
+    if (fallen) total = C->death_cost;
+    int64_t rs = fallen ? 1 : 0;
+    if (progress >= (int64_t)C->max_episode_length - 1) rs = 1;
+    rew = total;
+    reset = rs;
+}
+
 // OneAnt (one_ant.py:465-627): the four leg lanes fill the 60-wide row; lane 0 computes the reward.
 struct OneAntLaneOut { float ec, lim, acost; };
 MMS_HD OneAntLaneOut oneant_obs_lane(const mms_config* C, const LegConst& L, const AntLane& S, int leg, V3 origin,

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     float* s_stage = s_obs + obs_pad;              // [prev_dim][3 origin][2 progress][2 reset_count]
     // The clamped actions go straight into their slots of the observation row (ten_ant.py:1346, one_ant.py:615) and are
     // read back from there by the substeps: no registers held across the physics loop for them.
-    float* s_act = s_obs + (TASK == MMS_TASK_TEN_ANT ? 38 * ant + 30 + 2 * leg : 52 + 2 * leg);
+    float* s_act = s_obs + (TASK != MMS_TASK_ONE_ANT ? 38 * ant + 30 + 2 * leg : 52 + 2 * leg);
 
     const int actors = A + 1;
     const bool reset_now = a.reset[env] != 0;
@@ -445,6 +445,29 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
             if (a.rew_out) a.rew_out[env_e] = rew;
             if (a.done_out) a.done_out[env_e] = (uint8_t)rs;
         }
+    } else if (TASK == MMS_TASK_MULTI_ANT_CIRCLE) {   // two ants on the ring, no box in the scene (the box lead only finishes the reward)
+        if (is_ant) {
+            const float pbx = s_stage[2 * ant], pby = s_stage[2 * ant + 1];
+            const float act0 = s_act[0], act1 = s_act[1];
+            CircleLaneOut o = circle_obs_reward_lane(C, L, S, ant, leg, origin, act0, act1, pbx, pby, s_obs);
+            float ec = quad_sum(o.ec), lim = quad_sum(o.lim), ac = quad_sum(o.acost);
+            if (leg == 0) {
+                float* r = s_red + RP_STRIDE * ant;
+                r[RP_ADR] = o.rk; r[RP_UP] = o.up; r[RP_EC] = ec; r[RP_LIM] = lim; r[RP_FALLEN] = o.fallen; r[RP_ACOST] = ac;
+            }
+            if (leg == 0 && live) { prev_env[2 * ant] = o.px; prev_env[2 * ant + 1] = o.py; }   // multi_ant_circle.py:382-383
+        }
+        __syncthreads();
+        if (box_lead && live) {
+            float rew;
+            int64_t rs;
+            circle_reward_finish(C, A, s_red, progress, rew, rs);
+            a.rew[env_e] = rew;
+            a.reset[env_e] = rs;
+            a.progress[env_e] = progress;
+            if (a.rew_out) a.rew_out[env_e] = rew;
+            if (a.done_out) a.done_out[env_e] = (uint8_t)rs;
+        }
     } else {  // OneAnt: the four leg lanes stage their reward partials, the box lead finishes
         if (is_ant) {
             const float act0 = s_act[0], act1 = s_act[1];
@@ -656,6 +679,7 @@ hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {
     }
     const int lpe = ((4 * a.num_agents + 7) & ~7) + 8;        // lanes one env needs
     if (task == MMS_TASK_ONE_ANT) return (a.packing != 0) ? launch_ant<MMS_TASK_ONE_ANT, 64, 4, 1>(a, stream) : launch_ant<MMS_TASK_ONE_ANT, 64, 1, 1>(a, stream);
+    if (task == MMS_TASK_MULTI_ANT_CIRCLE) return launch_ant<MMS_TASK_MULTI_ANT_CIRCLE, 64, 1, 0>(a, stream);   // 16 lanes per env: one env per wave
     if (task != MMS_TASK_TEN_ANT) return hipErrorInvalidValue;
     // TenAnt, two packed layouts.  <192,4>: 4 envs per block, the third wave half ant lanes / half box lanes -- many small blocks,
     // best while there are fewer than 16 envs per CU.  <768,16>: 16 envs per block = ten pure ant waves + two pure box waves, one

@@ -17,7 +17,7 @@ import math
 import xml.etree.ElementTree as ET
 
 MMS_ABI_VERSION = 3
-TASK_IDS = {"TenAnt": 0, "OneAnt": 1, "MultiIngenuity": 2}
+TASK_IDS = {"TenAnt": 0, "OneAnt": 1, "MultiIngenuity": 2, "MultiAntCircle": 3}
 
 
 class MmsModel(ctypes.Structure):
@@ -243,7 +243,9 @@ def build_model(task, num_agents, dt, substeps, gravity):
 # tests check this dict against the reference YAML when the reference tree is present.
 # ----------------------------------------------------------------------------------------------
 def default_cfg(task):
-    name, spacing = {"TenAnt": ("ten_ant", 40), "OneAnt": ("one_ant", 5), "MultiIngenuity": ("multi_ingenuity", 2.5)}[task]
+    # (MultiAntCircle ships no YAML in the reference: the keys its constructor reads, multi_ant_circle.py:33-52, with TenAnt's values)
+    name, spacing = {"TenAnt": ("ten_ant", 40), "OneAnt": ("one_ant", 5), "MultiIngenuity": ("multi_ingenuity", 2.5),
+                     "MultiAntCircle": ("multi_ant_circle", 10)}[task]
     dr_prop = lambda rng, op, dist: {"range": rng, "operation": op, "distribution": dist}
     return {
         "env": {
@@ -296,7 +298,7 @@ def make_config(task, cfg=None, num_envs=None, num_agents=None, device=0, seed=0
     env, sim = cfg["env"], cfg["sim"]
     n = int(num_envs if num_envs is not None else env["numEnvs"])
     if num_agents is None:
-        num_agents = {"TenAnt": 10, "OneAnt": 1, "MultiIngenuity": 4}[task]
+        num_agents = {"TenAnt": 10, "OneAnt": 1, "MultiIngenuity": 4, "MultiAntCircle": 2}[task]
     c = MmsConfig()
     c.abi_version = MMS_ABI_VERSION
     c.task = TASK_IDS[task]
@@ -320,7 +322,12 @@ def make_config(task, cfg=None, num_envs=None, num_agents=None, device=0, seed=0
     # ten_ant.py:55-59 / one_ant.py:56-60
     c.quat_reward_scale = 1.0 if task == "OneAnt" else 0.0
     c.ant_dist_reward_scale = c.goal_dist_reward_scale = 500.0
-    if task == "OneAnt":
+    if task == "MultiAntCircle":
+        # two ants at (+-3, 0, 1) (multi_ant_circle.py:216-219); the scene has no box: the engine's box actor rests far outside any
+        # ant's reach (env-local y = 1000 m; collisions are per env) and never enters an observation or the reward
+        c.ant_start_x, c.ant_start_z = 3.0, 1.0
+        c.box_start[0], c.box_start[1], c.box_start[2] = 0.0, 1000.0, 0.5
+    elif task == "OneAnt":
         c.ant_start_x, c.ant_start_z = -6.0, 1.0
         c.box_start[0], c.box_start[1], c.box_start[2] = -4.0, 0.0, 1.0
     else:
@@ -354,4 +361,6 @@ def task_dims(task, num_agents):
         return a + 1, 8 * a, 8 * a, 38 * a + 8, 4 * a + 2
     if task == "OneAnt":
         return 2, 8, 8, 60, 6
+    if task == "MultiAntCircle":
+        return a + 1, 8 * a, 8 * a, 38 * a, 2 * a
     return a, 4 * a, 6 * a, 13 * a, 3 * a

@@ -1,11 +1,13 @@
 """parse_task (agents/utils/parse_task.py:25-93): builds (task, env) for the 'Python' and 'MultiAgent' task types."""
 from ..tasks.agent_base.multi_vec_task import MultiVecTaskPython
 from ..tasks.agent_base.vec_task import VecTaskPython
+from ..tasks.multi_ant_circle import MultiAntCircle
 from ..tasks.multi_ingenuity import MultiIngenuity
 from ..tasks.one_ant import OneAnt
 from ..tasks.ten_ant import TenAnt
 
-_TASKS = {"TenAnt": TenAnt, "OneAnt": OneAnt, "MultiIngenuity": MultiIngenuity}
+# (MultiAntCircle is not registered in the reference's parse_task.py:8-10 -- it cannot be imported there; here it can be asked for)
+_TASKS = {"TenAnt": TenAnt, "OneAnt": OneAnt, "MultiIngenuity": MultiIngenuity, "MultiAntCircle": MultiAntCircle}
 
 
 def parse_task(args, cfg, cfg_train, sim_params, agent_index=None):

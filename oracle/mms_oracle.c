@@ -372,6 +372,60 @@ MO_EXPORT void mo_tenant_reward_batch(int64_t n, const float* obs /*[n][10][38]*
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* MultiAntCircle (multi_ant_circle.py:385-502), INTENDED semantics: the reference's functions   */
+/* cannot run (numpy on tensors, bool arithmetic); pinned by tests/golden/circle_reward.npz,      */
+/* generated from a patched temp copy (tests/golden/make_circle_fixture.py lists the patches).    */
+/* ------------------------------------------------------------------------------------------ */
+/* compute_angle (:385-398): degrees in [0, 360), measured from +x through +y */
+static float circle_angle(float a, float b) {
+    float deg = fabsf(atan2f(b, a) * 180.f / 3.141592653589793f);
+    return (b < 0.f) ? 360.f + (-1.f) * deg : deg;
+}
+/* one env: obs [2][38], actions [16], pos_before [2][2] (the caches: obs[k][0:2] of the previous step) */
+static void circle_reward(const reward_params* rp, const float* obs, const float* actions, const float* pos_before,
+                          int64_t reset_in, int64_t progress, float* rew_out, int64_t* reset_out) {
+    float rew = 0.f, up_reward = 0.f, actions_cost = 0.f, electricity = 0.f;
+    int lim = 0, fallen = 0;
+    for (int k = 0; k < 2; k++) {
+        const float* o = obs + 38 * k;
+        float sgn = (k == 0) ? 1.f : -1.f;                          /* pos_2 = -obs_buf_2[:, :2] (:428); pos_before_2 is NOT negated (:431) */
+        float px = sgn * o[0], py = sgn * o[1];
+        float dist = sqrtf(px * px + py * py);                      /* per-env norm: the reading of np.linalg.norm(pos) */
+        float ang = circle_angle(px, py), ang_before = circle_angle(pos_before[2 * k], pos_before[2 * k + 1]);
+        int on = (ang - ang_before > 0.f) && (dist >= 2.7f) && (dist <= 3.3f);
+        float rk = (on ? 2.f : 0.f) + ((on ? 1.f : 0.f) - 1.f);      /* (b) * 2 + ((b) - 1) */
+        rew = (k == 0) ? rk : rew + rk;
+        float ur = (o[12] > 0.93f) ? (0.f + rp->up_weight) : 0.f;
+        up_reward = (k == 0) ? ur : up_reward + ur;
+        float ac = 0.f, ec = 0.f;
+        for (int j = 0; j < 8; j++) {
+            ac += actions[8 * k + j] * actions[8 * k + j];
+            ec += fabsf(actions[8 * k + j] * o[22 + j]);
+            lim += (o[14 + j] > 0.99f) ? 1 : 0;
+        }
+        actions_cost = (k == 0) ? ac : actions_cost + ac;
+        electricity = (k == 0) ? ec : electricity + ec;
+        fallen = fallen || (o[2] < rp->termination_height);
+    }
+    float total = up_reward + rew - rp->actions_cost * actions_cost - rp->energy_cost * electricity - (float)lim * rp->joints_at_limit_cost;
+    if (fallen) total = rp->death_cost;
+    int64_t reset = fallen ? 1 : reset_in;
+    if (progress >= (int64_t)rp->max_episode_length - 1) reset = 1;
+    *rew_out = total;
+    *reset_out = reset;
+}
+MO_EXPORT void mo_circle_reward_batch(int64_t n, const float* obs /*[n][2][38]*/, const int64_t* reset_in, const int64_t* progress,
+                                      const float* actions /*[n][16]*/, const float* pos_before /*[n][2][2]*/,
+                                      const float* scal /*up_weight, heading_weight, actions_cost, energy_cost, joints_at_limit_cost, termination_height, death_cost, max_len*/,
+                                      float* rew, int64_t* reset, float* angle_1) {
+    reward_params rp = {scal[0], scal[1], scal[2], scal[3], scal[4], scal[5], scal[6], 0.f, 0.f, 0.f, (int32_t)scal[7]};
+    for (int64_t i = 0; i < n; i++) {
+        circle_reward(&rp, obs + 76 * i, actions + 16 * i, pos_before + 4 * i, reset_in[i], progress[i], rew + i, reset + i);
+        if (angle_1) angle_1[i] = circle_angle(obs[76 * i], obs[76 * i + 1]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* OneAnt (one_ant.py:563-627 obs, :465-560 reward)                                            */
 /* ------------------------------------------------------------------------------------------ */
 MO_EXPORT void mo_oneant_obs(const float root[13], const float box_root[13], const float dof_pos[8],
@@ -1158,7 +1212,7 @@ static void heli_substep(const mms_model* M, real h, real root[13], const real t
 static void physics_core(const mms_config* c, int A, const float* act_in, real* roots, real* dofs, real* sensors, const float* dr) {
     const mms_model* M = &c->model;
     const real h = (real)c->dt / (real)c->substeps;
-    if (c->task == MMS_TASK_TEN_ANT || c->task == MMS_TASK_ONE_ANT) {
+    if (c->task == MMS_TASK_TEN_ANT || c->task == MMS_TASK_ONE_ANT || c->task == MMS_TASK_MULTI_ANT_CIRCLE) {
         for (int s = 0; s < c->substeps; s++) {
             real* br = roots + 13 * A;
             box_pose box;
@@ -1195,7 +1249,7 @@ MO_EXPORT void mo_physics_f64(const mms_config* c, int64_t n, const float* actio
                               const float* sens_in, const float* dr, const int64_t* reset, double* root_out, double* dof_out,
                               double* sens_out) {
     int A = c->num_agents;
-    int ant = (c->task == MMS_TASK_TEN_ANT || c->task == MMS_TASK_ONE_ANT);
+    int ant = (c->task == MMS_TASK_TEN_ANT || c->task == MMS_TASK_ONE_ANT || c->task == MMS_TASK_MULTI_ANT_CIRCLE);
     int actors = ant ? A + 1 : A, dofs = ant ? 8 * A : 4 * A, nact = ant ? 8 * A : 6 * A;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; i++) {
@@ -1226,7 +1280,7 @@ typedef struct mo_engine {
     int dr_enabled;
 } mo_engine;
 
-static int is_ant_task(int task) { return task == MMS_TASK_TEN_ANT || task == MMS_TASK_ONE_ANT; }
+static int is_ant_task(int task) { return task == MMS_TASK_TEN_ANT || task == MMS_TASK_ONE_ANT || task == MMS_TASK_MULTI_ANT_CIRCLE; }
 
 /* global-frame copy of a root row: position + env origin, rest unchanged */
 static void to_global(const float* root_local, const float* origin, float out[13]) {
@@ -1253,6 +1307,9 @@ static void init_prev_from_initial(mo_engine* e, int i) {
         to_global(r0, org, g); pv[0] = g[0]; pv[1] = g[1];
         to_global(r0 + 13, org, g); pv[2] = g[0]; pv[3] = g[1];
         pv[4] = -4.f / c->dt; pv[5] = -4.f / c->dt;                       /* one_ant.py:143-144 */
+    } else if (c->task == MMS_TASK_MULTI_ANT_CIRCLE) {
+        float g[13];                                                      /* multi_ant_circle.py:367-368 on the first step */
+        for (int k = 0; k < e->A; k++) { to_global(r0 + 13 * k, org, g); pv[2 * k] = g[0]; pv[2 * k + 1] = g[1]; }
     }
 }
 
@@ -1263,8 +1320,8 @@ MO_EXPORT mo_engine* mo_create(const mms_config* cfg) {
     int N = e->N = cfg->num_envs, A = e->A = cfg->num_agents;
     if (is_ant_task(cfg->task)) {
         e->actors = A + 1; e->dofs_per_env = 8 * A; e->num_actions = 8 * A;
-        e->obs_dim = (cfg->task == MMS_TASK_TEN_ANT) ? 38 * A + 8 : 60;
-        e->prev_dim = (cfg->task == MMS_TASK_TEN_ANT) ? 4 * A + 2 : 6;  /* OneAnt: pos_before, box_before, potentials, prev_potentials */
+        e->obs_dim = (cfg->task == MMS_TASK_TEN_ANT) ? 38 * A + 8 : (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE ? 38 * A : 60);
+        e->prev_dim = (cfg->task == MMS_TASK_TEN_ANT) ? 4 * A + 2 : (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE ? 2 * A : 6);  /* OneAnt: pos_before, box_before, potentials, prev_potentials */
     } else {
         e->actors = A; e->dofs_per_env = 4 * A; e->num_actions = 6 * A; e->obs_dim = 13 * A; e->prev_dim = 3 * A;
     }
@@ -1299,6 +1356,9 @@ MO_EXPORT mo_engine* mo_create(const mms_config* cfg) {
             for (int k = 0; k < A; k++) {
                 float off = (A == 1) ? 0.f : (1.5f + 3.f * (float)(k / 2)) * ((k % 2 == 0) ? -1.f : 1.f);
                 r[13 * k + 0] = cfg->ant_start_x; r[13 * k + 1] = off; r[13 * k + 2] = cfg->ant_start_z;
+                if (cfg->task == MMS_TASK_MULTI_ANT_CIRCLE) {             /* multi_ant_circle.py:216-219: (3, 0, 1) and (-3, 0, 1) */
+                    r[13 * k + 0] = (k % 2 == 0) ? cfg->ant_start_x : -cfg->ant_start_x; r[13 * k + 1] = 0.f;
+                }
             }
             for (int j = 0; j < 3; j++) r[13 * A + j] = cfg->box_start[j];
         } else {
@@ -1410,6 +1470,16 @@ static void post_step_env(mo_engine* e, int i, int first_step) {
         for (int k = 0; k < A; k++) { pv[2 * k] = obs[38 * k]; pv[2 * k + 1] = obs[38 * k + 1]; }   /* :906-926 */
         memcpy(pv + 2 * A, goals, (size_t)2 * A * 4);
         pv[4 * A] = bp[0]; pv[4 * A + 1] = bp[1];
+    } else if (c->task == MMS_TASK_MULTI_ANT_CIRCLE) {
+        float g[13];
+        for (int k = 0; k < A; k++) {                                      /* :322-341: the 38 entries of TenAnt's ants, target = origin */
+            to_global(roots + 13 * k, org, g);
+            float dp[8], dv[8];
+            for (int j = 0; j < 8; j++) { dp[j] = dofs[2 * (8 * k + j)]; dv[j] = dofs[2 * (8 * k + j) + 1]; }
+            mo_tenant_ant_obs(g, dp, dv, M->dof_lower, M->dof_upper, c->dof_vel_scale, act + 8 * k, obs + 38 * k);
+        }
+        circle_reward(&rp, obs, act, pv, e->reset[i], e->progress[i], e->rew + i, e->reset + i);
+        for (int k = 0; k < A; k++) { pv[2 * k] = obs[38 * k]; pv[2 * k + 1] = obs[38 * k + 1]; }   /* :382-383 */
     } else if (c->task == MMS_TASK_ONE_ANT) {
         float g[13], gb[13], dp[8], dv[8];
         to_global(roots, org, g);

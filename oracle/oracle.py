@@ -49,6 +49,7 @@ def lib():
         _lib.mo_tenant_obs_batch.argtypes = [c64, F, F, F, F, F, cf, F, F]
         _lib.mo_tenant_goals_batch.argtypes = [c64, F, F, F, F, F, F]
         _lib.mo_tenant_reward_batch.argtypes = [c64, F, I64, I64, F, F, F, F, F, F, F, I64]
+        _lib.mo_circle_reward_batch.argtypes = [c64, F, I64, I64, F, F, F, F, I64, F]
         _lib.mo_oneant_obs_batch.argtypes = [c64] + [F] * 12
         _lib.mo_oneant_reward_batch.argtypes = [c64, F, I64, I64, F, F, F, F, F, F, F, F, I64]
         _lib.mo_ingenuity_thrust_batch.argtypes = [c64, F, cf, F]

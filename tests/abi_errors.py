@@ -42,6 +42,8 @@ def check_abi_error_paths(L, device):
     fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="4 helicopters")
     c = cfg("OneAnt"); c.num_agents = 2
     fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="one ant")
+    c = cfg("MultiAntCircle"); c.num_agents = 3
+    fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)), contains="two ants")
     c = cfg(); c.device = 0 if device < 0 else -1                    # the other library's device
     fails(L.mms_create(ctypes.byref(c), ctypes.byref(h)))
     if device >= 0:

@@ -76,7 +76,7 @@ def angle_err(a, b):
 
 def angle_columns(task, num_agents):
     """(columns holding yaw / roll / angle_to_target, per-ant stride) of the observation row."""
-    if task == "TenAnt":
+    if task in ("TenAnt", "MultiAntCircle"):
         return [38 * k + j for k in range(num_agents) for j in (9, 10, 11)]
     if task == "OneAnt":
         return [7, 8, 9]
@@ -415,6 +415,46 @@ def fixture_oneant(make, load_golden, tag):
     np.testing.assert_array_equal(impl.get("reset"), np.where(fallen | (g["progress"] >= 999), 1, 0))
     record(tag + "fixture_oneant_reward", max_abs=e, rows=n, fallen_rows=int(fallen.sum()))
     assert e < 2e-3, e                                                               # 500 x sqrt rounding x 2 terms (oracle test: 5e-4 per term)
+    impl.close()
+
+
+def fixture_circle(make, load_golden, tag):
+    """tests/golden/circle_reward.npz (multi_ant_circle.py:385-543 through a patched temp copy: INTENDED semantics, the reference cannot
+    run this task -- tests/golden/make_circle_fixture.py lists the substitutions) through the MultiAntCircle step: two ants' states in,
+    the 76-wide observation row, the ring reward, the reset flags and the position caches out."""
+    g = load_golden("circle_reward")
+    n = g["root_1"].shape[0]
+    impl = make("MultiAntCircle", cfg=_cfg("MultiAntCircle"), num_envs=n)
+    root = impl.get("root_states").reshape(n, 3, 13).copy()                  # (row 2: the engine's inert box, far away)
+    root[:, 0], root[:, 1] = g["root_1"], g["root_2"]
+    dof = np.stack([np.stack([g["dof_pos_1"], g["dof_vel_1"]], -1), np.stack([g["dof_pos_2"], g["dof_vel_2"]], -1)], 1).reshape(n * 16, 2)
+    prev = np.concatenate([g["pos_before_1"], g["pos_before_2"]], 1).astype(np.float32)
+    impl.put("root_states", root.reshape(n * 3, 13))
+    impl.put("dof_state", dof.astype(np.float32))
+    impl.put("prev", prev)
+    impl.put("reset", np.zeros(n, np.int64))
+    impl.put("progress", (g["progress"] - 1).astype(np.int64))
+    impl.post_step(g["actions"])
+    obs = impl.get("obs")
+    ref = np.concatenate([g["obs1"], g["obs2"]], 1)
+    ang = [9, 10, 11, 38 + 9, 38 + 10, 38 + 11]
+    rest = [i for i in range(76) if i not in ang]
+    e_rest = float(np.max(np.abs(obs[:, rest] - ref[:, rest])))
+    ok = np.ones(n, bool)
+    for q in (g["root_1"][:, 3:7], g["root_2"][:, 3:7]):
+        ok &= np.abs(2.0 * (q[:, 3] * q[:, 1] - q[:, 2] * q[:, 0])) < 0.999
+    e_ang = float(angle_err(obs[ok][:, ang], ref[ok][:, ang]).max())
+    d_rew = np.abs(impl.get("rew") - g["rew"])
+    # the ring reward is a step function of the position (+-3 per ant): rows where torch's atan2 / norm and the implementation's
+    # land on different sides of a threshold are counted, not averaged in
+    flips = int(np.sum(d_rew > 1e-3))
+    e_rew = float(np.max(np.where(d_rew > 1e-3, 0.0, d_rew)))
+    np.testing.assert_array_equal(impl.get("reset"), g["reset"])
+    pv = impl.get("prev")
+    np.testing.assert_array_equal(pv[:, 0:2], obs[:, 0:2])
+    np.testing.assert_array_equal(pv[:, 2:4], obs[:, 38:40])
+    record(tag + "fixture_circle", obs_max_abs=e_rest, angle=e_ang, reward_max_abs=e_rew, reward_threshold_flips=flips, rows=n)
+    assert e_rest < 1e-4 and e_ang < 1e-4 and e_rew < 1e-4 and flips <= 2, (e_rest, e_ang, e_rew, flips)
     impl.close()
 
 

@@ -107,16 +107,16 @@ class CpuImpl:
         self.eng.close()
 
 
-@pytest.mark.parametrize("check", [parity.fixture_tenant_obs, parity.fixture_tenant_goals, parity.fixture_oneant, parity.fixture_ingenuity])
+@pytest.mark.parametrize("check", [parity.fixture_tenant_obs, parity.fixture_tenant_goals, parity.fixture_oneant, parity.fixture_ingenuity, parity.fixture_circle])
 def test_reference_fixtures_through_cpu_build(check):
     check(lambda task, cfg=None, **kw: CpuImpl(task, cfg=cfg, **kw), load_golden, "cpu/")
 
 
-@pytest.mark.parametrize("task,n,steps", [("OneAnt", 64, 100), ("TenAnt", 8, 80), ("MultiIngenuity", 16, 80)])
+@pytest.mark.parametrize("task,n,steps", [("OneAnt", 64, 100), ("TenAnt", 8, 80), ("MultiIngenuity", 16, 80), ("MultiAntCircle", 16, 80)])
 def test_teacher_forced_parity_vs_oracle(task, n, steps):
     """BASELINE configs[0]'s shape (OneAnt, 64 envs) and the other tasks on the CPU build, step for step against the oracle."""
     kw = dict(num_envs=n, seed=5, total_envs=64, env_offset=0)
-    if task == "MultiIngenuity":
+    if task in ("MultiIngenuity", "MultiAntCircle"):      # (both measure their reward in the GLOBAL frame)
         cfg = default_cfg(task)
         cfg["env"]["envSpacing"] = 0.0
         kw["cfg"] = cfg
@@ -251,6 +251,48 @@ def test_marl_wrappers_and_generators_on_cpu_build():
         assert x[0].shape == (mb, 388) and x[1].shape == (mb, 46) and x[4].shape == (mb, 8) and x[5].shape == (mb, 1) and x[10].shape == (mb, 1)
         assert x[11] is None and x[12].shape == (mb, 1)
     env.task.engine.close()
+
+
+def test_multi_ant_circle_wrappers_on_cpu_build():
+    """MultiAntCircle (intended semantics, tasks/multi_ant_circle.py) through both wrappers on the CPU build: the single-agent view
+    (76 observations, 16 actions), the MultiAgent view (two agents x 38, share_obs 76, no shared tail), resets by fall and by time,
+    the ring reward on envs at the global origin, parse_task knows the name."""
+    from massive_marl_benchmark_amd.tasks.agent_base.multi_vec_task import MultiVecTaskPython
+    from massive_marl_benchmark_amd.tasks.agent_base.vec_task import VecTaskPython
+    from massive_marl_benchmark_amd.tasks.multi_ant_circle import MultiAntCircle
+    from massive_marl_benchmark_amd.utils.parse_task import _TASKS
+    assert _TASKS["MultiAntCircle"] is MultiAntCircle
+    cfg = default_cfg("MultiAntCircle")
+    cfg["env"]["numEnvs"], cfg["env"]["envSpacing"], cfg["env"]["episodeLength"] = 16, 0.0, 40
+    task = MultiAntCircle(cfg, None, "physx", "cpu", 0, True)
+    env = VecTaskPython(task, "cpu", 5.0, 1.0)
+    assert env.num_obs == 76 and env.num_acts == 16 and task.root_states.shape == (48, 13) and task.ant_root_states.shape == (16, 2, 13)
+    obs = env.reset()
+    assert obs.shape == (16, 76) and torch.allclose(task.ant_root_states[:, 0, 0], torch.full((16,), 3.0)) and torch.allclose(task.ant_root_states[:, 1, 0], torch.full((16,), -3.0))
+    g = torch.Generator().manual_seed(0)
+    seen_reset, rewards = 0, []
+    for t in range(60):
+        obs, rew, done, _ = env.step(torch.rand(16, 16, generator=g) * 2 - 1)
+        seen_reset += int(done.sum())
+        rewards.append(rew.clone())
+        assert torch.equal(task.prev[:, 0:2], task.obs_buf[:, 0:2]) and torch.equal(task.prev[:, 2:4], task.obs_buf[:, 38:40])
+    assert seen_reset >= 16 and bool(torch.isfinite(torch.stack(rewards)).all())          # every env timed out at least once (40 steps)
+    r = torch.stack(rewards)
+    assert float(r.max()) > 1.5 and float(r.min()) <= -2.0 + 1e-6                           # on-ring bonus seen, deaths seen
+    assert float(task.root_states.view(16, 3, 13)[:, 2, 1].min()) > 900.0                   # the engine's box stayed out of the way
+    task.engine.close()
+    cfg = default_cfg("MultiAntCircle")
+    cfg["env"]["numEnvs"], cfg["clip_observations"] = 8, 7.0
+    task = MultiAntCircle(cfg, None, "physx", "cpu", 0, True, is_multi_agent=True)
+    menv = MultiVecTaskPython(task, "cpu")
+    assert menv.num_agents == 2 and menv.num_observations == 38 and menv.nums_share_observations == 76
+    o, s, _ = menv.reset()
+    oa, sa, ra, da, _, _ = menv.step([torch.rand(8, 8, generator=g) * 2 - 1 for _ in range(2)])
+    assert oa.shape == (8, 2, 38) and sa.shape == (8, 2, 76) and ra.shape == (8, 2, 1) and da.shape == (8, 2)
+    assert torch.equal(oa[:, 1], torch.clamp(task.obs_buf[:, 38:76], -7, 7)) and torch.equal(sa[:, 0], torch.clamp(task.obs_buf, -7, 7))
+    task.engine.close()
+    with pytest.raises(_lib.MmsError, match="two ants"):
+        Engine("MultiAntCircle", num_envs=4, num_agents=3, device="cpu")
 
 
 def test_make_entry_glue():

@@ -57,7 +57,7 @@ STATE = parity.STATE
 def task_kw(task, **kw):
     """MultiIngenuity envs away from the global origin die on every step (the reward measures distances in the GLOBAL frame,
     multi_ingenuity.py:381-453: SURVEY section 0 fact 6): the physics tests keep its envs at the origin."""
-    if task == "MultiIngenuity":
+    if task in ("MultiIngenuity", "MultiAntCircle"):     # (MultiAntCircle's ring is drawn round the GLOBAL origin too: multi_ant_circle.py:424)
         from massive_marl_benchmark_amd.model import default_cfg
         cfg = default_cfg(task)
         cfg["env"]["envSpacing"] = 0.0
@@ -74,7 +74,7 @@ def drive(o, e, tf, act, what):
     tf.after(what)
 
 
-@pytest.mark.parametrize("task,n,steps", [("TenAnt", 6, 120), ("OneAnt", 8, 120), ("MultiIngenuity", 8, 120)])
+@pytest.mark.parametrize("task,n,steps", [("TenAnt", 6, 120), ("OneAnt", 8, 120), ("MultiIngenuity", 8, 120), ("MultiAntCircle", 8, 120)])
 def test_teacher_forced_parity(emu, task, n, steps):
     kw = task_kw(task, num_envs=n, seed=5, total_envs=64, env_offset=3)
     o = OracleEngine(task, **kw)
@@ -234,7 +234,7 @@ class EmuImpl:
         self.e.ref.close()
 
 
-@pytest.mark.parametrize("check", [parity.fixture_tenant_obs, parity.fixture_tenant_goals, parity.fixture_oneant, parity.fixture_ingenuity])
+@pytest.mark.parametrize("check", [parity.fixture_tenant_obs, parity.fixture_tenant_goals, parity.fixture_oneant, parity.fixture_ingenuity, parity.fixture_circle])
 def test_reference_fixtures_through_lanes(emu, check):
     """Every reference fixture of the task functions through the lane code's step path (the CPU rehearsal of the GPU test)."""
     from conftest import load_golden

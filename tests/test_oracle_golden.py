@@ -98,6 +98,38 @@ def test_tenant_reward_golden(olib):
     assert len(np.unique(g["reset"])) == 2 and (g["rew"] == -2.0).any() and (g["rew"] > 100).any()
 
 
+def test_circle_golden(olib):
+    """MultiAntCircle (agents/tasks/multi_ant_circle.py), INTENDED semantics: the reference cannot import the task, the fixtures come
+    from a temp copy with five recorded substitutions (tests/golden/make_circle_fixture.py; the meta string of each .npz lists them).
+    Its observation function is TenAnt's 38 entries; its reward is the ring reward of :400-502."""
+    g = load_golden("circle_obs")
+    assert "INTENDED SEMANTICS" in str(g["meta"]) and "np.linalg.norm" in str(g["meta"])
+    n = g["root"].shape[0]
+    obs = np.zeros((n, 38), np.float32)
+    olib.mo_tenant_obs_batch(n, fp(f32(g["root"])), fp(f32(g["dof_pos"])), fp(f32(g["dof_vel"])), fp(f32(g["dof_lower"])),
+                             fp(f32(g["dof_upper"])), float(0.2), fp(f32(g["actions"])), fp(obs))
+    ang_idx = [9, 10, 11]
+    rest = [i for i in range(38) if i not in ang_idx]
+    assert np.max(np.abs(obs[:, rest] - g["obs"][:, rest])) < TOL
+    q = g["root"][:, 3:7]
+    ok = np.abs(2.0 * (q[:, 3] * q[:, 1] - q[:, 2] * q[:, 0])) < 0.999
+    for i in ang_idx:
+        assert angle_close(obs[ok, i], g["obs"][ok, i], 0) < TOL, i
+    g = load_golden("circle_reward")
+    n = g["obs1"].shape[0]
+    obs2 = f32(np.stack([g["obs1"], g["obs2"]], 1).reshape(n, 76))
+    pb = f32(np.stack([g["pos_before_1"], g["pos_before_2"]], 1).reshape(n, 4))
+    par = g["params"]
+    scal = f32(np.array([par[0], par[1], par[2], par[3], par[4], par[5], par[6], par[7]]))
+    rew, reset, ang = np.zeros(n, np.float32), np.zeros(n, np.int64), np.zeros(n, np.float32)
+    olib.mo_circle_reward_batch(n, fp(obs2), ip(np.zeros(n, np.int64)), ip(i64(g["progress"])), fp(f32(g["actions"])), fp(pb), fp(scal), fp(rew),
+                                ip(reset), fp(ang))
+    np.testing.assert_array_equal(reset, g["reset"])
+    assert np.max(np.abs(ang - g["angle_1"])) < 1e-4                       # degrees
+    assert np.max(np.abs(rew - g["rew"])) < 1e-5                           # (steps of +-3 would show as O(1))
+    assert (g["rew"] == -2.0).any() and (g["rew"] > 3.0).any() and len(np.unique(g["reset"])) == 2
+
+
 def test_oneant_golden(olib):
     g = load_golden("oneant_obs")
     n = g["root"].shape[0]

@@ -22,6 +22,8 @@ def algorithmic_bytes(task, A):
         return 24 * 4 + 2 * 4 * (13 + 8) * 4 + 52 * 4 + 4 + 24
     if task == "OneAnt":
         return 32 + 2 * (13 + 16 + 13) * 4 + 2 * (2 + 2 + 1 + 1) * 4 + 60 * 4 + 4 + 8 + 16
+    if task == "MultiAntCircle":       # two ants, no box in the reference's scene: actions R, state R+W, caches R+W, 76-wide row W, ...
+        return 16 * 4 + 2 * 2 * (13 + 16) * 4 + 2 * 4 * 4 + 76 * 4 + 4 + 8 + 16
     state = A * (13 + 16) + 13
     caches = 4 * A + 2
     return 8 * A * 4 + 2 * state * 4 + 2 * caches * 4 + (38 * A + 8) * 4 + 4 + 8 + 16
@@ -80,6 +82,7 @@ def main():
              ("OneAnt", 64, None),                  # configs[0]'s shape on the GPU engine
              ("OneAnt", 4096, None),
              ("TenAnt", 4096, None),                # configs[1] (sim-only series, for reference beside bench.py)
+             ("MultiAntCircle", 8192, None),        # the task of SURVEY 8(f)3 (intended semantics): generic one-env-per-wave layout
              ("TenAnt", 2048, 100)]                 # configs[4]: 100-ant swarm, 16384 envs over 8 GPUs = 2048 per GPU
     for (task, N, A) in cases:
         if args.only and args.only != task:
