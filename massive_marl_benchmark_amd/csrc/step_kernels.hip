@@ -141,8 +141,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     const bool live = env_raw < a.num_envs;                  // a partial last block still runs every barrier
     const int env = live ? env_raw : a.num_envs - 1;
     const int ant = tid >> 2, leg = tid & 3;
-    const int obs_dim = AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim;
-    const int prev_dim = AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 4 * AT + 2 : 6) : a.prev_dim;
+    constexpr int kObsAT = TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : (TASK == MMS_TASK_MULTI_ANT_CIRCLE ? 38 * AT : 60);
+    constexpr int kPrevAT = TASK == MMS_TASK_TEN_ANT ? 4 * AT + 2 : (TASK == MMS_TASK_MULTI_ANT_CIRCLE ? 2 * AT : 6);
+    const int obs_dim = AT > 0 ? kObsAT : a.obs_dim;
+    const int prev_dim = AT > 0 ? kPrevAT : a.prev_dim;
     const int obs_pad = (obs_dim + 3) & ~3;
 
     // per-leg constants and the box pose live in LDS and are read at the point of use: keeping them in registers
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     // env): the slice comes in as coalesced 16-B loads (nine 1-KB wave transactions for 16 envs) and every lane takes its torso --
     // and the box lead its box -- from LDS, instead of 13 scalar dword loads per lane with four lanes of a quad fetching the same 52
     // bytes (each such wave load touched ~26 cache lines).  The way back is the same: final poses into LDS, coalesced stores out.
-    float* s_root = lds_envs + (size_t)EPB * ((ant_env_lds_floats(AT > 0 ? (TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : 60) : a.obs_dim, A) + 3) & ~(size_t)3);
+    float* s_root = lds_envs + (size_t)EPB * ((ant_env_lds_floats(AT > 0 ? kObsAT : a.obs_dim, A) + 3) & ~(size_t)3);
     // (compile-time layouts whose slice starts and ends on 16 B only; the runtime-sized layouts load and store per lane)
     constexpr bool kStage = AT > 0 && ((EPB * (AT + 1) * 13) % 4) == 0;
     const int root_floats = kStage ? EPB * (A + 1) * 13 : 0;
@@ -679,7 +681,8 @@ hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {
     }
     const int lpe = ((4 * a.num_agents + 7) & ~7) + 8;        // lanes one env needs
     if (task == MMS_TASK_ONE_ANT) return (a.packing != 0) ? launch_ant<MMS_TASK_ONE_ANT, 64, 4, 1>(a, stream) : launch_ant<MMS_TASK_ONE_ANT, 64, 1, 1>(a, stream);
-    if (task == MMS_TASK_MULTI_ANT_CIRCLE) return launch_ant<MMS_TASK_MULTI_ANT_CIRCLE, 64, 1, 0>(a, stream);   // 16 lanes per env: one env per wave
+    // MultiAntCircle: 8 ant + 8 box lanes per env; four envs fill a wave (the packed form OneAnt uses), one env per wave when unpacked
+    if (task == MMS_TASK_MULTI_ANT_CIRCLE) return (a.packing != 0) ? launch_ant<MMS_TASK_MULTI_ANT_CIRCLE, 64, 4, 2>(a, stream) : launch_ant<MMS_TASK_MULTI_ANT_CIRCLE, 64, 1, 0>(a, stream);
     if (task != MMS_TASK_TEN_ANT) return hipErrorInvalidValue;
     // TenAnt, two packed layouts.  <192,4>: 4 envs per block, the third wave half ant lanes / half box lanes -- many small blocks,
     // best while there are fewer than 16 envs per CU.  <768,16>: 16 envs per block = ten pure ant waves + two pure box waves, one
