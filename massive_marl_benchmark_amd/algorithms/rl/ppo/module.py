@@ -81,6 +81,7 @@ class ActorCritic(nn.Module):
     # THIRD of that kernel's error against the float64 product (tests/test_gpu_parity.py::test_split_layers_error).
     # Applies when the batch and every hidden width are multiples of 128; False = the exact-fp32 MFMA kernel (mms_linear2_act).
     split_layers = True
+    split_min_tiles = None  # least number of 128 x 128 output tiles of the widest layer for the split path (None: one per CU)
     fuse_head = True
     two_streams = True      # critic beside the actor on a second stream
     defer_value = False     # opt-in: `act` returns before the critic has finished; the owner calls join() before reading values
@@ -127,8 +128,18 @@ class ActorCritic(nn.Module):
             return planes
         return hit[1]
 
-    def _split_applies(self, M, lins):
-        return self.split_layers and M > 0 and M % 128 == 0 and all(l.out_features % 128 == 0 for l in lins)
+    def _split_applies(self, M, lins, networks=2):
+        """Shapes the split kernel takes (batch and widths multiples of 128) AND is worth taking: the widest layer must give each CU at
+        least one 128 x 128 output tile (`split_min_tiles`: None = the device's CU count) -- below that the kernel's fixed cost per
+        launch (first slice, epilogue: ~7-15 us) outweighs its faster k-steps and the exact-fp32 kernel's 64-row tiles are quicker
+        (PPO demo at 4096 x [256, 128, 128]: 1.07 against 1.34 M env-steps/s end to end)."""
+        if not (self.split_layers and M > 0 and M % 128 == 0 and all(l.out_features % 128 == 0 for l in lins)):
+            return False
+        need = self.split_min_tiles
+        if need is None:
+            dev = lins[0].weight.device
+            need = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 1
+        return max(networks * (M // 128) * (l.out_features // 128) for l in lins) >= need
 
     def _split_hidden(self, nets, inputs, tag):
         """Hidden layers of the networks in `nets` (lists of their hidden Linear layers, the same shapes in every network), one
@@ -336,7 +347,7 @@ class ActorCritic(nn.Module):
             L, idx, stream = _lib.for_device(x.device)
             p = lambda t: ctypes.c_void_p(t.data_ptr())
             h, M = x.contiguous(), x.shape[0]
-            if self._split_applies(M, lin[:-1]) and h.data_ptr() % 16 == 0:
+            if self._split_applies(M, lin[:-1], networks=1) and h.data_ptr() % 16 == 0:
                 h = self._split_hidden([lin[:-1]], [h], "value")[0]
             else:
                 key = (M, str(x.device))

@@ -513,7 +513,10 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(LayerNormArgs a) {
 
 // kHeadRows rows per wave: the output layer's weights ([A, H], at most 64 KB) are staged in LDS once per block and reused by its
 // 4 x kHeadRows rows (read per row straight from L2 they cost 18 KB per row: 202 us per launch against 60 us now, twenty networks).
+// (ROWS = 2 for small launches -- the PPO bootstrap value head, one network x 4096 rows: 128 blocks of 32 rows left half the CUs idle,
+//  18.9 us; with 8 rows per block every CU has two)
 constexpr int kHeadRows = 8;
+template <int ROWS>
 __global__ void __launch_bounds__(256) marl_heads_kernel(HeadsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];          // [A][H]
     const int g = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -531,8 +534,8 @@ __global__ void __launch_bounds__(256) marl_heads_kernel(HeadsArgs a) {
     }
     const float bias = (lane < A) ? a.b[g][lane] : 0.f;
     const float sd = (a.std[g] && lane < A) ? a.std[g][lane] : 0.f;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * kHeadRows;
-    for (int r = 0; r < kHeadRows; r++) {
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * ROWS;
+    for (int r = 0; r < ROWS; r++) {
         const int64_t row = row0 + r;
         if (row >= a.M) return;
         const float* __restrict__ h = a.h[g] + row * H;
@@ -682,8 +685,11 @@ hipError_t launch_marl_heads(const HeadsArgs& a, int groups, hipStream_t s) {
     int amax = 1;
     for (int g = 0; g < groups; g++) amax = a.A[g] > amax ? a.A[g] : amax;
     const size_t lds = (size_t)amax * a.H * sizeof(float);                       // <= 16 x 1024 x 4 = 64 KB
-    const int64_t per_block = 4 * kHeadRows;
-    hipLaunchKernelGGL(marl_heads_kernel, dim3((unsigned)((a.M + per_block - 1) / per_block), groups), dim3(256), lds, s, a);
+    const bool small = (a.M + 4 * kHeadRows - 1) / (4 * kHeadRows) * groups < 512;      // fewer than two blocks per CU at 8 rows per wave
+    const int64_t per_block = 4 * (small ? 2 : kHeadRows);
+    const dim3 grid((unsigned)((a.M + per_block - 1) / per_block), groups);
+    if (small) hipLaunchKernelGGL(marl_heads_kernel<2>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(marl_heads_kernel<kHeadRows>, grid, dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--fixed-lr", action="store_true", help="no adaptive KL schedule")
     ap.add_argument("--value-coef", type=float, default=1.0)
+    ap.add_argument("--exact-fp32-layers", action="store_true",
+                    help="hidden layers on the exact-fp32 MFMA kernel instead of the three-plane split kernel (which applies when batch and hidden widths are multiples of 128)")
     ap.add_argument("--friction-combine", default="average", choices=["average", "min"],
                     help="cfg env.frictionCombine: PhysX's average rule (default) or min = a box that is frictionless against everything")
     args = ap.parse_args()
@@ -54,6 +56,7 @@ def main():
     T, EPOCHS, MINIB, CLIP, GAMMA, LAM, DESIRED_KL, MAX_GRAD = args.nsteps, 5, 4, 0.2, args.gamma, 0.95, 0.016, 1.0
     ac = ActorCritic((obs_dim,), (0,), (act_dim,), 0.8, {"pi_hid_sizes": args.hidden, "vf_hid_sizes": args.hidden, "activation": "elu"},
                      seed=args.seed).to(dev)
+    ac.split_layers = not args.exact_fp32_layers
     storage = RolloutStorage(N, T, (obs_dim,), (0,), (act_dim,), device=str(dev))
     opt = torch.optim.Adam(ac.parameters(), lr=args.lr)
     lr = args.lr
