@@ -551,6 +551,76 @@ __attribute__((visibility("default"))) int mms_linear_group_act_split(int device
     return 0;
 }
 
+// ---- the same with two scaled fp16 planes per operand (split16_kernels.hip) -----------------------------------------------------
+__attribute__((visibility("default"))) int mms_split_planes16_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch,
+                                                                    const float* const* x, void* const* planes, float* const* scale, float* const* inv,
+                                                                    int32_t nchains, int32_t L, const float* const* chain, float* const* chain_scale,
+                                                                    float* const* chain_inv, void* s) {
+    MMS_DEV(device)
+    if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_split_planes16_group: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
+    if (x_pitch == 0) x_pitch = K;
+    if (!x || !planes || !scale || !inv || rows < 0 || K <= 0 || x_pitch < K || nchains < 0 || L < 0 || (nchains > 0 && (L < 1 || !chain || !chain_scale || !chain_inv))) {
+        g_create_error = "mms_split_planes16_group: bad arguments (x_pitch >= K; nchains > 0 needs L >= 1, chain, chain_scale, chain_inv)";
+        return 1;
+    }
+    mms::Split16PlanesArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !planes[g] || (reinterpret_cast<uintptr_t>(planes[g]) & 15) != 0 || (reinterpret_cast<uintptr_t>(x[g]) & 3) != 0 ||
+            (nchains > 0 && (!chain[g] || !chain_scale[g] || !chain_inv[g]))) {
+            g_create_error = "mms_split_planes16_group: null or misaligned pointer in a group (planes 16-byte aligned)";
+            return 1;
+        }
+        a.x[g] = x[g]; a.planes[g] = planes[g]; a.scale[g] = scale[g]; a.inv[g] = inv[g];
+        if (nchains > 0) { a.chain[g] = chain[g]; a.chain_scale[g] = chain_scale[g]; a.chain_inv[g] = chain_inv[g]; }
+    }
+    a.rows = rows; a.K = K; a.x_pitch = x_pitch; a.nchains = nchains; a.L = nchains > 0 ? L : 0;
+    MMS_FREE(mms::launch_split16_planes_group(a, groups, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_linear_group_act_split16(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x,
+                                                                        const void* const* w, const float* const* b, void* const* y,
+                                                                        const float* const* x_inv, const float* const* w_inv, const float* const* y_scale,
+                                                                        int32_t act, int32_t out_mode, const float* const* ln_s,
+                                                                        const float* const* ln_stat_in, float* const* ln_part_out,
+                                                                        const float* const* head_w, float* const* head_part, int32_t head_dim, void* s) {
+    MMS_DEV(device)
+    if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_linear_group_act_split16: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
+    if (!x || !w || !b || !x_inv || !w_inv || M < 0 || M > 0x7fffffff || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3 ||
+        out_mode < 0 || out_mode > 2 || (out_mode != 2 && !y) || (out_mode == 1 && !y_scale)) {
+        g_create_error = "mms_linear_group_act_split16: bad arguments (M and N multiples of 128, act 0..3, out_mode 0..2, x_inv, w_inv, y_scale with out_mode 1)";
+        return 1;
+    }
+    const bool ln = ln_s || ln_stat_in || ln_part_out;
+    if (ln && (!ln_s || !ln_stat_in || !ln_part_out || act != 1 || out_mode == 0)) {
+        g_create_error = "mms_linear_group_act_split16: the LayerNorm folds come together (ln_s, ln_stat_in, ln_part_out), with act = ELU and out_mode 1 or 2";
+        return 1;
+    }
+    if (out_mode == 2 && (!ln || !head_w || !head_part || head_dim < 1 || head_dim > 16)) {
+        g_create_error = "mms_linear_group_act_split16: out_mode 2 needs the LayerNorm folds, head_w, head_part and 1 <= head_dim <= 16";
+        return 1;
+    }
+    mms::Split16LinearArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !w[g] || !b[g] || !x_inv[g] || !w_inv[g] || (out_mode != 2 && !y[g]) || (out_mode == 1 && !y_scale[g]) ||
+            (ln && (!ln_s[g] || !ln_stat_in[g] || !ln_part_out[g])) || (out_mode == 2 && (!head_w[g] || !head_part[g]))) {
+            g_create_error = "mms_linear_group_act_split16: null pointer in a group";
+            return 1;
+        }
+        uintptr_t bits = reinterpret_cast<uintptr_t>(x[g]) | reinterpret_cast<uintptr_t>(w[g]) | reinterpret_cast<uintptr_t>(b[g]) | reinterpret_cast<uintptr_t>(w_inv[g]);
+        if (out_mode != 2) bits |= reinterpret_cast<uintptr_t>(y[g]);
+        if (ln) bits |= reinterpret_cast<uintptr_t>(ln_s[g]) | (reinterpret_cast<uintptr_t>(ln_stat_in[g]) << 1) | (reinterpret_cast<uintptr_t>(ln_part_out[g]) << 1);
+        if ((bits & 15) != 0) { g_create_error = "mms_linear_group_act_split16: operands must be 16-byte aligned"; return 1; }
+        a.x[g] = x[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.y[g] = out_mode != 2 ? y[g] : nullptr;
+        a.xinv[g] = x_inv[g]; a.winv[g] = w_inv[g]; a.yscale[g] = out_mode == 1 ? y_scale[g] : nullptr;
+        if (ln) { a.s[g] = ln_s[g]; a.stat_in[g] = ln_stat_in[g]; a.part_out[g] = ln_part_out[g]; }
+        if (out_mode == 2) { a.head_w[g] = head_w[g]; a.head_part[g] = head_part[g]; }
+    }
+    a.M = (int)M; a.N = N; a.KC = (K + 31) / 32; a.act = act; a.out_mode = out_mode; a.head_dim = out_mode == 2 ? head_dim : 0;
+    MMS_FREE(mms::launch_linear_split16(a, groups, (hipStream_t)s));
+    return 0;
+}
+
 __attribute__((visibility("default"))) int mms_row_stats_chan_group(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part,
                                                                     float* const* stat, float eps, void* s) {
     MMS_DEV(device)

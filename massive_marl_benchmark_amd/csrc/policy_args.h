@@ -123,6 +123,49 @@ struct SplitPlanesArgs {
     int K, x_pitch;
 };
 
+// The same layer with both operands as TWO scaled fp16 planes per fp32 number, format "H32" (split16_kernels.hip): x_g [M, KC, 2, 32] f16
+// holding hi = f16(x xs[row]), lo = f16((x xs[row] - hi) 2^11) with xs[row] a power of two per row; w_g likewise with ws[row].
+//   xinv[g][m] = 1 / xs (f32 [M]), winv[g][n] = 1 / ws (f32 [N]): the epilogue's exact rescaling of the accumulators
+//   yscale[g][m] (out_mode 1): the power of two the output row m is multiplied with before it is split into the y planes
+struct Split16LinearArgs {
+    const void* x[kMaxGroups];
+    const void* w[kMaxGroups];
+    const float* b[kMaxGroups];
+    void* y[kMaxGroups];
+    const float* xinv[kMaxGroups];
+    const float* winv[kMaxGroups];
+    const float* yscale[kMaxGroups];
+    int M, N, KC;
+    int act, out_mode;              // as SplitLinearArgs
+    const float* s[kMaxGroups];     // LayerNorm folds, as SplitLinearArgs
+    const float* stat_in[kMaxGroups];
+    float* part_out[kMaxGroups];
+    const float* head_w[kMaxGroups];
+    float* head_part[kMaxGroups];
+    int head_dim;
+    int tiles;
+};
+
+// H32 planes of `groups` matrices of the same shape (x_g rows at pitch x_pitch floats) with a power-of-two scale per row taken from the
+// row's largest magnitude (scale[g][row], inv[g][row] = 1 / scale), and -- nchains > 0 -- the scales of the layers this row then
+// flows through: chain[g] = [nchains][L][2] (mult, add) with bound_{l+1} = mult_l bound_l + add_l starting from the row's largest
+// magnitude (mult = the layer's largest weight-row 1-norm, add = its largest |bias|; mult = 0 for a layer behind a LayerNorm, whose
+// output bound does not depend on its input), chain_scale[g] / chain_inv[g] = [nchains][L][rows].
+struct Split16PlanesArgs {
+    const float* x[kMaxGroups];
+    void* planes[kMaxGroups];
+    float* scale[kMaxGroups];
+    float* inv[kMaxGroups];
+    const float* chain[kMaxGroups];
+    float* chain_scale[kMaxGroups];
+    float* chain_inv[kMaxGroups];
+    int64_t rows;
+    int K, x_pitch;
+    int nchains, L;
+};
+
+hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, hipStream_t s);
+hipError_t launch_linear_split16(const Split16LinearArgs& a, int groups, hipStream_t s);
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
 hipError_t launch_row_stats_chan(const RowStatsArgs& a, int groups, hipStream_t s);
 hipError_t launch_marl_heads_finish(const HeadsFinishArgs& a, int groups, hipStream_t s);

@@ -1,0 +1,506 @@
+// split16_kernels.hip -- the policy layers Y = act(X W^T + b) with fp32 operands carried as TWO scaled fp16 planes each.
+//
+// The sibling of split_kernels.hip (three bf16 planes, every operand exact).  Here a number is x s = hi + lo 2^-11 with s a power of
+// two per ROW, hi = f16(x s), lo = f16((x s - hi) 2^11): 11 + 11 significant bits and the residual's sign, i.e. the operand is kept
+// to 2^-22 |x| worst case (4e-8 rms) instead of exactly, in 4 bytes instead of 6, and
+//     x w = hi_x hi_w + 2^-11 (hi_x lo_w + lo_x hi_w) + [2^-22 lo_x lo_w <= 2^-24 |x w|, dropped]
+// is THREE v_mfma_f32_16x16x32_f16 products instead of six bf16 ones.  The layers are bound by the L2 -> LDS operand stream (16-18
+// bytes per clock and CU, profiles/r03_split_layer_pmc.txt), so two thirds of the bytes is two thirds of the k-loop, and at 48 KB
+// per 256 x 128 k-step THREE LDS stages fit: the DMA of slice k + 2 is in flight across the barrier of step k + 1 (counted vmcnt,
+// raw s_barrier) instead of every step draining the queue.  Error against the float64 product, measured like the bf16 kernel's
+// (tests/test_gpu_parity.py::test_split16_layers_error): still below the exact-fp32 MFMA kernel's, whose k-ordered fma chain
+// rounds 16 times as often.
+//
+// Why a scale, and why it cannot overflow: fp16 ends at 65504.  Every plane row carries a power of two that puts a BOUND of the
+// row's magnitudes at 2^14: for an input (observation, weight row) the bound is the row's own largest magnitude; for a hidden
+// activation it is a-priori, from the chain |act(W x + b)| <= (max row 1-norm of W) max|x| + max|b| (ELU, ReLU, tanh and the
+// identity all satisfy |act(y)| <= |y|), evaluated per row by the kernel that splits the network's input (split16_planes_kernel:
+// chain / chain_scale).  The products of powers of two are undone exactly in the epilogue.  Elements far below the bound lose
+// nothing that matters: hi goes subnormal 2^-29 below the bound and lo still carries the residual (measured: the error of a layer
+// does not change when the scale is lowered by 2^18).
+//
+// Plane format "H32": [rows][KC][2][32] f16, KC = ceil(K / 32): hi and lo of 32 consecutive k of a row are 128 contiguous bytes
+// (one cache line).  Columns past K are zero.
+//
+// Tiling as split_kernels.hip: 512-thread block = 8 waves (4 (m) x 2 (n)), output tile (64 MT) x 128, the product evaluated
+// transposed (W fragments as the A operand), persistent grid of at most one block per CU.  LDS image of a k-step: the tile's rows
+// at pitch 128 (X rows, then W rows), each row eight 16-byte slots [plane][k-group] with the slot index XORed with (row >> 1) & 7:
+// the sixteen lanes of a ds_read_b128 group (rows 0-3 / 12-15 with k-group g, rows 4-11 with k-group g +- 1) then cover the sixteen
+// slots of the 256-byte bank row exactly once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "policy_args.h"
+
+namespace mms {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChunk16 = 128;                    // one row's two planes of 32 k
+constexpr float kLoScale = 2048.f;               // the lo plane holds the residual times 2^11
+constexpr int kTopExp = 14;                      // a row's bound sits at 2^14 (fp16 ends just below 2^16)
+
+// scale = 2^(14 - e) with bound <= 2^e; an all-zero row keeps scale 1
+__device__ __forceinline__ void pow2_scale(float bound, float& scale, float& inv) {
+    int e = kTopExp;
+    if (bound > 0.f) (void)frexpf(bound, &e);    // bound = f 2^e, 0.5 <= f < 1
+    int sh = kTopExp - e;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    scale = ldexpf(1.f, sh);
+    inv = ldexpf(1.f, -sh);
+}
+
+// ---- fp32 [rows, K] -> H32 planes + per-row scales -----------------------------------------------------------------------------
+// One wave per row, two passes over it (largest magnitude, then the planes): the second pass finds the row in L1 / L2.
+template <bool ALIGNED>
+__global__ void __launch_bounds__(256) split16_planes_kernel(Split16PlanesArgs a, int KC) {
+    const int g = blockIdx.y;
+    const float* __restrict__ x = a.x[g];
+    uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(a.planes[g]);
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;                                          // (wave-uniform)
+    const int K = a.K;
+    const float* src = x + row * (int64_t)a.x_pitch;
+    const int pieces = KC * 4;                                          // 8-element pieces of the row
+    auto load8 = [&](int p, float* v) {
+        const int k0 = p * 8;
+        if (ALIGNED && k0 + 8 <= K) {
+            const float4 q0 = *reinterpret_cast<const float4*>(src + k0), q1 = *reinterpret_cast<const float4*>(src + k0 + 4);
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (k0 + j < K) ? src[k0 + j] : 0.f;
+        }
+    };
+    float big = 0.f;
+    for (int p = lane; p < pieces; p += 64) {
+        float v[8];
+        load8(p, v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) big = fmaxf(big, fabsf(v[j]));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) big = fmaxf(big, __shfl_xor(big, m, 64));
+    float scale, inv;
+    pow2_scale(big, scale, inv);
+    for (int p = lane; p < pieces; p += 64) {
+        float v[8];
+        load8(p, v);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float t = v[j] * scale;
+            hi[j] = (_Float16)t;
+            lo[j] = (_Float16)((t - (float)hi[j]) * kLoScale);
+        }
+        uint8_t* dst = out + (row * KC + (p >> 2)) * (int64_t)kChunk16 + (p & 3) * 16;
+        *reinterpret_cast<f16x8*>(dst) = hi;
+        *reinterpret_cast<f16x8*>(dst + 64) = lo;
+    }
+    if (lane == 0) {
+        if (a.scale[g]) a.scale[g][row] = scale;
+        if (a.inv[g]) a.inv[g][row] = inv;
+    }
+    // the scales of the layers behind this input: one chain per lane
+    for (int c = lane; c < a.nchains; c += 64) {
+        const float* ch = a.chain[g] + (size_t)c * a.L * 2;
+        float bound = big;
+        for (int l = 0; l < a.L; l++) {
+            bound = (ch[2 * l] * bound + ch[2 * l + 1]) * 1.001f;       // (rounding of the bound itself; 2^14 leaves a factor 4 besides)
+            float sc, iv;
+            pow2_scale(bound, sc, iv);
+            a.chain_scale[g][((size_t)c * a.L + l) * a.rows + row] = sc;
+            a.chain_inv[g][((size_t)c * a.L + l) * a.rows + row] = iv;
+        }
+    }
+}
+
+hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, hipStream_t s) {
+    if (a.rows == 0 || groups == 0) return hipSuccess;
+    const int KC = (a.K + 31) / 32;
+    bool aligned = (a.x_pitch % 4) == 0;
+    for (int g = 0; g < groups; g++) aligned = aligned && (reinterpret_cast<uintptr_t>(a.x[g]) & 15) == 0;
+    const dim3 grid((unsigned)((a.rows + 3) / 4), groups);
+    if (aligned) hipLaunchKernelGGL(split16_planes_kernel<true>, grid, dim3(256), 0, s, a, KC);
+    else hipLaunchKernelGGL(split16_planes_kernel<false>, grid, dim3(256), 0, s, a, KC);
+    return hipGetLastError();
+}
+
+// ---- the layer -------------------------------------------------------------------------------------------------------------
+template <int MT>
+struct Geom16 {
+    static constexpr int TM = 64 * MT, TN = 128;
+    static constexpr int XBYTES = TM * kChunk16, WBYTES = TN * kChunk16, BUF = XBYTES + WBYTES;     // 48 KB (MT = 4) / 32 KB (MT = 2)
+    static constexpr int NDMA = BUF / 1024 / 8;                         // 1-KB LDS-DMA instructions per wave and k-step: 6 / 4
+    static constexpr int NX = TM / 64;                                  // ... of which in the X rows (TM / 8 instructions over 8 waves)
+    static constexpr int SCRATCH = 8 * 16 * (2 * kChunk16 + 16);        // epilogue scratch: 8 waves x 16 rows x 272 bytes
+    static constexpr bool SCRATCH_IN_BUF = BUF >= SCRATCH;              // inside the operand buffer the last k-step has just consumed
+    static constexpr int HW_OFF = 3 * BUF + (SCRATCH_IN_BUF ? 0 : SCRATCH);
+    static constexpr size_t LDS = (size_t)HW_OFF + 16 * 128 * 4;        // + the output head's weights [16][128] f32 (out_mode 2)
+};
+
+__device__ __forceinline__ float act16_apply(float v, int act) {
+    if (act == 1) return (v > 0.f) ? v : (expf(v) - 1.f);
+    if (act == 2) return fmaxf(v, 0.f);
+    if (act == 3) return 1.f - 2.f / (__expf(2.f * v) + 1.f);
+    return v;
+}
+
+typedef const __attribute__((address_space(1))) void* gptr16_t;
+typedef __attribute__((address_space(3))) void* lptr16_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// OUT / LN as linear_split_kernel (split_kernels.hip).  The k-loop runs on THREE operand buffers: at the top of step k every wave
+// waits until at most the DMA of slice k + 1 (its own NDMA instructions, the youngest) is outstanding -- slice k has landed --, the
+// raw barrier makes that true for all waves and says that everyone is done reading slice k - 1, whose buffer then takes the DMA of
+// slice k + 2.  Nothing in the loop waits for vmcnt(0) except a tile's last step.
+template <int MT, int OUT, int LN>
+__global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArgs a) {
+    using G = Geom16<MT>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int KC = a.KC, N = a.N;
+    const int tiles_n = N / G::TN, tiles_m = a.M / G::TM, total = a.tiles;
+    const size_t pitch = (size_t)KC * kChunk16;
+
+    // LDS-DMA: instruction c of a k-step fills image bytes [1024 c, + 1024) = eight rows; lane s of it owns the physical 16-byte
+    // slot S = 64 c + s = (row S / 8, slot q = S % 8) and fetches the (plane, k-group) = q ^ ((row >> 1) & 7) that lives there.  Wave w
+    // issues c = w, w + 8, ...: the first NX in the X rows, the rest in the W rows; the source is a uniform base (the tile's first
+    // X / W row at the current k) + a per-lane 32-bit offset that does not depend on the tile.
+    uint32_t goff[G::NDMA];
+#pragma unroll
+    for (int i = 0; i < G::NDMA; i++) {
+        const int S = 64 * (wave + 8 * i) + lane;
+        const int row = S >> 3, c8 = (S & 7) ^ ((row >> 1) & 7);
+        goff[i] = (uint32_t)((i < G::NX ? row : row - G::TM) * (int)pitch + (c8 >> 2) * 64 + (c8 & 3) * 16);
+    }
+    int gi, m0, n0, tn;
+    const uint8_t* xb;
+    const uint8_t* wb;
+    auto setup_tile = [&](int v) {
+        int L = v;
+        if ((total & 7) == 0 && (gridDim.x & 7) == 0) L = (v & 7) * (total >> 3) + (v >> 3);       // XCD-aware: as linear_split_kernel
+        tn = L % tiles_n;
+        const int rest = L / tiles_n;
+        const int tm = rest % tiles_m;
+        gi = rest / tiles_m;
+        m0 = tm * G::TM;
+        n0 = tn * G::TN;
+        xb = reinterpret_cast<const uint8_t*>(a.x[gi]) + (size_t)m0 * pitch;
+        wb = reinterpret_cast<const uint8_t*>(a.w[gi]) + (size_t)n0 * pitch;
+    };
+    auto dma_slice = [&](int kc, int buf) {
+        const uint8_t* xs = xb + (size_t)kc * kChunk16;
+        const uint8_t* ws = wb + (size_t)kc * kChunk16;
+#pragma unroll
+        for (int i = 0; i < G::NDMA; i++)
+            __builtin_amdgcn_global_load_lds((gptr16_t)((i < G::NX ? xs : ws) + goff[i]), (lptr16_t)(lds + buf * G::BUF + (wave + 8 * i) * 1024), 16, 0, 0);
+    };
+
+    // this lane's fragment address inside a buffer: row r16 of a 16-row tile, plane 0, k-group g4; plane 1 is the same address ^ 64
+    const int frag = (lane & 15) * kChunk16 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) * 16);
+    const int xfrag = (wm * 16 * MT) * kChunk16 + frag;                  // + mt * 16 * 128
+    const int wfrag = G::XBYTES + (wn * 64) * kChunk16 + frag;           // + nt * 16 * 128
+
+    // `acc` takes hi hi, `lo` the two cross products (2^11 times their value); added once at the end
+    f32x4 acc[MT][4], lo[MT][4];
+    constexpr bool kDmaBehindFirstTile = MT == 4;
+
+    auto step = [&](int buf, bool more, int kc_next, int buf_next) {
+        const uint8_t* base = lds + buf * G::BUF;
+        if (!kDmaBehindFirstTile && more) dma_slice(kc_next, buf_next);
+        f16x8 wf[4][2];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            wf[nt][0] = *reinterpret_cast<const f16x8*>(base + (wfrag + nt * 16 * kChunk16));
+            wf[nt][1] = *reinterpret_cast<const f16x8*>(base + ((wfrag + nt * 16 * kChunk16) ^ 64));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            f16x8 xf[2];
+            xf[0] = *reinterpret_cast<const f16x8*>(base + (xfrag + mt * 16 * kChunk16));
+            xf[1] = *reinterpret_cast<const f16x8*>(base + ((xfrag + mt * 16 * kChunk16) ^ 64));
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][1], xf[0], lo[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][0], xf[1], lo[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][0], xf[0], acc[mt][nt], 0, 0, 0);
+            if (kDmaBehindFirstTile && mt == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) dma_slice(kc_next, buf_next);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // 16-byte output stores a lane issues per tile BEHIND the next tile's prefetch (the count the next tile's first wait may leave
+    // outstanding besides its own second slice); out_mode 2 stores under a predicate: none counted, the wait then covers them too
+    constexpr int kStores = OUT == 2 ? 0 : MT * 4;
+
+    int v = blockIdx.x;
+    setup_tile(v);
+    int cur = 0;                                      // the buffer slice 0 of the current tile lives in
+    bool stores_in_flight = false;
+    dma_slice(0, 0);
+    if (KC > 1) dma_slice(1, 1);
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < KC; kt++) {
+            const bool ahead = kt + 1 < KC;                             // slice kt + 1 is in flight behind slice kt
+            if (kt == 0 && stores_in_flight) {
+                if (ahead) wait_vm<G::NDMA + kStores>(); else wait_vm<kStores>();
+            } else {
+                if (ahead) wait_vm<G::NDMA>(); else wait_vm<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            const int nxt = cur == 0 ? 2 : cur - 1;                      // (cur + 2) % 3: the buffer step kt - 1 read
+            step(cur, kt + 2 < KC, kt + 2, nxt);
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        const int blast = cur == 0 ? 2 : cur - 1;                        // the buffer the last k-step read
+        __builtin_amdgcn_s_barrier();                                    // ... which becomes the waves' epilogue scratch
+
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));                                // (tile-independent epilogue addresses are re-derived, not kept live across the k-loop)
+        const int r16 = lane_e & 15, g4 = lane_e >> 4;
+        const int e_gi = gi, e_tn = tn;
+        const int mbase = m0 + wm * 16 * MT, nbase = n0 + wn * 64, e_n0 = n0;
+        // the epilogue's operands first: an ordinary load's result is waited for with vmcnt(0), which must not find the next tile's
+        // prefetch in the queue
+        const float* __restrict__ Bv = a.b[e_gi];
+        const float* __restrict__ Wi = a.winv[e_gi];
+        const float* __restrict__ Xi = a.xinv[e_gi];
+        float4 bias[4], wi[4];
+        float xi[MT], ys[MT];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            bias[nt] = *reinterpret_cast<const float4*>(Bv + nbase + 16 * nt + 4 * g4);
+            wi[nt] = *reinterpret_cast<const float4*>(Wi + nbase + 16 * nt + 4 * g4);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            xi[mt] = Xi[mbase + 16 * mt + r16];
+            ys[mt] = OUT == 1 ? a.yscale[e_gi][mbase + 16 * mt + r16] : 1.f;
+        }
+        float4 sv[4];
+        float2 st[MT];
+        if constexpr (LN != 0) {
+            const float* __restrict__ Sv = a.s[e_gi];
+            const float2* __restrict__ stat = reinterpret_cast<const float2*>(a.stat_in[e_gi]);
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) sv[nt] = *reinterpret_cast<const float4*>(Sv + nbase + 16 * nt + 4 * g4);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) st[mt] = stat[mbase + 16 * mt + r16];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            asm volatile("" : "+v"(bias[nt].x), "+v"(bias[nt].y), "+v"(bias[nt].z), "+v"(bias[nt].w), "+v"(wi[nt].x), "+v"(wi[nt].y), "+v"(wi[nt].z), "+v"(wi[nt].w));
+            if constexpr (LN != 0) asm volatile("" : "+v"(sv[nt].x), "+v"(sv[nt].y), "+v"(sv[nt].z), "+v"(sv[nt].w));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            asm volatile("" : "+v"(xi[mt]), "+v"(ys[mt]));
+            if constexpr (LN != 0) asm volatile("" : "+v"(st[mt].x), "+v"(st[mt].y));
+        }
+        const int vnext = v + (int)gridDim.x;
+        const bool has_next = vnext < total;
+        const int nb0 = blast == 2 ? 0 : blast + 1, nb1 = nb0 == 2 ? 0 : nb0 + 1;
+        if (has_next) {                                                 // the next tile's first two slices into the two free buffers
+            setup_tile(vnext);
+            dma_slice(0, nb0);
+            if (KC > 1) dma_slice(1, nb1);
+        }
+        uint8_t* scr_base = lds + (G::SCRATCH_IN_BUF ? blast * G::BUF : 3 * G::BUF);
+        const int act = a.act;
+        // hi hi + 2^-11 cross, the operands' scales undone (powers of two: exact), bias, activation -- in place of the accumulators
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const float wv[4] = {wi[nt].x, wi[nt].y, wi[nt].z, wi[nt].w}, bb[4] = {bias[nt].x, bias[nt].y, bias[nt].z, bias[nt].w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float raw = ((acc[mt][nt][r] + lo[mt][nt][r] * (1.f / kLoScale)) * wv[r]) * xi[mt];
+                    if constexpr (LN == 0) acc[mt][nt][r] = act16_apply(raw + bb[r], act);
+                    else acc[mt][nt][r] = raw;
+                }
+            }
+        if constexpr (LN != 0) {
+            float2* __restrict__ part = reinterpret_cast<float2*>(a.part_out[e_gi]) + (size_t)(2 * e_tn + wn) * a.M;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const int m = mbase + 16 * mt + r16;
+                float sum = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    const float ss[4] = {sv[nt].x, sv[nt].y, sv[nt].z, sv[nt].w}, bb[4] = {bias[nt].x, bias[nt].y, bias[nt].z, bias[nt].w};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float x = st[mt].y * (acc[mt][nt][r] - st[mt].x * ss[r]) + bb[r];
+                        x = (x > 0.f) ? x : (expf(x) - 1.f);
+                        acc[mt][nt][r] = x;
+                        sum += x;
+                    }
+                }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float mean = sum * (1.f / 64.f);
+                float m2 = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const float d = acc[mt][nt][r] - mean; m2 += d * d; }
+                m2 += __shfl_xor(m2, 16, 64);
+                m2 += __shfl_xor(m2, 32, 64);
+                if (g4 == 0) part[m] = make_float2(sum, m2);
+            }
+        }
+        if constexpr (OUT == 2) {
+            const int A = a.head_dim;
+            float* hw = reinterpret_cast<float*>(lds + G::HW_OFF);                           // [A][128], a region of its own
+            const float* __restrict__ HW = a.head_w[e_gi];
+            for (int i = t; i < A * 128; i += 512) hw[i] = HW[(size_t)(i >> 7) * N + e_n0 + (i & 127)];
+            __syncthreads();
+            float keep[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) keep[mt][i] = 0.f;
+            for (int j = 0; j < A; j++) {
+                float4 hj[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) hj[nt] = *reinterpret_cast<const float4*>(hw + j * 128 + wn * 64 + 16 * nt + 4 * g4);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    float p = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++)
+                        p += acc[mt][nt][0] * hj[nt].x + acc[mt][nt][1] * hj[nt].y + acc[mt][nt][2] * hj[nt].z + acc[mt][nt][3] * hj[nt].w;
+                    p += __shfl_xor(p, 16, 64);
+                    p += __shfl_xor(p, 32, 64);
+                    if ((j & 3) == g4) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) if ((j >> 2) == i) keep[mt][i] = p;
+                    }
+                }
+            }
+            float* __restrict__ hp = a.head_part[e_gi] + (size_t)(2 * e_tn + wn) * a.M * 16;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (4 * i + g4 < A) hp[(size_t)(mbase + 16 * mt + r16) * 16 + 4 * i + g4] = keep[mt][i];
+            __syncthreads();                                            // (hw is restaged by the next tile)
+        } else if constexpr (OUT == 1) {
+            constexpr int RS = 2 * kChunk16 + 16;                        // scratch row: this wave's two chunks (64 n) of one m, padded
+            uint8_t* scr = scr_base + wave * (16 * RS);
+            uint8_t* __restrict__ Y = reinterpret_cast<uint8_t*>(a.y[e_gi]);
+            const size_t ypitch = (size_t)(N / 32) * kChunk16;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    f16x4 hi, lw;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float x = acc[mt][nt][r] * ys[mt];
+                        hi[r] = (_Float16)x;
+                        lw[r] = (_Float16)((x - (float)hi[r]) * kLoScale);
+                    }
+                    uint8_t* d = scr + r16 * RS + (nt >> 1) * kChunk16 + (nt & 1) * 32 + g4 * 8;
+                    *reinterpret_cast<f16x4*>(d) = hi;
+                    *reinterpret_cast<f16x4*>(d + 64) = lw;
+                }
+                // 16 rows x 256 bytes back out as 16-byte pieces: 16 per row, contiguous in HBM
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int idx = lane_e + 64 * j, row = idx >> 4, off = (idx & 15) * 16;
+                    const uint4 d = *reinterpret_cast<const uint4*>(scr + row * RS + off);
+                    *reinterpret_cast<uint4*>(Y + (size_t)(mbase + 16 * mt + row) * ypitch + (size_t)(nbase / 32) * kChunk16 + off) = d;
+                }
+            }
+        } else {
+            constexpr int RS = 256 + 16;
+            uint8_t* scr = scr_base + wave * (16 * RS);
+            float* __restrict__ Y = reinterpret_cast<float*>(a.y[e_gi]);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++)
+                    *reinterpret_cast<float4*>(scr + r16 * RS + (16 * nt + 4 * g4) * 4) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int idx = lane_e + 64 * j, row = idx >> 4, off = (idx & 15) * 16;
+                    const uint4 d = *reinterpret_cast<const uint4*>(scr + row * RS + off);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(Y + (size_t)(mbase + 16 * mt + row) * N + nbase) + off) = d;
+                }
+            }
+        }
+        if (!has_next) break;
+        v = vnext;
+        cur = nb0;
+        stores_in_flight = true;
+    }
+}
+
+static hipError_t allow_lds16(const void* kernel, int slot, size_t bytes) {
+    static bool done[8][64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !done[slot][dev]) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[slot][dev] = true;
+    }
+    return hipSuccess;
+}
+
+// M a multiple of 128, N of 128 (checked by the caller).  256-row tiles when they still give every CU a block.
+hipError_t launch_linear_split16(const Split16LinearArgs& a, int groups, hipStream_t s) {
+    if (a.M == 0 || a.N == 0 || groups == 0) return hipSuccess;
+    int cus = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    static const int force_mt = getenv("MMS_SPLIT_MT") ? atoi(getenv("MMS_SPLIT_MT")) : 0;
+    const int64_t tiles256 = (a.M % 256 == 0) ? (int64_t)groups * (a.M / 256) * (a.N / 128) : 0;
+    const bool big = force_mt ? (force_mt == 4 && tiles256 > 0) : tiles256 >= cus;
+    const bool ln = a.stat_in[0] != nullptr;
+    if (a.out_mode < 0 || a.out_mode > 2 || (ln && a.out_mode == 0) || (!ln && a.out_mode == 2)) return hipErrorInvalidValue;
+#define MMS_LAUNCH_SPLIT16(MT, OUT, LNF, SLOT)                                                                                 \
+    {                                                                                                                          \
+        auto kern = linear_split16_kernel<MT, OUT, LNF>;                                                                       \
+        if (hipError_t e = allow_lds16(reinterpret_cast<const void*>(kern), SLOT, Geom16<MT>::LDS); e != hipSuccess) return e; \
+        Split16LinearArgs b = a;                                                                                               \
+        b.tiles = (int)((int64_t)groups * (a.M / (64 * MT)) * (a.N / 128));                                                    \
+        const unsigned grid = (unsigned)(b.tiles < cus ? b.tiles : cus);        /* persistent: at most one block per CU */      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Geom16<MT>::LDS, s, b);                                                \
+    }
+    if (ln) {
+        if (big && a.out_mode == 1) MMS_LAUNCH_SPLIT16(4, 1, 3, 4)
+        else if (big) MMS_LAUNCH_SPLIT16(4, 2, 3, 5)
+        else if (a.out_mode == 1) MMS_LAUNCH_SPLIT16(2, 1, 3, 6)
+        else MMS_LAUNCH_SPLIT16(2, 2, 3, 7)
+    } else if (big && a.out_mode == 1) MMS_LAUNCH_SPLIT16(4, 1, 0, 0)
+    else if (big) MMS_LAUNCH_SPLIT16(4, 0, 0, 1)
+    else if (a.out_mode == 1) MMS_LAUNCH_SPLIT16(2, 1, 0, 2)
+    else MMS_LAUNCH_SPLIT16(2, 0, 0, 3)
+#undef MMS_LAUNCH_SPLIT16
+    return hipGetLastError();
+}
+
+}  // namespace mms
