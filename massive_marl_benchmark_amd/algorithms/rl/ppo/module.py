@@ -82,6 +82,11 @@ class ActorCritic(nn.Module):
     # Applies when the batch and every hidden width are multiples of 128; False = the exact-fp32 MFMA kernel (mms_linear2_act).
     split_layers = True
     split_min_tiles = None  # least number of 128 x 128 output tiles of the widest layer for the split path (None: one per CU)
+    # Which planes: "f16x2" = two fp16 planes per operand under a power-of-two scale per row (csrc/split16_kernels.hip: three MFMA
+    # products, 4 bytes per element; the operand is kept to 2^-22 instead of exactly, the layer's error against float64 is 0.4 x the
+    # exact-fp32 kernel's, tests/test_gpu_parity.py::test_split16_layers_error; the scales come from a bound chain over the weights'
+    # row norms and cannot overflow) or "bf16x3" = three bf16 planes, every operand exact, six products (0.32 x, ~1.5 x slower).
+    split_format = "f16x2"
     fuse_head = True
     two_streams = True      # critic beside the actor on a second stream
     defer_value = False     # opt-in: `act` returns before the critic has finished; the owner calls join() before reading values
@@ -128,6 +133,98 @@ class ActorCritic(nn.Module):
             return planes
         return hit[1]
 
+    @staticmethod
+    def _h32_bytes(rows, K):
+        return rows * ((K + 31) // 32) * 128               # MMS_H32_BYTES (include/mms.h)
+
+    def _weight_planes16(self, lin, L, idx, stream):
+        """H32 planes of a Linear layer's weight, the inverse of its row scales, and the layer's entry of the bound chain
+        (largest row 1-norm, largest |bias|: |act(W x + b)| <= that norm max|x| + that bias) as a device tensor [2]; refreshed when the
+        weight or the bias has changed (version counters) or moved."""
+        if self._wplanes is None:
+            self._wplanes = {}
+        w, b = lin.weight.detach(), lin.bias.detach()
+        tag = (w._version, w.data_ptr(), b._version, b.data_ptr(), str(w.device))
+        hit = self._wplanes.get(("h", id(lin)))
+        if hit is None or hit[0] != tag:
+            N, K = lin.out_features, lin.in_features
+            fresh = hit is None or hit[1].device != w.device
+            planes = torch.empty(self._h32_bytes(N, K), dtype=torch.uint8, device=w.device) if fresh else hit[1]
+            scale = torch.empty(N, device=w.device) if fresh else hit[4]
+            inv = torch.empty(N, device=w.device) if fresh else hit[2]
+            wc = w.contiguous()
+            one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+            _lib.check(L.mms_split_planes16_group(idx, 1, N, K, 0, one(wc), one(planes), one(scale), one(inv), 0, 0, None, None, None, stream),
+                       None, "mms_split_planes16_group", L)
+            bound = torch.stack([wc.abs().sum(1).max(), b.abs().max()])
+            hit = (tag, planes, inv, bound, scale)
+            self._wplanes[("h", id(lin))] = hit
+        return hit[1], hit[2], hit[3], hit[0]
+
+    def _split_hidden16(self, nets, inputs, tag):
+        """As _split_hidden on two scaled fp16 planes per operand (mms_split_planes16_group / mms_linear_group_act_split16).  The
+        kernel that splits a network's input also evaluates, per row, the scales of the hidden activations behind it from the
+        layers' bound chain."""
+        x0 = inputs[0]
+        dev, M = x0.device, x0.shape[0]
+        L, idx, stream = _lib.for_device(dev)
+        G, nl = len(nets), len(nets[0])
+        key = (tag, "h", M, tuple(x.shape[1] for x in inputs), str(dev), G, tuple(l.out_features for l in nets[0]))
+        if self._split_bufs is None:
+            self._split_bufs = {}
+        bufs = self._split_bufs.get(key)
+        f32 = lambda *sh: torch.empty(*sh, device=dev)
+        if bufs is None:
+            u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+            bufs = {"x": [u8(self._h32_bytes(M, x.shape[1])) for x in inputs], "xs": [f32(M) for _ in range(G)], "xi": [f32(M) for _ in range(G)],
+                    "cs": [f32(G, max(nl - 1, 1), M) for _ in range(G)], "ci": [f32(G, max(nl - 1, 1), M) for _ in range(G)],
+                    "h": [[u8(self._h32_bytes(M, l.out_features)) for _ in range(G)] for l in nets[0][:-1]],
+                    "out": [f32(M, nets[0][-1].out_features) for _ in range(G)], "chain": {}}
+            self._split_bufs[key] = bufs
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        wpl = [[self._weight_planes16(l, L, idx, stream) for l in net] for net in nets]
+        # distinct inputs: each is split once, with one bound chain per network it feeds
+        src, users = [], []                    # src[g] = (index of the input's first user, chain slot)
+        for g, x in enumerate(inputs):
+            same = next((h for h in range(g) if inputs[h].data_ptr() == x.data_ptr() and inputs[h].shape == x.shape), None)
+            if same is None:
+                users.append([g])
+                src.append((g, 0))
+            else:
+                first = src[same][0]
+                grp = next(u for u in users if u[0] == first)
+                src.append((first, len(grp)))
+                grp.append(g)
+        for grp in users:
+            g0 = grp[0]
+            x = inputs[g0]
+            assert x.dtype == torch.float32 and x.stride(1) == 1
+            nch = len(grp) if nl > 1 else 0
+            chain = None
+            if nch:
+                ckey = tuple(wpl[g][li][3] for g in grp for li in range(nl - 1))
+                hit = bufs["chain"].get(g0)
+                if hit is None or hit[0] != ckey:
+                    hit = (ckey, torch.stack([torch.stack([wpl[g][li][2] for li in range(nl - 1)]) for g in grp]).contiguous())
+                    bufs["chain"][g0] = hit
+                chain = hit[1]
+            _lib.check(L.mms_split_planes16_group(idx, 1, M, x.shape[1], x.stride(0), arr([x]), arr([bufs["x"][g0]]), arr([bufs["xs"][g0]]), arr([bufs["xi"][g0]]),
+                                                  nch, nl - 1 if nch else 0, arr([chain]) if nch else None, arr([bufs["cs"][g0]]) if nch else None,
+                                                  arr([bufs["ci"][g0]]) if nch else None, stream), None, "mms_split_planes16_group", L)
+        cur = [bufs["x"][src[g][0]] for g in range(G)]
+        cur_inv = [bufs["xi"][src[g][0]] for g in range(G)]
+        for li in range(nl):
+            lins = [net[li] for net in nets]
+            last = li == nl - 1
+            out = bufs["out"] if last else bufs["h"][li]
+            ysc = None if last else arr([bufs["cs"][src[g][0]][src[g][1], li] for g in range(G)])
+            _lib.check(L.mms_linear_group_act_split16(idx, G, M, lins[0].out_features, lins[0].in_features, arr(cur), arr([wpl[g][li][0] for g in range(G)]),
+                                                      arr([l.bias.detach() for l in lins]), arr(out), arr(cur_inv), arr([wpl[g][li][1] for g in range(G)]), ysc,
+                                                      1, 0 if last else 1, None, None, None, None, None, 0, stream), None, "mms_linear_group_act_split16", L)
+            if not last:
+                cur, cur_inv = out, [bufs["ci"][src[g][0]][src[g][1], li] for g in range(G)]
+        return bufs["out"]
+
     def _split_applies(self, M, lins, networks=2):
         """Shapes the split kernel takes (batch and widths multiples of 128) AND is worth taking: the widest layer must give each CU at
         least one 128 x 128 output tile (`split_min_tiles`: None = the device's CU count) -- below that the kernel's fixed cost per
@@ -145,6 +242,9 @@ class ActorCritic(nn.Module):
         """Hidden layers of the networks in `nets` (lists of their hidden Linear layers, the same shapes in every network), one
         mms_linear_group_act_split launch per layer for all of them.  `inputs`: one fp32 [M, K] tensor per network (the same tensor
         twice is split once).  Activations stay in the three-plane format between the layers; the last one leaves fp32 [M, H]."""
+        if self.split_format == "f16x2":
+            return self._split_hidden16(nets, inputs, tag)
+        assert self.split_format == "bf16x3", self.split_format
         x0 = inputs[0]
         dev, M, K = x0.device, x0.shape[0], x0.shape[1]
         L, idx, stream = _lib.for_device(dev)

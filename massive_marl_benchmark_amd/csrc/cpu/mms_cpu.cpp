@@ -452,26 +452,78 @@ MMS_API int mms_split_planes_group(int device, int32_t groups, int64_t rows, int
     return 0;
 }
 
+// The layer on decoded operands, shared by the two plane formats: `wf` [N][KC * 32] and `decode_x(m, xr)` give the operands as the
+// floats the planes stand for (times their row scales in the H32 format, undone by `rescale(m, n)` = 1 for P32), `encode_y(m, row)`
+// stores the finished row (out_mode 0 / 1).
+template <class DecodeX, class Rescale, class EncodeY>
+static void split_layer_rows(int64_t M, int32_t N, int KC, const std::vector<float>& wf, const float* b, int32_t act, int32_t out_mode, const float* ln_s,
+                             const float* ln_stat_in, float* ln_part_out, const float* head_w, float* head_part, int32_t head_dim, DecodeX decode_x,
+                             Rescale rescale, EncodeY encode_y) {
+    const int slots = N / 64;
+    const bool ln = ln_s != nullptr;
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; m++) {
+        std::vector<float> xr((size_t)KC * 32), row((size_t)N);
+        decode_x(m, xr.data());
+        for (int n = 0; n < N; n++) {
+            float s = 0.f;
+            const float* wr = wf.data() + (size_t)n * KC * 32;
+            for (int k = 0; k < KC * 32; k++) s = fmaf(xr[k], wr[k], s);
+            s *= rescale(m, n);
+            if (ln) s = ln_stat_in[2 * m + 1] * (s - ln_stat_in[2 * m] * ln_s[n]);
+            row[n] = act_fn(s + b[n], act);
+        }
+        if (ln)
+            for (int sl = 0; sl < slots; sl++) {                                    // (sum, M2 about the slot mean) per 64 columns
+                float sum = 0.f, m2 = 0.f;
+                for (int n = 64 * sl; n < 64 * sl + 64; n++) sum += row[n];
+                const float mean = sum * (1.f / 64.f);
+                for (int n = 64 * sl; n < 64 * sl + 64; n++) m2 += (row[n] - mean) * (row[n] - mean);
+                ln_part_out[((size_t)sl * M + m) * 2 + 0] = sum;
+                ln_part_out[((size_t)sl * M + m) * 2 + 1] = m2;
+            }
+        if (out_mode == 2) {
+            for (int sl = 0; sl < slots; sl++)
+                for (int j = 0; j < head_dim; j++) {
+                    float p = 0.f;
+                    for (int n = 64 * sl; n < 64 * sl + 64; n++) p += row[n] * head_w[(size_t)j * N + n];
+                    head_part[((size_t)sl * M + m) * 16 + j] = p;
+                }
+        } else {
+            encode_y(m, row.data());
+        }
+    }
+}
+
+static int split_layer_check(const char* fn, int32_t groups, const void* x, const void* w, const void* b, int64_t M, int32_t N, int32_t K, int32_t act,
+                             int32_t out_mode, const void* y, const void* ln_s, const void* ln_stat_in, const void* ln_part_out, const void* head_w,
+                             const void* head_part, int32_t head_dim) {
+    const std::string f(fn);
+    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = f + ": groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
+    if (!x || !w || !b || M < 0 || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3 || out_mode < 0 || out_mode > 2 || (out_mode != 2 && !y)) {
+        g_error = f + ": bad arguments (M and N multiples of 128, act 0..3, out_mode 0..2)";
+        return 1;
+    }
+    const bool ln = ln_s || ln_stat_in || ln_part_out;
+    if (ln && (!ln_s || !ln_stat_in || !ln_part_out || act != 1 || out_mode == 0)) {
+        g_error = f + ": the LayerNorm folds come together (ln_s, ln_stat_in, ln_part_out), with act = ELU and out_mode 1 or 2";
+        return 1;
+    }
+    if (out_mode == 2 && (!ln || !head_w || !head_part || head_dim < 1 || head_dim > 16)) {
+        g_error = f + ": out_mode 2 needs the LayerNorm folds, head_w, head_part and 1 <= head_dim <= 16";
+        return 1;
+    }
+    return 0;
+}
+
 MMS_API int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
                                        const float* const* b, void* const* y, int32_t act, int32_t out_mode, const float* const* ln_s,
                                        const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
                                        int32_t head_dim, void*) {
     if (cpu_only(device)) return 1;
-    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_linear_group_act_split: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
-    if (!x || !w || !b || M < 0 || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3 || out_mode < 0 || out_mode > 2 || (out_mode != 2 && !y)) {
-        g_error = "mms_linear_group_act_split: bad arguments (M and N multiples of 128, act 0..3, out_mode 0..2)";
-        return 1;
-    }
-    const bool ln = ln_s || ln_stat_in || ln_part_out;
-    if (ln && (!ln_s || !ln_stat_in || !ln_part_out || act != 1 || out_mode == 0)) {
-        g_error = "mms_linear_group_act_split: the LayerNorm folds come together (ln_s, ln_stat_in, ln_part_out), with act = ELU and out_mode 1 or 2";
-        return 1;
-    }
-    if (out_mode == 2 && (!ln || !head_w || !head_part || head_dim < 1 || head_dim > 16)) {
-        g_error = "mms_linear_group_act_split: out_mode 2 needs the LayerNorm folds, head_w, head_part and 1 <= head_dim <= 16";
-        return 1;
-    }
-    const int KC = (K + 31) / 32, NC = N / 32, slots = N / 64;
+    if (split_layer_check("mms_linear_group_act_split", groups, x, w, b, M, N, K, act, out_mode, y, ln_s, ln_stat_in, ln_part_out, head_w, head_part, head_dim)) return 1;
+    const bool ln = ln_s != nullptr;
+    const int KC = (K + 31) / 32, NC = N / 32;
     for (int g = 0; g < groups; g++) {
         if (!x[g] || !w[g] || !b[g] || (out_mode != 2 && !y[g]) || (ln && (!ln_s[g] || !ln_stat_in[g] || !ln_part_out[g])) ||
             (out_mode == 2 && (!head_w[g] || !head_part[g]))) {
@@ -483,42 +535,161 @@ MMS_API int mms_linear_group_act_split(int device, int32_t groups, int64_t M, in
         std::vector<float> wf((size_t)N * KC * 32);
         for (int64_t n = 0; n < N; n++)
             for (int k = 0; k < KC * 32; k++) wf[n * KC * 32 + k] = join3(wp + (n * KC + k / 32) * 96, k % 32);
+        void* yg = out_mode != 2 ? y[g] : nullptr;
+        split_layer_rows(M, N, KC, wf, b[g], act, out_mode, ln ? ln_s[g] : nullptr, ln ? ln_stat_in[g] : nullptr, ln ? ln_part_out[g] : nullptr,
+                         out_mode == 2 ? head_w[g] : nullptr, out_mode == 2 ? head_part[g] : nullptr, head_dim,
+                         [&](int64_t m, float* xr) { for (int k = 0; k < KC * 32; k++) xr[k] = join3(xp + (m * KC + k / 32) * 96, k % 32); },
+                         [](int64_t, int) { return 1.f; },
+                         [&](int64_t m, const float* row) {
+                             if (out_mode == 1) {
+                                 for (int n = 0; n < N; n++) {
+                                     uint16_t* c = (uint16_t*)yg + (m * NC + n / 32) * 96 + n % 32;
+                                     split3(row[n], c, c + 32, c + 64);
+                                 }
+                             } else {
+                                 memcpy((float*)yg + m * N, row, (size_t)N * 4);
+                             }
+                         });
+    }
+    return 0;
+}
+
+// ---- the same with two scaled fp16 planes per operand (csrc/split16_kernels.hip), format H32 = f16 [rows, KC, 2, 32] -------------------
+static inline uint16_t f2h(float f) {                                     // round to nearest even, subnormals kept, as v_cvt_f16_f32
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);               // rounds to 65520 or more: infinity
+    if (u < 0x38800000u) {                                                // below 2^-14: a subnormal half (or zero)
+        if (u < 0x33000000u) return (uint16_t)sign;                       // below 2^-25: zero
+        const int e = (int)(u >> 23);                                     // biased exponent, 102 .. 112
+        uint32_t m = (u & 0x7fffffu) | 0x800000u;                         // 24-bit significand
+        const int shift = 126 - e;                                        // the half's unit is 2^-24: value = m 2^(e - 150) = (m >> shift) 2^-24
+        const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+    }
+    const uint32_t r = u + 0xfffu + ((u >> 13) & 1u);                      // round the 13 dropped bits to nearest even
+    return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
+}
+static inline float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else {
+            const float v = (float)m * 5.9604644775390625e-08f;           // m 2^-24, exact
+            memcpy(&u, &v, 4);
+            u |= sign;
+        }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline void pow2_scale(float bound, float& scale, float& inv) {    // as split16_kernels.hip
+    int e = 14;
+    if (bound > 0.f) (void)frexpf(bound, &e);
+    int sh = 14 - e;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    scale = ldexpf(1.f, sh);
+    inv = ldexpf(1.f, -sh);
+}
+static inline void split2(float t, uint16_t* hi, uint16_t* lo) {
+    *hi = f2h(t);
+    *lo = f2h((t - h2f(*hi)) * 2048.f);
+}
+static inline float join2(const uint16_t* chunk, int j) { return h2f(chunk[j]) + h2f(chunk[32 + j]) * (1.f / 2048.f); }
+
+MMS_API int mms_split_planes16_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch, const float* const* x, void* const* planes,
+                                     float* const* scale, float* const* inv, int32_t nchains, int32_t L, const float* const* chain,
+                                     float* const* chain_scale, float* const* chain_inv, void*) {
+    if (cpu_only(device)) return 1;
+    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_split_planes16_group: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
+    if (x_pitch == 0) x_pitch = K;
+    if (!x || !planes || !scale || !inv || rows < 0 || K <= 0 || x_pitch < K || nchains < 0 || L < 0 || (nchains > 0 && (L < 1 || !chain || !chain_scale || !chain_inv))) {
+        g_error = "mms_split_planes16_group: bad arguments (x_pitch >= K; nchains > 0 needs L >= 1, chain, chain_scale, chain_inv)";
+        return 1;
+    }
+    const int KC = (K + 31) / 32;
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !planes[g] || (nchains > 0 && (!chain[g] || !chain_scale[g] || !chain_inv[g]))) {
+            g_error = "mms_split_planes16_group: null or misaligned pointer in a group (planes 16-byte aligned)";
+            return 1;
+        }
+        uint16_t* out = (uint16_t*)planes[g];
+        const float* xg = x[g];
 #pragma omp parallel for schedule(static)
-        for (int64_t m = 0; m < M; m++) {
-            std::vector<float> xr((size_t)KC * 32), row((size_t)N);
-            for (int k = 0; k < KC * 32; k++) xr[k] = join3(xp + (m * KC + k / 32) * 96, k % 32);
-            for (int n = 0; n < N; n++) {
-                float s = 0.f;
-                const float* wr = wf.data() + (size_t)n * KC * 32;
-                for (int k = 0; k < KC * 32; k++) s = fmaf(xr[k], wr[k], s);
-                if (ln) s = ln_stat_in[g][2 * m + 1] * (s - ln_stat_in[g][2 * m] * ln_s[g][n]);
-                row[n] = act_fn(s + b[g][n], act);
+        for (int64_t r = 0; r < rows; r++) {
+            float big = 0.f;
+            for (int k = 0; k < K; k++) big = fmaxf(big, fabsf(xg[r * x_pitch + k]));
+            float sc, iv;
+            pow2_scale(big, sc, iv);
+            for (int kc = 0; kc < KC; kc++) {
+                uint16_t* c = out + (r * KC + kc) * 64;
+                for (int j = 0; j < 32; j++) {
+                    const int k = kc * 32 + j;
+                    split2(k < K ? xg[r * x_pitch + k] * sc : 0.f, c + j, c + 32 + j);
+                }
             }
-            if (ln)
-                for (int sl = 0; sl < slots; sl++) {                                    // (sum, M2 about the slot mean) per 64 columns
-                    float sum = 0.f, m2 = 0.f;
-                    for (int n = 64 * sl; n < 64 * sl + 64; n++) sum += row[n];
-                    const float mean = sum * (1.f / 64.f);
-                    for (int n = 64 * sl; n < 64 * sl + 64; n++) m2 += (row[n] - mean) * (row[n] - mean);
-                    ln_part_out[g][((size_t)sl * M + m) * 2 + 0] = sum;
-                    ln_part_out[g][((size_t)sl * M + m) * 2 + 1] = m2;
+            if (scale[g]) scale[g][r] = sc;
+            if (inv[g]) inv[g][r] = iv;
+            for (int c = 0; c < nchains; c++) {
+                float bound = big;
+                for (int l = 0; l < L; l++) {
+                    bound = (chain[g][((size_t)c * L + l) * 2] * bound + chain[g][((size_t)c * L + l) * 2 + 1]) * 1.001f;
+                    float s2, i2;
+                    pow2_scale(bound, s2, i2);
+                    chain_scale[g][((size_t)c * L + l) * rows + r] = s2;
+                    chain_inv[g][((size_t)c * L + l) * rows + r] = i2;
                 }
-            if (out_mode == 2) {
-                for (int sl = 0; sl < slots; sl++)
-                    for (int j = 0; j < head_dim; j++) {
-                        float p = 0.f;
-                        for (int n = 64 * sl; n < 64 * sl + 64; n++) p += row[n] * head_w[g][(size_t)j * N + n];
-                        head_part[g][((size_t)sl * M + m) * 16 + j] = p;
-                    }
-            } else if (out_mode == 1) {
-                for (int n = 0; n < N; n++) {
-                    uint16_t* c = (uint16_t*)y[g] + (m * NC + n / 32) * 96 + n % 32;
-                    split3(row[n], c, c + 32, c + 64);
-                }
-            } else {
-                memcpy((float*)y[g] + m * N, row.data(), (size_t)N * 4);
             }
         }
+    }
+    return 0;
+}
+
+MMS_API int mms_linear_group_act_split16(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
+                                         const float* const* b, void* const* y, const float* const* x_inv, const float* const* w_inv,
+                                         const float* const* y_scale, int32_t act, int32_t out_mode, const float* const* ln_s,
+                                         const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
+                                         int32_t head_dim, void*) {
+    if (cpu_only(device)) return 1;
+    if (split_layer_check("mms_linear_group_act_split16", groups, x, w, b, M, N, K, act, out_mode, y, ln_s, ln_stat_in, ln_part_out, head_w, head_part, head_dim)) return 1;
+    if (!x_inv || !w_inv || (out_mode == 1 && !y_scale)) { g_error = "mms_linear_group_act_split16: bad arguments (x_inv, w_inv, y_scale with out_mode 1)"; return 1; }
+    const bool ln = ln_s != nullptr;
+    const int KC = (K + 31) / 32, NC = N / 32;
+    for (int g = 0; g < groups; g++) {
+        if (!x[g] || !w[g] || !b[g] || !x_inv[g] || !w_inv[g] || (out_mode != 2 && !y[g]) || (out_mode == 1 && !y_scale[g]) ||
+            (ln && (!ln_s[g] || !ln_stat_in[g] || !ln_part_out[g])) || (out_mode == 2 && (!head_w[g] || !head_part[g]))) {
+            g_error = "mms_linear_group_act_split16: null pointer in a group";
+            return 1;
+        }
+        const uint16_t* xp = (const uint16_t*)x[g];
+        const uint16_t* wp = (const uint16_t*)w[g];
+        std::vector<float> wf((size_t)N * KC * 32);
+        for (int64_t n = 0; n < N; n++)
+            for (int k = 0; k < KC * 32; k++) wf[n * KC * 32 + k] = join2(wp + (n * KC + k / 32) * 64, k % 32);
+        void* yg = out_mode != 2 ? y[g] : nullptr;
+        const float* xi = x_inv[g];
+        const float* wi = w_inv[g];
+        const float* ys = out_mode == 1 ? y_scale[g] : nullptr;
+        split_layer_rows(M, N, KC, wf, b[g], act, out_mode, ln ? ln_s[g] : nullptr, ln ? ln_stat_in[g] : nullptr, ln ? ln_part_out[g] : nullptr,
+                         out_mode == 2 ? head_w[g] : nullptr, out_mode == 2 ? head_part[g] : nullptr, head_dim,
+                         [&](int64_t m, float* xr) { for (int k = 0; k < KC * 32; k++) xr[k] = join2(xp + (m * KC + k / 32) * 64, k % 32); },
+                         [&](int64_t m, int n) { return wi[n] * xi[m]; },
+                         [&](int64_t m, const float* row) {
+                             if (out_mode == 1) {
+                                 for (int n = 0; n < N; n++) {
+                                     uint16_t* c = (uint16_t*)yg + (m * NC + n / 32) * 64 + n % 32;
+                                     split2(row[n] * ys[m], c, c + 32);
+                                 }
+                             } else {
+                                 memcpy((float*)yg + m * N, row, (size_t)N * 4);
+                             }
+                         });
     }
     return 0;
 }

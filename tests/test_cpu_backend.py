@@ -309,7 +309,6 @@ def test_make_entry_glue():
         make("OneAnt", "mtppo", cpu)
 
 
-@pytest.mark.skipif(not os.path.isdir(os.environ.get("MMS_REFERENCE", "/root/reference")), reason="reference tree not present")
 def test_split_operand_layers_on_cpu_build():
     """mms_split_planes / mms_linear_group_act_split on the CPU build (the same ABI as the HIP kernels of csrc/split_kernels.hip): the
     three bf16 planes of a value sum back to it EXACTLY, columns past K are zero, and a layer on the planes equals torch's
@@ -352,6 +351,7 @@ def test_split_operand_layers_on_cpu_build():
     # the module on the CPU build
     from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
     ac = ActorCritic((36,), (0,), (8,), 0.8, {"pi_hid_sizes": [128, 128], "vf_hid_sizes": [128, 128], "activation": "elu"}, seed=3)
+    ac.split_format = "bf16x3"
     obs, states = torch.randn(128, 36), torch.zeros(128, 0)
     hidden = ac._fused_hidden(obs, obs)                               # (on the CPU build one tile is enough: split_min_tiles None -> 1)
     assert hidden is not None and ac._split_bufs
@@ -362,6 +362,84 @@ def test_split_operand_layers_on_cpu_build():
         hidden = ac._fused_hidden(obs, obs)
         assert float((ac.actor[:-1](obs) - hidden[0]).abs().max()) < 1e-5 and float((ac.critic[:-1](obs) - hidden[1]).abs().max()) < 1e-5
         assert float((ac.value(obs) - ac.critic(obs)).abs().max()) < 1e-5 if obs.is_cuda else True
+
+
+def test_split16_layers_on_cpu_build():
+    """mms_split_planes16_group / mms_linear_group_act_split16 on the CPU build (the ABI of csrc/split16_kernels.hip): two fp16 planes
+    under a power-of-two row scale keep every element to 2^-22 of itself (also far below the row's largest magnitude: subnormal
+    halves), columns past K are zero, the bound chain's scales keep every hidden activation below 2^14 on the fp16 axis, a layer on
+    the planes equals torch's Linear + ELU in float64 to fp32 accuracy, and the module's default path follows parameter updates."""
+    L = _lib.lib_cpu()
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    nbytes = lambda rows, K: rows * ((K + 31) // 32) * 128
+
+    def join(planes, rows, K, inv):
+        v = planes.view(torch.float16).view(rows, (K + 31) // 32, 2, 32).double()
+        return ((v[:, :, 0] + v[:, :, 1] / 2048.0).reshape(rows, -1) * inv.double()[:, None])[:, :K], v
+    torch.manual_seed(5)
+    for rows, K, pitch in ((128, 388, 388), (9, 36, 40), (4, 1, 4)):
+        x = torch.randn(rows, pitch) * torch.exp2(torch.randint(-20, 12, (rows, 1)).float())
+        x[0, 0] = x[0, :K].abs().max() * 2.0 ** -20                   # far below its row's scale
+        if rows > 2:
+            x[2] = 0.0                                                # an all-zero row keeps scale 1
+        planes = torch.full((nbytes(rows, K),), 0xAB, dtype=torch.uint8)
+        sc, iv = torch.empty(rows), torch.empty(rows)
+        assert L.mms_split_planes16_group(-1, 1, rows, K, pitch, arr([x]), arr([planes]), arr([sc]), arr([iv]), 0, 0, None, None, None, None) == 0, _lib.last_error(None, L)
+        back, v = join(planes, rows, K, iv)
+        ref = x[:, :K].double()
+        big = ref.abs().max(1, keepdim=True).values
+        assert float(((back - ref).abs() / ref.abs().clamp_min(1e-300)).max()) <= 2.0 ** -21 + 1e-12 or float(((back - ref).abs() / big.clamp_min(1e-300)).max()) < 2.0 ** -34
+        assert float(((back - ref).abs() - 2.0 ** -21 * ref.abs()).clamp_min(0).max()) <= float((big * 2.0 ** -35).max())
+        assert torch.equal(sc * iv, torch.ones(rows)) and float((ref.abs().max(1).values * sc.double()).max()) <= 2.0 ** 14
+        assert float(v.permute(0, 1, 3, 2).reshape(rows, -1, 2)[:, K:].abs().sum()) == 0.0
+    # a chain of two layers: scales from the bound chain, planes between the layers
+    M, K, H = 128, 100, 256
+    x = torch.randn(M, K) * 3
+    w = [[torch.randn(H, K) / K ** 0.5, torch.randn(H, H) / H ** 0.5] for _ in range(2)]
+    b = [[torch.randn(H), torch.randn(H)] for _ in range(2)]
+    wp = [[torch.empty(nbytes(wl.shape[0], wl.shape[1]), dtype=torch.uint8) for wl in net] for net in w]
+    winv = [[torch.empty(H) for _ in net] for net in w]
+    for g in range(2):
+        for li in range(2):
+            sc = torch.empty(H)
+            assert L.mms_split_planes16_group(-1, 1, H, w[g][li].shape[1], 0, arr([w[g][li]]), arr([wp[g][li]]), arr([sc]), arr([winv[g][li]]), 0, 0, None, None, None, None) == 0
+    chain = torch.stack([torch.stack([torch.stack([w[g][0].abs().sum(1).max(), b[g][0].abs().max()])]) for g in range(2)]).contiguous()    # [2 chains][1 layer][2]
+    xp, xs, xi = torch.empty(nbytes(M, K), dtype=torch.uint8), torch.empty(M), torch.empty(M)
+    cs, ci = torch.empty(2, 1, M), torch.empty(2, 1, M)
+    assert L.mms_split_planes16_group(-1, 1, M, K, 0, arr([x]), arr([xp]), arr([xs]), arr([xi]), 2, 1, arr([chain]), arr([cs]), arr([ci]), None) == 0, _lib.last_error(None, L)
+    hp = [torch.empty(nbytes(M, H), dtype=torch.uint8) for _ in range(2)]
+    assert L.mms_linear_group_act_split16(-1, 2, M, H, K, arr([xp, xp]), arr([wp[0][0], wp[1][0]]), arr([b[0][0], b[1][0]]), arr(hp), arr([xi, xi]),
+                                          arr([winv[0][0], winv[1][0]]), arr([cs[0, 0], cs[1, 0]]), 1, 1, None, None, None, None, None, 0, None) == 0, _lib.last_error(None, L)
+    ys = [torch.empty(M, H) for _ in range(2)]
+    assert L.mms_linear_group_act_split16(-1, 2, M, H, H, arr(hp), arr([wp[0][1], wp[1][1]]), arr([b[0][1], b[1][1]]), arr(ys), arr([ci[0, 0], ci[1, 0]]),
+                                          arr([winv[0][1], winv[1][1]]), None, 1, 0, None, None, None, None, None, 0, None) == 0, _lib.last_error(None, L)
+    for g in range(2):
+        h1 = torch.nn.functional.elu(torch.nn.functional.linear(x.double(), w[g][0].double(), b[g][0].double()))
+        got1, v = join(hp[g], M, H, ci[g, 0])
+        assert float((got1 - h1).abs().max()) < 1e-6 * float(h1.abs().max())      # (the host build's product is an fp32 fma chain)
+        assert float(v[:, :, 0].abs().max()) <= 2.0 ** 14             # the hi plane of every hidden activation is inside the bound
+        ref = torch.nn.functional.elu(torch.nn.functional.linear(got1, w[g][1].double(), b[g][1].double()))
+        assert float((ys[g].double() - ref).abs().max()) < 1e-6 * float(ref.abs().max())
+    assert L.mms_linear_group_act_split16(-1, 2, M, H, K, arr([xp, xp]), arr([wp[0][0], wp[1][0]]), arr([b[0][0], b[1][0]]), arr(hp), arr([xi, xi]),
+                                          arr([winv[0][0], winv[1][0]]), None, 1, 1, None, None, None, None, None, 0, None) != 0
+    assert "y_scale" in _lib.last_error(None, L)
+    # the module on the CPU build (default format)
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
+    ac = ActorCritic((36,), (0,), (8,), 0.8, {"pi_hid_sizes": [128, 256, 128], "vf_hid_sizes": [128, 256, 128], "activation": "elu"}, seed=3)
+    assert ac.split_format == "f16x2"
+    obs = torch.randn(128, 36) * 4
+    hidden = ac._fused_hidden(obs, obs)
+    assert hidden is not None and any(k[1] == "h" for k in ac._split_bufs)
+    with torch.no_grad():
+        assert float((ac.actor[:-1](obs) - hidden[0]).abs().max()) < 1e-5 and float((ac.critic[:-1](obs) - hidden[1]).abs().max()) < 1e-5
+        for q in ac.parameters():
+            q.add_(0.05 * torch.randn_like(q))                        # an in-place "optimizer step": weights AND biases move
+        hidden = ac._fused_hidden(obs, obs)
+        assert float((ac.actor[:-1](obs) - hidden[0]).abs().max()) < 1e-5 and float((ac.critic[:-1](obs) - hidden[1]).abs().max()) < 1e-5
+        big = obs * 1e4                                               # rows far outside the training range: the row scale follows
+        hidden = ac._fused_hidden(big, big)
+        ref = ac.actor[:-1](big)
+        assert float((ref - hidden[0]).abs().max()) < 1e-5 * float(ref.abs().max())
 
 
 def test_reference_learners_drop_in_unchanged(tmp_path):

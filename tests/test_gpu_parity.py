@@ -1272,6 +1272,157 @@ def test_split_layers_error(torch_cuda):
     assert "null pointer" in _lib.last_error(None)
 
 
+def _h32_bytes(rows, K):
+    return rows * ((K + 31) // 32) * 128
+
+
+def _h32_to_f64(torch, planes, rows, K, inv):
+    v = planes.view(torch.float16).view(rows, (K + 31) // 32, 2, 32).double()
+    return ((v[:, :, 0] + v[:, :, 1] / 2048.0).reshape(rows, -1) * inv.double()[:, None])[:, :K], v
+
+
+def test_split16_planes(torch_cuda):
+    """mms_split_planes16_group: two fp16 planes under a power-of-two scale per row.  Every element is kept to 2^-22 of itself (or, far
+    below its row's largest magnitude, to 2^-35 of that magnitude: subnormal halves), the scale puts the row's largest magnitude in
+    [2^13, 2^14], columns past K are zero, row pitches are honoured, and the planes are bit-identical to the CPU build's (the same
+    round-to-nearest-even conversions); the bound chain's scales are the ones the formula gives."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    L, C = _lib.lib(), _lib.lib_cpu()
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(2)
+    for (rows, K, pitch) in ((4096, 388, 388), (1024, 1024, 1024), (7, 36, 40), (3, 1, 4), (5, 1028, 1028), (130, 64, 64), (9, 2500, 2500)):
+        x = torch.randn(rows, pitch, device="cuda") * torch.exp2(torch.randint(-24, 16, (rows, 1), device="cuda").float())
+        if K >= 8:
+            x[0, :8] = torch.tensor([0.0, -0.0, 1e-30, -3e4, 1.0 + 2 ** -23, 2 ** -20, 65504.0, -1e-20], device="cuda")
+        if rows > 2:
+            x[2] = 0.0
+        planes = torch.full((_h32_bytes(rows, K),), 0xAB, dtype=torch.uint8, device="cuda")
+        sc, iv = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+        _lib.check(L.mms_split_planes16_group(0, 1, rows, K, pitch, arr([x]), arr([planes]), arr([sc]), arr([iv]), 0, 0, None, None, None, stream), None, "split16")
+        torch.cuda.synchronize()
+        back, v = _h32_to_f64(torch, planes, rows, K, iv)
+        ref = x[:, :K].double()
+        big = ref.abs().max(1, keepdim=True).values
+        assert float(((back - ref).abs() - 2.0 ** -21 * ref.abs() - 2.0 ** -35 * big).max()) <= 0.0, (rows, K)
+        top = (big[:, 0] * sc.double())
+        assert bool(((top <= 2.0 ** 14) & ((top > 2.0 ** 13) | (big[:, 0] == 0))).all()) and torch.equal(sc * iv, torch.ones_like(sc))
+        KC = (K + 31) // 32
+        if KC * 32 > K:
+            assert float(v.permute(0, 1, 3, 2).reshape(rows, KC * 32, 2)[:, K:].abs().max()) == 0.0
+        xc = x.cpu()
+        pc, scc, ivc = torch.empty(_h32_bytes(rows, K), dtype=torch.uint8), torch.empty(rows), torch.empty(rows)
+        assert C.mms_split_planes16_group(-1, 1, rows, K, pitch, arr([xc]), arr([pc]), arr([scc]), arr([ivc]), 0, 0, None, None, None, None) == 0
+        assert torch.equal(planes.cpu(), pc) and torch.equal(sc.cpu(), scc), (rows, K)
+    # chains: bound_{l+1} = (mult_l bound_l + add_l) 1.001, scale = 2^(14 - e) with bound <= 2^e
+    rows, K = 300, 64
+    x = torch.randn(rows, K, device="cuda") * torch.exp2(torch.randint(-10, 10, (rows, 1), device="cuda").float())
+    chain = torch.tensor([[[20.0, 0.5], [30.0, 0.1], [0.0, 7.0]], [[1e-3, 0.0], [5.0, 5.0], [2.0, 0.0]]], device="cuda")
+    planes, sc, iv = torch.empty(_h32_bytes(rows, K), dtype=torch.uint8, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    cs, ci = torch.empty(2, 3, rows, device="cuda"), torch.empty(2, 3, rows, device="cuda")
+    _lib.check(L.mms_split_planes16_group(0, 1, rows, K, 0, arr([x]), arr([planes]), arr([sc]), arr([iv]), 2, 3, arr([chain]), arr([cs]), arr([ci]), stream), None, "split16 chain")
+    torch.cuda.synchronize()
+    bound = x.abs().max(1).values
+    for c in range(2):
+        bd = bound.clone()
+        for l in range(3):
+            bd = (chain[c, l, 0] * bd + chain[c, l, 1]) * 1.001
+            e = torch.frexp(bd)[1].float()
+            assert torch.equal(cs[c, l], torch.exp2(14 - e)) and torch.equal(cs[c, l] * ci[c, l], torch.ones(rows, device="cuda"))
+    assert L.mms_split_planes16_group(0, 1, rows, K, 0, arr([x]), arr([planes]), arr([sc]), arr([iv]), 2, 3, None, arr([cs]), arr([ci]), stream) != 0
+    assert "chain" in _lib.last_error(None)
+
+
+def test_split16_layers_error(torch_cuda):
+    """mms_linear_group_act_split16 (fp32 operands as two scaled fp16 planes, three f16 MFMA products, fp32 accumulation) against the
+    float64 product, NEXT TO the exact-fp32 MFMA kernel (mms_linear2_act) on the same inputs, as test_split_layers_error does for the
+    three-plane kernel.  Gates: every element within the fp32 kernel's own per-element bound (5e-7 of sum |x||w| + |b|), rms error <=
+    0.6 x the fp32 kernel's (measured 0.38-0.45 x), worst error <= 0.8 x (measured 0.3-0.45 x), no mean error of its own.  The hidden
+    activations' scales come from the bound chain; a row with a huge input and one with a tiny input ride along (their scales differ
+    by 2^40)."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    L = _lib.lib()
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(5)
+    acts = {0: lambda v: v, 1: torch.nn.functional.elu, 2: torch.relu, 3: torch.tanh}
+    margins = {}
+    f32 = lambda *sh: torch.empty(*sh, device="cuda")
+    for (M, N, K, act, G, planes_out) in ((4096, 1024, 388, 1, 2, 1), (4096, 1024, 1024, 1, 2, 1), (4096, 512, 1024, 1, 2, 0),
+                                          (4096, 1024, 1024, 1, 1, 0), (128, 128, 32, 0, 1, 1), (256, 384, 100, 2, 2, 1),
+                                          (384, 128, 1028, 3, 3, 0), (8192, 256, 256, 2, 1, 1), (2560, 512, 64, 1, 20, 1)):
+        x = [torch.randn(M, K, device="cuda") for _ in range(G)]
+        x = [torch.where(t > 0, t, torch.expm1(t)).contiguous() for t in x]                      # ELU-shaped activations
+        for t in x:
+            t[1] *= 1e6
+            t[2] *= 1e-6
+        w = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(G)]
+        b = [torch.randn(N, device="cuda") * 0.1 for _ in range(G)]
+        xp = [torch.empty(_h32_bytes(M, K), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        wp = [torch.empty(_h32_bytes(N, K), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        xs, xi, ws, wi = [[f32(n) for _ in range(G)] for n in (M, M, N, N)]
+        chain = [torch.stack([w[g].abs().sum(1).max(), b[g].abs().max()]).view(1, 1, 2).contiguous() for g in range(G)]
+        cs, ci = [f32(1, 1, M) for _ in range(G)], [f32(1, 1, M) for _ in range(G)]
+        _lib.check(L.mms_split_planes16_group(0, G, M, K, 0, arr(x), arr(xp), arr(xs), arr(xi), 1, 1, arr(chain), arr(cs), arr(ci), stream), None, "split16 x")
+        _lib.check(L.mms_split_planes16_group(0, G, N, K, 0, arr(w), arr(wp), arr(ws), arr(wi), 0, 0, None, None, None, stream), None, "split16 w")
+        ys = [torch.full((_h32_bytes(M, N) if planes_out else M * N * 4,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(G)]
+        rc = L.mms_linear_group_act_split16(0, G, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), arr(xi), arr(wi), arr([c[0, 0] for c in cs]) if planes_out else None,
+                                            act, planes_out, None, None, None, None, None, 0, stream)
+        assert rc == 0, _lib.last_error(None)
+        y32 = [torch.empty(M, N, device="cuda") for _ in range(G)]
+        for g in range(G):
+            assert L.mms_linear2_act(0, M, N, (K + 3) // 4 * 4, p(torch.nn.functional.pad(x[g], (0, (-K) % 4))), p(torch.nn.functional.pad(w[g], (0, (-K) % 4))),
+                                     p(b[g]), p(y32[g]), None, None, None, None, act, stream) == 0
+        torch.cuda.synchronize()
+        e_split, e_f32 = [], []
+        for g in range(G):
+            if planes_out:
+                out, v = _h32_to_f64(torch, ys[g], M, N, ci[g][0, 0])
+                assert float(v[:, :, 0].abs().max()) <= 2.0 ** 14, "a hidden activation left the bound"
+            else:
+                out = ys[g].view(torch.float32).view(M, N).double()
+            ref = acts[act](torch.nn.functional.linear(x[g].double(), w[g].double(), b[g].double()))
+            scale = x[g].abs().double() @ w[g].abs().double().t() + b[g].abs().double()
+            assert float(((out - ref).abs() / scale).max()) < 5e-7, (M, N, K, act, g)
+            keep = torch.ones(M, dtype=torch.bool, device="cuda")
+            keep[1] = keep[2] = False                               # (the two rescaled rows would dominate / vanish in an rms over all rows)
+            e_split.append((out - ref)[keep])
+            e_f32.append((y32[g].double() - ref)[keep])
+        es, ef = torch.cat(e_split), torch.cat(e_f32)
+        rms_ratio = float(es.pow(2).mean().sqrt() / ef.pow(2).mean().sqrt())
+        max_ratio = float(es.abs().max() / ef.abs().max())
+        margins["%dx%dx%dx%d" % (G, M, N, K)] = {"rms_ratio": rms_ratio, "max_ratio": max_ratio}
+        if K >= 100:                                                 # (tiny K: both errors are a few ulps of single roundings)
+            assert rms_ratio <= 0.6 and max_ratio <= 0.8, (M, N, K, rms_ratio, max_ratio)
+            assert abs(float(es.mean())) <= max(2.0 * abs(float(ef.mean())), 0.02 * float(es.pow(2).mean().sqrt())), "biased"
+        if planes_out and N % 128 == 0 and act == 1:                 # chained: this layer's planes feed the next split layer unchanged
+            w2 = [torch.randn(128, N, device="cuda") / N ** 0.5 for _ in range(G)]
+            w2p = [torch.empty(_h32_bytes(128, N), dtype=torch.uint8, device="cuda") for _ in range(G)]
+            w2s, w2i = [f32(128) for _ in range(G)], [f32(128) for _ in range(G)]
+            _lib.check(L.mms_split_planes16_group(0, G, 128, N, 0, arr(w2), arr(w2p), arr(w2s), arr(w2i), 0, 0, None, None, None, stream), None, "split16 w2")
+            y2 = [torch.empty(M, 128, device="cuda") for _ in range(G)]
+            b2 = [torch.zeros(128, device="cuda") for _ in range(G)]
+            assert L.mms_linear_group_act_split16(0, G, M, 128, N, arr(ys), arr(w2p), arr(b2), arr(y2), arr([c[0, 0] for c in ci]), arr(w2i), None, 0, 0,
+                                                  None, None, None, None, None, 0, stream) == 0
+            torch.cuda.synchronize()
+            for g in range(G):
+                h = _h32_to_f64(torch, ys[g], M, N, ci[g][0, 0])[0]
+                ref2 = h @ w2[g].double().t()
+                assert float(((y2[g].double() - ref2).abs() / ref2.abs().max(1, keepdim=True).values).max()) < 2e-6
+    parity.record("gpu/split16_layers_vs_fp32_mfma", **margins)
+    z = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    zb = torch.zeros(256, device="cuda")
+    one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+    bad = lambda M, N, G=1, w=None, ysc=None, out_mode=0: L.mms_linear_group_act_split16(0, G, M, N, 32, one(z), w or one(z), one(zb), one(z), one(zb), one(zb), ysc,
+                                                                                         1, out_mode, None, None, None, None, None, 0, stream)
+    assert bad(100, 128) != 0 and bad(128, 100) != 0 and bad(128, 128, G=0) != 0 and bad(128, 128, out_mode=1) != 0
+    assert bad(128, 128, w=(ctypes.c_void_p * 1)(None)) != 0 and "null pointer" in _lib.last_error(None)
+    assert bad(128, 128, ysc=one(zb), out_mode=1) == 0
+
+
 def test_actor_critic_split_layers(torch_cuda):
     """ActorCritic.act / .value with the hidden layers on the split path (batch and hidden widths multiples of 128) against the torch
     modules and against the exact-fp32 kernel path; an in-place optimizer step is picked up (the weight planes are re-split when the
@@ -1287,7 +1438,9 @@ def test_actor_critic_split_layers(torch_cuda):
     assert ac.split_layers and not ac._split_applies(n, hidden_lins)      # too little work for a 256-CU chip: the exact-fp32 kernel is chosen ...
     ac.split_min_tiles = 0                                                 # ... unless asked (this test is about the split path's results)
     assert ac._split_applies(n, hidden_lins)
-    for trial in range(2):
+    assert ac.split_format == "f16x2"
+    for trial in range(4):
+        ac.split_format = "f16x2" if trial < 2 else "bf16x3"
         _, _, v_s, mu_s, _ = ac.act(obs, states)
         val_s = ac.value(obs)
         assert ac._split_bufs, "the split path did not run"
