@@ -7,10 +7,11 @@
 
 One "step" = one PPO rollout step over this rank's 4096 envs: actor + critic inference (the reference's
 ActorCritic, agents/algorithms/rl/ppo/module.py: two MLPs [1024,1024,512], ELU, fp32 -- each hidden layer of both networks one
-launch with bias + ELU fused: mms_linear_group_act_split, the fp32 product evaluated on the bf16 matrix pipe from operands carried
-as three bf16 planes (exact split, six plane products, fp32 accumulation; its error against float64 is measured in this run next to
-the exact-fp32 MFMA kernel's, `policy_layers_error_vs_f64`, and the rollout with the exact-fp32 MFMA layers, mms_linear2_act, is
-timed beside it: `rollout_exact_fp32_layers`), both last layers + Gaussian action sample + log-prob + the
+launch with bias + ELU fused: mms_linear_group_act_split16, the fp32 product evaluated on the 16-bit matrix pipe from operands carried
+as two fp16 planes under a power-of-two scale per row (operands kept to 2^-22, three plane products, fp32 accumulation; its error
+against float64 is measured in this run next to the exact-fp32 MFMA kernel's and the three-bf16-plane kernel's,
+`policy_layers_error_vs_f64`, and the rollout with each of those two layer kernels is timed beside it:
+`rollout_exact_fp32_layers`, `rollout_bf16x3_layers`), both last layers + Gaussian action sample + log-prob + the
 add_transitions stores (mms_ppo_heads_act, one HIP launch), the fused VecTask
 step (mms_step: physics substeps + reset + obs + reward in one HIP launch, writing observation / reward / done
 straight into the rollout slots), and every nsteps=8 steps the GAE scan + advantage normalisation
@@ -89,7 +90,9 @@ def main():
     ap.add_argument("--library-gemms", action="store_true",
                     help="A/B: the policy's layers as library GEMMs + separate ELU passes (critic on a second stream) instead of mms_linear2_act / mms_ppo_heads_act")
     ap.add_argument("--exact-fp32-layers", action="store_true",
-                    help="A/B: headline with the hidden layers on the exact-fp32 MFMA kernel (mms_linear2_act) instead of the three-plane split kernel")
+                    help="A/B: headline with the hidden layers on the exact-fp32 MFMA kernel (mms_linear2_act) instead of a split kernel")
+    ap.add_argument("--split-format", default="f16x2", choices=["f16x2", "bf16x3"],
+                    help="planes of the split layer kernel: two scaled fp16 planes (mms_linear_group_act_split16, default) or three exact bf16 planes (mms_linear_group_act_split)")
     ap.add_argument("--one-stream", action="store_true", help="A/B: actor and critic MLPs on one stream")
     ap.add_argument("--defer-critic", action="store_true",
                     help="A/B: let the critic pass overlap the sampling kernel and the env step (joined before the GAE); faster, but "
@@ -207,9 +210,10 @@ def main():
     kernel_ms_pre = time_step_kernel()
 
     # ---- PPO rollout series -----------------------------------------------------------------------------------
-    def measure_rollout(pdtype, K_req, W_req, split=True):
+    def measure_rollout(pdtype, K_req, W_req, split=True, fmt=None):
         ac_ = ac if pdtype == torch.float32 else ac_bf16
         ac_.split_layers = bool(split)
+        ac_.split_format = fmt or args.split_format
         ac_.bind_rollout(None if args.unfused else storage, None if args.unfused else actions_buf)
         ac_.two_streams = not args.one_stream
         ac_.fuse_head = not args.library_gemms
@@ -357,9 +361,11 @@ def main():
     else:
         ac_bf16 = ac.to(torch.bfloat16)
     # the same rollout with the hidden layers on the exact-fp32 MFMA kernel (round 2's headline path), beside the split kernel
-    ex_elapsed, ex_K = 0.0, 0
+    ex_elapsed, ex_K, b3_elapsed, b3_K = 0.0, 0, 0.0, 0
     if args.policy_dtype == "fp32" and not args.exact_fp32_layers and not args.library_gemms:
         ex_elapsed, ex_K, _, _ = measure_rollout(torch.float32, min(args.steps, 128), 16, split=False)
+        if args.split_format != "bf16x3":
+            b3_elapsed, b3_K, _, _ = measure_rollout(torch.float32, min(args.steps, 128), 16, fmt="bf16x3")
     elapsed, K, W, graphed = measure_rollout(pdtype, args.steps, args.warmup, split=not args.exact_fp32_layers)
     graph = graphed or None
     layer_err = policy_layer_errors(torch, ac, obs_clipped) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
@@ -401,13 +407,15 @@ def main():
             "metric": "env-steps/sec (whole node), TenAnt 4096 envs/GPU, PPO rollout",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "warmup_effective": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (policy-layer products: fp32 operands as 3 exact bf16 planes, 6 bf16 MFMA products, fp32 accumulation; "
+            "dtype": (("f32 (policy-layer products: fp32 operands as 2 row-scaled fp16 planes (kept to 2^-22), 3 f16 MFMA products, fp32 accumulation; "
+                       if args.split_format == "f16x2" else
+                       "f32 (policy-layer products: fp32 operands as 3 exact bf16 planes, 6 bf16 MFMA products, fp32 accumulation; ") +
                       "error vs float64 <= the exact-fp32 MFMA kernel's, see policy_layers_error_vs_f64)") if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "f32",
             "data": "synthetic",
             "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
                                    "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else (("mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)" if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "mms_linear2_act (exact fp32 MFMA)") + " + mms_ppo_heads_act"),
+                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else ((("mms_linear_group_act_split16 (2 x fp16 planes, row scales, fp32 accumulate)" if args.split_format == "f16x2" else "mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)") if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "mms_linear2_act (exact fp32 MFMA)") + " + mms_ppo_heads_act"),
                        "friction": {"rule": "average" if abs(eng.config.model.boxgnd_mu) > 0 else "min", "gnd_mu": eng.config.model.gnd_mu,
                                     "boxgnd_mu": eng.config.model.boxgnd_mu, "antbox_mu": eng.config.model.antbox_mu,
                                     "note": "this build's modelling choice (PhysX default combine rule), not reference-pinned: DESIGN.md section 4"},
@@ -440,6 +448,10 @@ def main():
             line["rollout_exact_fp32_layers"] = {"value": world * N * ex_K / ex_elapsed, "unit": "env-steps/s", "steps": ex_K, "ms_per_step": 1e3 * ex_elapsed / ex_K,
                                                  "note": "the same rollout with the hidden layers on the exact-fp32 MFMA kernel (mms_linear2_act, v_mfma_f32_32x32x2_f32): "
                                                          "round 2's headline path, kept as the A/B of the split kernel"}
+        if b3_K:
+            line["rollout_bf16x3_layers"] = {"value": world * N * b3_K / b3_elapsed, "unit": "env-steps/s", "steps": b3_K, "ms_per_step": 1e3 * b3_elapsed / b3_K,
+                                             "note": "the same rollout with the hidden layers on the three-bf16-plane kernel (mms_linear_group_act_split: every operand exact, "
+                                                     "six products): the headline path of this round's first half, kept as an A/B"}
         if layer_err is not None:
             line["policy_layers_error_vs_f64"] = layer_err
         if bf_K:
@@ -452,21 +464,21 @@ def main():
 
 
 def policy_layer_errors(torch, ac, obs):
-    """Both networks' last hidden activations (three layers deep) on the bench's own observation rows and weights: the split kernel
-    and the exact-fp32 MFMA kernel, each against the same layers evaluated in float64."""
+    """Both networks' last hidden activations (three layers deep) on the bench's own observation rows and weights: the two split
+    kernels and the exact-fp32 MFMA kernel, each against the same layers evaluated in float64."""
     import copy
     obs = obs.detach().clone()
     out = {}
     with torch.no_grad():
         ref = [copy.deepcopy(net[:-1]).double()(obs.double()) for net in (ac.actor, ac.critic)]
         scale = float(torch.cat(ref).pow(2).mean().sqrt())
-        for name, split in (("split_3xbf16", True), ("exact_fp32_mfma", False)):
-            keep = ac.split_layers
-            ac.split_layers = split
+        for name, split, fmt in (("split_2xf16", True, "f16x2"), ("split_3xbf16", True, "bf16x3"), ("exact_fp32_mfma", False, None)):
+            keep = (ac.split_layers, ac.split_format)
+            ac.split_layers, ac.split_format = split, (fmt or ac.split_format)
             try:
                 hid = ac._fused_hidden(obs, obs)
             finally:
-                ac.split_layers = keep
+                ac.split_layers, ac.split_format = keep
             if hid is None:
                 return None
             e = torch.cat([hid[g].double() - ref[g] for g in range(2)])

@@ -82,7 +82,7 @@ def _critic_halves(table, n):
 
 
 class GroupedPolicyInference:
-    def __init__(self, actors, critics, seed=0, row_offset=0, fold_layernorm=True, split_layers=True):
+    def __init__(self, actors, critics, seed=0, row_offset=0, fold_layernorm=True, split_layers=True, split_format="f16x2"):
         if len(actors) != len(critics) or not actors:
             raise ValueError("one actor and one critic per agent")
         self._chunks = None
@@ -92,7 +92,8 @@ class GroupedPolicyInference:
             self.n = len(actors)
             self._ranges = [(lo, min(lo + 16, self.n)) for lo in range(0, self.n, 16)]
             self._chunks = [GroupedPolicyInference(actors[lo:hi], critics[lo:hi], seed=int(seed) + lo, row_offset=row_offset,
-                                                   fold_layernorm=fold_layernorm, split_layers=split_layers) for lo, hi in self._ranges]
+                                                   fold_layernorm=fold_layernorm, split_layers=split_layers, split_format=split_format)
+                            for lo, hi in self._ranges]
             return
         for m in list(actors) + list(critics):
             if getattr(m, "_use_recurrent_policy", False) or getattr(m, "_use_naive_recurrent_policy", False):
@@ -110,6 +111,13 @@ class GroupedPolicyInference:
         # feature LayerNorm folded like the critics', and the output heads finished from per-slot partial dot products that the LAST
         # hidden layer's epilogue leaves (mms_marl_heads_finish): the last activations are never written or re-read.
         self.split_layers = bool(split_layers)
+        # The planes: "f16x2" (default) = two fp16 planes per operand under a power-of-two scale per row (csrc/split16_kernels.hip: three
+        # products, 4 bytes per element, error against float64 still below the exact-fp32 kernel's); "bf16x3" = three exact bf16 planes.
+        # Every layer here sits behind a LayerNorm, so the bound that fixes a hidden activation's scale does not depend on the data:
+        # |W~ xhat + c| <= |W~ row|_2 sqrt(K) + |c| with xhat the normalised input (|xhat|_2 <= sqrt(K)).
+        if split_format not in ("f16x2", "bf16x3"):
+            raise ValueError("split_format: f16x2 or bf16x3")
+        self.split_format = split_format
         self.a_blocks = [_blocks(a.base) for a in self.actors]
         self.c_blocks = [_blocks(c.base) for c in self.critics]
         depth = {len(b) for b in self.a_blocks + self.c_blocks}
@@ -210,16 +218,34 @@ class GroupedPolicyInference:
         hwt = (hw * g_last[:, None, :]).contiguous()
         heads = (hwt, hwt.sum(-1).contiguous(), (torch.einsum("gjk,gk->gj", hw, b_last) + hb).contiguous())
 
-        def planes(Wg):                                                                 # [G, N, K] -> G P32 plane tensors
+        h16 = self.split_format == "f16x2"
+        up = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+        def planes(Wg):                                                                 # [G, N, K] -> G plane tensors (+ G inverse row scales)
             G, N, K = Wg.shape
-            out = [torch.empty(N * ((K + 31) // 32) * 192, dtype=torch.uint8, device=self.device) for _ in range(G)]
+            out = [torch.empty(N * ((K + 31) // 32) * (128 if h16 else 192), dtype=torch.uint8, device=self.device) for _ in range(G)]
+            inv = torch.empty(G, N, device=self.device) if h16 else None
+            scr = torch.empty(G, N, device=self.device) if h16 else None
             for lo in range(0, G, 32):
                 src, dst = [Wg[g] for g in range(lo, min(lo + 32, G))], out[lo:lo + 32]
-                _lib.check(L.mms_split_planes_group(idx, len(src), N, K, 0, _ptrs(src), (ctypes.c_void_p * len(dst))(*[t.data_ptr() for t in dst]), stream),
-                           None, "mms_split_planes_group", L)
-            return out
+                if h16:
+                    _lib.check(L.mms_split_planes16_group(idx, len(src), N, K, 0, _ptrs(src), up(dst), up(list(scr[lo:lo + 32].unbind(0))),
+                                                          up(list(inv[lo:lo + 32].unbind(0))), 0, 0, None, None, None, stream), None, "mms_split_planes16_group", L)
+                else:
+                    _lib.check(L.mms_split_planes_group(idx, len(src), N, K, 0, _ptrs(src), up(dst), stream), None, "mms_split_planes_group", L)
+            return (out, inv) if h16 else out
+
+        def out_scale(fold):                                                            # [G] power of two: the layer's output bound at 2^14
+            Wt, _, cv = fold
+            bound = ((Wt.pow(2).sum(-1).sqrt() * float(Wt.shape[-1]) ** 0.5 + cv.abs()).max(-1).values * 1.001).clamp_min(1e-30)
+            return torch.exp2(14.0 - torch.frexp(bound)[1].float())
         self._sp = {"a1": fold_a1, "heads": heads, "w_a1": planes(fold_a1[0]), "w_c1": planes(self._fold_c1[0]),
                     "w": {l: planes(self._fold[l][0]) for l in self._fold}}
+        if h16:
+            # output scales per layer over the 2n networks (actors first): layer 0 = the two first layers, l >= 1 = the H x H layers
+            self._sp["ysc"] = {0: torch.cat([out_scale(fold_a1), out_scale(self._fold_c1)])}
+            for l in self._fold:
+                self._sp["ysc"][l] = out_scale(self._fold[l])
 
     def _param_versions(self):
         """(data_ptr, version) of every source parameter: what the derived copies of refresh() were built from"""
@@ -270,10 +296,17 @@ class GroupedPolicyInference:
         if self._sp is not None:
             sp = self._sp
             up = lambda ts: (self._keep.append(ts), (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]))[1]
-            self.p["sw_a1"], self.p["sw_c1"] = up(sp["w_a1"]), up(sp["w_c1"])
+            h16 = self.split_format == "f16x2"
+            pl_of = (lambda v: v[0]) if h16 else (lambda v: v)
+            self.p["sw_a1"], self.p["sw_c1"] = up(pl_of(sp["w_a1"])), up(pl_of(sp["w_c1"]))
             self.p["fs1_a"], self.p["fc1_a"] = arr(list(sp["a1"][1].unbind(0))), arr(list(sp["a1"][2].unbind(0)))
             for l, pl in sp["w"].items():
-                self.p["sw%d" % l] = up(pl)
+                self.p["sw%d" % l] = up(pl_of(pl))
+            if h16:
+                self.p["swi_a1"], self.p["swi_c1"] = arr(list(sp["w_a1"][1].unbind(0))), arr(list(sp["w_c1"][1].unbind(0)))
+                for l, pl in sp["w"].items():
+                    self.p["swi%d" % l] = arr(list(pl[1].unbind(0)))
+            self._M = None                                        # (the per-row output scales of _buffers are built from this refresh's bounds)
             self.p["hwt"], self.p["hs"], self.p["hc"] = arr(list(sp["heads"][0].unbind(0))), arr(list(sp["heads"][1].unbind(0))), arr(list(sp["heads"][2].unbind(0)))
         self._A = (ctypes.c_int32 * (2 * self.n))(*([self.act_dim] * self.n + [1] * self.n))
         self._A1 = (ctypes.c_int32 * self.n)(*([1] * self.n))
@@ -307,7 +340,8 @@ class GroupedPolicyInference:
             "part": _ptrs(ub(self.part)), "part_a": _ptrs(ub(self.part[:n])), "part_c": _ptrs(ub(self.part[n:])), "stat": _ptrs(ub(self.stat)),
         }
         if self._sp is not None and M % 128 == 0:
-            u8 = lambda g, rows, K: [torch.empty(rows * ((K + 31) // 32) * 192, dtype=torch.uint8, device=dev) for _ in range(g)]
+            h16 = self.split_format == "f16x2"
+            u8 = lambda g, rows, K: [torch.empty(rows * ((K + 31) // 32) * (128 if h16 else 192), dtype=torch.uint8, device=dev) for _ in range(g)]
             self.sx_a, self.sx_c = u8(n, M, self.obs_dim), u8(n, M, self.sobs_dim)
             self.sh = [u8(2 * n, M, H), u8(2 * n, M, H)]
             self.stat_a = z(n, M, 2)
@@ -316,6 +350,17 @@ class GroupedPolicyInference:
             self.q.update({"sx_a": up(self.sx_a), "sx_c": up(self.sx_c), "sx_c0": up([self.sx_c[0]] * n), "sh0": up(self.sh[0]), "sh1": up(self.sh[1]),
                            "sh0_a": up(self.sh[0][:n]), "sh0_c": up(self.sh[0][n:]), "stat_a": _ptrs(ub(self.stat_a)),
                            "hpart": _ptrs(ub(self.head_part)), "hpart_a": _ptrs(ub(self.head_part[:n])), "hpart_c": _ptrs(ub(self.head_part[n:]))})
+            if h16:
+                # row scales of the raw inputs (written by the split) and of the hidden activations (constants of the refresh, one per
+                # network and layer, laid out per row because that is what the kernel reads)
+                self.xs_a, self.xi_a, self.xs_c, self.xi_c = z(n, M), z(n, M), z(n, M), z(n, M)
+                self.ysc = {l: v[:, None].expand(2 * n, M).contiguous() for l, v in self._sp["ysc"].items()}
+                self.yinv = {l: (1.0 / v) for l, v in self.ysc.items()}
+                self.q.update({"xs_a": _ptrs(ub(self.xs_a)), "xi_a": _ptrs(ub(self.xi_a)), "xs_c": _ptrs(ub(self.xs_c)), "xi_c": _ptrs(ub(self.xi_c)),
+                               "xi_c0": _ptrs([self.xi_c[0]] * n)})
+                for l in self.ysc:
+                    self.q["ysc%d" % l], self.q["yinv%d" % l] = _ptrs(ub(self.ysc[l])), _ptrs(ub(self.yinv[l]))
+                self.q["ysc0_a"], self.q["yinv0_a"] = _ptrs(ub(self.ysc[0][:n])), _ptrs(ub(self.yinv[0][:n]))
         _critic_halves(self.q, n)
         self._M = M
 
@@ -325,7 +370,7 @@ class GroupedPolicyInference:
                 and sobs_pitch == self.sobs_dim and self.sobs_dim >= 8)
 
     def _forward_split(self, L, idx, stream, M, obs_p, obs_pitch, sobs_p, with_actors, std_p, out_p, logp_p, pitch_p, cnt_p):
-        """Every layer through mms_linear_group_act_split with all LayerNorms folded and the heads finished from the last layer's
+        """Every layer through mms_linear_group_act_split16 / mms_linear_group_act_split with all LayerNorms folded and the heads finished from the last layer's
         partials: split + row moments of the raw observations, fc1 of the actors (K = obs) and of the critics (K = share_obs), the
         H x H layers of all networks, mms_marl_heads_finish.  with_actors = False: the critics alone (get_values)."""
         n, H, p, q = self.n, self.hidden, self.p, self.q
@@ -335,29 +380,43 @@ class GroupedPolicyInference:
         G = 2 * n if with_actors else n
         last_mode = lambda l: 2 if l == depth - 1 else 1
         heads = lambda l, key_w, key_p: (p[key_w], q[key_p], A) if l == depth - 1 else (None, None, 0)
+        h16 = self.split_format == "f16x2"
+
+        def split(groups, K, pitch, src, dst, xs, xi):
+            if h16:
+                chk(L.mms_split_planes16_group(idx, groups, M, K, pitch, src, q[dst], q[xs], q[xi], 0, 0, None, None, None, stream), "mms_split_planes16_group")
+            else:
+                chk(L.mms_split_planes_group(idx, groups, M, K, pitch, src, q[dst], stream), "mms_split_planes_group")
+
+        def layer(groups, K, x, w, b, y, mode, sv, stat, part, hw, hp, hd, xinv, winv, ysc):
+            if h16:
+                chk(L.mms_linear_group_act_split16(idx, groups, M, H, K, x, w, b, y, xinv, winv, ysc if mode == 1 else None, 1, mode, sv, stat, part, hw, hp, hd, stream),
+                    "mms_linear_group_act_split16")
+            else:
+                chk(L.mms_linear_group_act_split(idx, groups, M, H, K, x, w, b, y, 1, mode, sv, stat, part, hw, hp, hd, stream), "mms_linear_group_act_split")
+        g16 = lambda table, key: table[key] if h16 else None
         if with_actors:
-            chk(L.mms_split_planes_group(idx, n, M, self.obs_dim, obs_pitch, obs_p, q["sx_a"], stream), "mms_split_planes_group")
+            split(n, self.obs_dim, obs_pitch, obs_p, "sx_a", "xs_a", "xi_a")
             chk(L.mms_row_moments_group(idx, n, M, self.obs_dim, obs_pitch, obs_p, q["stat_a"], self.eps, stream), "mms_row_moments_group")
         shared_rows = len({int(v) for v in sobs_p}) == 1                     # one centralised observation for all critics: one pass
         gs = 1 if shared_rows else n
-        chk(L.mms_split_planes_group(idx, gs, M, self.sobs_dim, self.sobs_dim, sobs_p, q["sx_c"], stream), "mms_split_planes_group")
+        split(gs, self.sobs_dim, self.sobs_dim, sobs_p, "sx_c", "xs_c", "xi_c")
         chk(L.mms_row_moments_group(idx, gs, M, self.sobs_dim, self.sobs_dim, sobs_p, q["stat_c"], self.eps, stream), "mms_row_moments_group")
         if with_actors:
             hw, hp, hd = heads(0, "hwt", "hpart_a")
             hw = None if hw is None else (ctypes.c_void_p * n)(*list(hw)[:n])
-            chk(L.mms_linear_group_act_split(idx, n, M, H, self.obs_dim, q["sx_a"], p["sw_a1"], p["fc1_a"], q["sh0_a"], 1, last_mode(0), p["fs1_a"],
-                                             q["stat_a"], q["part_a"], hw, hp, hd, stream), "mms_linear_group_act_split")
+            layer(n, self.obs_dim, q["sx_a"], p["sw_a1"], p["fc1_a"], q["sh0_a"], last_mode(0), p["fs1_a"], q["stat_a"], q["part_a"], hw, hp, hd,
+                  g16(q, "xi_a"), g16(p, "swi_a1"), g16(q, "ysc0_a"))
         hw, hp, hd = heads(0, "hwt/c", "hpart_c")
-        chk(L.mms_linear_group_act_split(idx, n, M, H, self.sobs_dim, q["sx_c0"] if shared_rows else q["sx_c"], p["sw_c1"], p["fc1_c"], q["sh0_c"], 1,
-                                         last_mode(0), p["fs1_c"], q["stat_c0"] if shared_rows else q["stat_c"], q["part_c"], hw, hp, hd, stream),
-            "mms_linear_group_act_split")
+        layer(n, self.sobs_dim, q["sx_c0"] if shared_rows else q["sx_c"], p["sw_c1"], p["fc1_c"], q["sh0_c"], last_mode(0), p["fs1_c"],
+              q["stat_c0"] if shared_rows else q["stat_c"], q["part_c"], hw, hp, hd, g16(q, "xi_c0" if shared_rows else "xi_c"), g16(p, "swi_c1"), g16(q, "ysc0/c"))
         cur = 0
         for l in range(1, depth):
             chk(L.mms_row_stats_chan_group(idx, G, M, slots, q["part" + sfx], q["stat" + sfx], self.eps, stream), "mms_row_stats_chan_group")
             hw, hp, hd = heads(l, "hwt" + sfx, "hpart" + sfx)
-            chk(L.mms_linear_group_act_split(idx, G, M, H, H, q["sh%d%s" % (cur, sfx)], p["sw%d%s" % (l, sfx)], p["fc%d%s" % (l, sfx)],
-                                             q["sh%d%s" % (1 - cur, sfx)], 1, last_mode(l), p["fs%d%s" % (l, sfx)], q["stat" + sfx], q["part" + sfx],
-                                             hw, hp, hd, stream), "mms_linear_group_act_split")
+            layer(G, H, q["sh%d%s" % (cur, sfx)], p["sw%d%s" % (l, sfx)], p["fc%d%s" % (l, sfx)], q["sh%d%s" % (1 - cur, sfx)], last_mode(l),
+                  p["fs%d%s" % (l, sfx)], q["stat" + sfx], q["part" + sfx], hw, hp, hd, g16(q, "yinv%d%s" % (l - 1, sfx)), g16(p, "swi%d%s" % (l, sfx)),
+                  g16(q, "ysc%d%s" % (l, sfx)) if l < depth - 1 else None)
             cur = 1 - cur
         A_arr = self._A if with_actors else self._A1
         chk(L.mms_marl_heads_finish(idx, G, M, slots, q["part" + sfx], q["hpart" + sfx], p["hs" + sfx], p["hc" + sfx], A_arr, std_p, out_p, logp_p,
