@@ -31,7 +31,8 @@
  *   ActorCritic.act sampling tail + RolloutStorage.add_transitions       mms_ppo_act, mms_ppo_heads_act,
  *     (algorithms/rl/ppo/module.py:73-87; storage.py:33-47)              mms_bind_rollout_out
  *   ActorCritic hidden layers (module.py:27-52)                          mms_linear2_act, mms_linear_group_act_split,
- *                                                                        mms_split_planes(_group), mms_row_stats_chan_group,
+ *                                                                        mms_split_planes(_group), mms_split_planes16_group,
+ *                                                                        mms_linear_group_act_split16, mms_row_stats_chan_group,
  *                                                                        mms_marl_heads_finish
  *   Actor / Critic forward of every MAPPO / HAPPO agent                  mms_linear_group_act, mms_layernorm_group,
  *     (algorithms/marl/actor_critic.py:43-69, 137-155; runner.py:186-216)  mms_row_stats_group, mms_marl_heads_act
@@ -339,6 +340,41 @@ int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N,
                                const float* const* b, void* const* y, int32_t act, int32_t out_mode, const float* const* ln_s,
                                const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
                                int32_t head_dim, void* hip_stream);
+
+/* ---- ... and with two scaled fp16 planes per operand (csrc/split16_kernels.hip): the default of the policy modules -----------------
+ * x s = hi + lo 2^-11 with s a power of two per ROW, hi = f16(x s), lo = f16((x s - hi) 2^11): the operand is kept to 2^-22 |x| (worst
+ * case; 4e-8 rms) instead of exactly, in 4 bytes instead of 6, and the product is THREE f16 MFMA products (hi hi, hi lo, lo hi) with fp32
+ * accumulation -- the layers are bound by the operand stream into LDS, so the k-loop takes two thirds of the three-plane kernel's time,
+ * and three LDS stages fit.  Error against the float64 product: 0.39-0.46 x the exact-fp32 MFMA kernel's on the PPO policy's layers,
+ * below it down to K = 32 (tests/test_gpu_parity.py::test_split16_layers_error).  What the two missing bits cost: behind a folded
+ * LayerNorm the operand error is amplified by |mean| / std of the row like the rounding of the activations themselves (x 4 against the
+ * fp32 passes at |mean| / std = 1000, tests/test_marl_policy.py); the three-plane entry points above have exact operands.
+ * Scales: a plane row's scale puts a bound of the row's magnitudes at 2^14 (fp16 ends at 65504).  Inputs (observations, weight rows): the
+ * row's own largest magnitude, found by the split.  Hidden activations: a-priori, |act(W x + b)| <= (largest row 1-norm of W) max|x| +
+ * max|b| (ELU, ReLU, tanh, identity: |act(y)| <= |y|), evaluated per row by the split of the network's input (`chain`); behind a
+ * LayerNorm the bound does not depend on the data (|W~ xhat + c| <= |W~ row|_2 sqrt(K) + |c|) and the caller passes constant scales.
+ * Plane format "H32": f16 [rows, KC, 2, 32], KC = ceil(K / 32): hi and lo of 32 consecutive k of a row, 128 contiguous bytes; columns
+ * past K are zero.  MMS_H32_BYTES(rows, K) bytes. */
+#define MMS_H32_BYTES(rows, K) ((size_t)(rows) * (size_t)(((K) + 31) / 32) * 128)
+
+/* planes_g <- split(x_g) for `groups` matrices [rows, K] f32 (row pitch x_pitch floats, 0 = K; unaligned rows take scalar loads), with
+ * scale[g][r] = the row's power of two and inv[g][r] = 1 / scale (f32 [rows]; entries of the two arrays may be NULL).
+ * nchains > 0: chain[g] = f32 [nchains, L, 2] of (mult, add) per layer; for each chain c and layer l < L the bound
+ * b_{l+1} = (mult_l b_l + add_l) 1.001, b_0 = the row's largest magnitude, gives chain_scale[g][c, l, r] = 2^(14 - e), b_{l+1} <= 2^e, and
+ * chain_inv = its inverse (f32 [nchains, L, rows] each): the y_scale / next x_inv of the layers below. */
+int mms_split_planes16_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch, const float* const* x, void* const* planes,
+                             float* const* scale, float* const* inv, int32_t nchains, int32_t L, const float* const* chain,
+                             float* const* chain_scale, float* const* chain_inv, void* hip_stream);
+
+/* mms_linear_group_act_split with x_g, w_g (and, out_mode 1, y_g) in the H32 format.  x_inv[g] f32 [M] and w_inv[g] f32 [N] (16-byte
+ * aligned) are the inverse row scales of the operands; y_scale[g] f32 [M] (out_mode 1) is the scale the output rows are stored with --
+ * it must put a bound of the row's activations at or below 2^14; the next layer's x_inv is its inverse.  Everything else (out_mode, the
+ * LayerNorm folds, the output-head partials) as mms_linear_group_act_split. */
+int mms_linear_group_act_split16(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
+                                 const float* const* b, void* const* y, const float* const* x_inv, const float* const* w_inv,
+                                 const float* const* y_scale, int32_t act, int32_t out_mode, const float* const* ln_s,
+                                 const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
+                                 int32_t head_dim, void* hip_stream);
 
 /* stat_g[r] = (mean, 1 / sqrt(var + eps)) of row r from mms_linear_group_act_split's ln_part_out (`slots` = N / 64 slots of 64). */
 int mms_row_stats_chan_group(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part, float* const* stat, float eps,

@@ -26,7 +26,8 @@ def main():
     ap.add_argument("--iters", type=int, default=16, help="timed rollouts of T = 8 steps")
     ap.add_argument("--agents", type=int, default=10, help="ants per env: 100 with --num-envs 2048 is BASELINE configs[4]'s per-GPU shard")
     ap.add_argument("--skip-reference-way", action="store_true")
-    ap.add_argument("--exact-fp32-layers", action="store_true", help="A/B: the layers on the exact-fp32 MFMA kernel instead of the three-plane split kernel")
+    ap.add_argument("--exact-fp32-layers", action="store_true", help="A/B: the layers on the exact-fp32 MFMA kernel instead of a split kernel")
+    ap.add_argument("--split-format", default="f16x2", choices=["f16x2", "bf16x3"], help="planes of the split layers: two scaled fp16 (default) or three exact bf16")
     args = ap.parse_args()
     import torch
     import marl_modules as mm
@@ -110,8 +111,9 @@ def main():
     env = make_env()
     sh = SharedRolloutBuffers(conf, env, "cuda:0")
     sh.warmup()
-    inf = GroupedPolicyInference(actors, critics, seed=3, split_layers=not args.exact_fp32_layers)
-    out["policy_layers"] = "mms_linear_group_act (exact fp32 MFMA)" if args.exact_fp32_layers else "mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)"
+    inf = GroupedPolicyInference(actors, critics, seed=3, split_layers=not args.exact_fp32_layers, split_format=args.split_format)
+    out["policy_layers"] = "mms_linear_group_act (exact fp32 MFMA)" if args.exact_fp32_layers else (
+        "mms_linear_group_act_split16 (2 x fp16 planes, row scales, fp32 accumulate)" if args.split_format == "f16x2" else "mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)")
     nxt = torch.zeros(n, A, device="cuda")
 
     def fused():
@@ -142,10 +144,10 @@ def main():
     f_cri = 2.0 * n * A * (sobs_w * H + 2 * H * H + H)
     flops_step = f_act + f_cri + f_cri / T
     tf = flops_step / (out["fused_graph"]["ms_per_env_step"] * 1e-3) / 1e12
-    peak = 157.3 if args.exact_fp32_layers else 2500.0 / 6.0
+    peak = 157.3 if args.exact_fp32_layers else 2500.0 / (3.0 if args.split_format == "f16x2" else 6.0)
     out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "frac_of_fp32_mfma_peak": tf / 157.3,
                        "note": "fp32-equivalent layer FLOPs per env step / whole env-step time (inference + env step + buffers + GAE); peak = the fp32 MFMA "
-                               "peak for the exact kernel, the bf16 dense peak / 6 plane products for the split kernel"}
+                               "peak for the exact kernel, the 16-bit dense peak / 3 (fp16 planes) or / 6 (bf16 planes) plane products for the split kernels"}
     if "reference_way_eager" in out:
         out["speedup_eager"] = out["reference_way_eager"]["ms_per_env_step"] / out["fused_eager"]["ms_per_env_step"]
         out["speedup_graph_vs_reference_eager"] = out["reference_way_eager"]["ms_per_env_step"] / out["fused_graph"]["ms_per_env_step"]
