@@ -211,7 +211,10 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
 
     // `acc` takes hi hi, `lo` the two cross products (2^11 times their value); added once at the end
     f32x4 acc[MT][4], lo[MT][4];
-    constexpr bool kDmaBehindFirstTile = MT == 4;
+#ifndef MMS_S16_DMA_BEHIND
+#define MMS_S16_DMA_BEHIND (MT == 4)
+#endif
+    constexpr bool kDmaBehindFirstTile = MMS_S16_DMA_BEHIND;
 
     auto step = [&](int buf, bool more, int kc_next, int buf_next) {
         const uint8_t* base = lds + buf * G::BUF;
