@@ -160,7 +160,8 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // waits until at most the DMA of slice k + 1 (its own NDMA instructions, the youngest) is outstanding -- slice k has landed --, the
 // raw barrier makes that true for all waves and says that everyone is done reading slice k - 1, whose buffer then takes the DMA of
 // slice k + 2.  Nothing in the loop waits for vmcnt(0) except a tile's last step.
-template <int MT, int OUT, int LN>
+// ELU: the activation is ELU (compile time: straight-line epilogue); false = a.act at run time (ReLU, tanh, identity: not on a hot path).
+template <int MT, int OUT, int LN, bool ELU>
 __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArgs a) {
     using G = Geom16<MT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -326,18 +327,22 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
         }
         uint8_t* scr_base = lds + (G::SCRATCH_IN_BUF ? blast * G::BUF : 3 * G::BUF);
         const int act = a.act;
-        // hi hi + 2^-11 cross, the operands' scales undone (powers of two: exact), bias, activation -- in place of the accumulators
+        // hi hi + 2^-11 cross, the operands' scales undone (powers of two: exact), bias, activation -- in place of the accumulators.
+        // Four-wide vector arithmetic (packed fp32 instructions: the accumulators sit in aligned register pairs); with ELU known at
+        // compile time the whole block is straight-line code (a per-element switch on `act` puts every element into basic blocks of
+        // its own, with scalar branches and a dependent mul -> exp -> add -> select chain each).
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) {
-                const float wv[4] = {wi[nt].x, wi[nt].y, wi[nt].z, wi[nt].w}, bb[4] = {bias[nt].x, bias[nt].y, bias[nt].z, bias[nt].w};
+                const f32x4 w4 = f32x4{wi[nt].x, wi[nt].y, wi[nt].z, wi[nt].w};
+                f32x4 raw = ((acc[mt][nt] + lo[mt][nt] * (1.f / kLoScale)) * w4) * xi[mt];
+                if constexpr (LN == 0) {
+                    raw += f32x4{bias[nt].x, bias[nt].y, bias[nt].z, bias[nt].w};
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float raw = ((acc[mt][nt][r] + lo[mt][nt][r] * (1.f / kLoScale)) * wv[r]) * xi[mt];
-                    if constexpr (LN == 0) acc[mt][nt][r] = act16_apply(raw + bb[r], act);
-                    else acc[mt][nt][r] = raw;
+                    for (int r = 0; r < 4; r++) raw[r] = act16_apply(raw[r], ELU ? 1 : act);
                 }
+                acc[mt][nt] = raw;
             }
         if constexpr (LN != 0) {
             float2* __restrict__ part = reinterpret_cast<float2*>(a.part_out[e_gi]) + (size_t)(2 * e_tn + wn) * a.M;
@@ -458,7 +463,7 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
 }
 
 static hipError_t allow_lds16(const void* kernel, int slot, size_t bytes) {
-    static bool done[8][64] = {};
+    static bool done[16][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -486,8 +491,8 @@ hipError_t launch_linear_split16(const Split16LinearArgs& a, int groups, hipStre
     if (a.out_mode < 0 || a.out_mode > 2 || (ln && a.out_mode == 0) || (!ln && a.out_mode == 2)) return hipErrorInvalidValue;
 #define MMS_LAUNCH_SPLIT16(MT, OUT, LNF, SLOT)                                                                                 \
     {                                                                                                                          \
-        auto kern = linear_split16_kernel<MT, OUT, LNF>;                                                                       \
-        if (hipError_t e = allow_lds16(reinterpret_cast<const void*>(kern), SLOT, Geom16<MT>::LDS); e != hipSuccess) return e; \
+        auto kern = (LNF != 0 || a.act == 1) ? linear_split16_kernel<MT, OUT, LNF, true> : linear_split16_kernel<MT, OUT, LNF, false>; \
+        if (hipError_t e = allow_lds16(reinterpret_cast<const void*>(kern), SLOT + ((LNF != 0 || a.act == 1) ? 0 : 8), Geom16<MT>::LDS); e != hipSuccess) return e; \
         Split16LinearArgs b = a;                                                                                               \
         b.tiles = (int)((int64_t)groups * (a.M / (64 * MT)) * (a.N / 128));                                                    \
         const unsigned grid = (unsigned)(b.tiles < cus ? b.tiles : cus);        /* persistent: at most one block per CU */      \
