@@ -369,6 +369,7 @@ def main():
     elapsed, K, W, graphed = measure_rollout(pdtype, args.steps, args.warmup, split=not args.exact_fp32_layers)
     graph = graphed or None
     layer_err = policy_layer_errors(torch, ac, obs_clipped) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
+    layer_roof = policy_layer_roofline(torch, ac, obs_clipped, args) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
     eng.bind_obs_out(None)
     eng.bind_rollout_out(None, None)
     eng.set_obs_outputs(True, True)
@@ -454,6 +455,8 @@ def main():
                                                      "six products): the headline path of this round's first half, kept as an A/B"}
         if layer_err is not None:
             line["policy_layers_error_vs_f64"] = layer_err
+        if layer_roof is not None:
+            line["roofline_policy_layers"] = layer_roof
         if bf_K:
             line["rollout_bf16_policy"] = {"value": world * N * bf_K / bf_elapsed, "unit": "env-steps/s", "steps": bf_K,
                                            "note": "same rollout with the policy MLPs in bf16 (fp32 accumulate); informational, not the headline"}
@@ -461,6 +464,41 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     eng.close()
+
+
+def policy_layer_roofline(torch, ac, obs, args):
+    """The hidden layers of both networks (the kernels that take two thirds of a rollout step), timed live with HIP events: the
+    launches of ActorCritic._fused_hidden back to back on the bench's observation rows -- the observation's split + the three layer
+    launches.  achieved = plane-product FLOPs (2 M N K per network and layer x the products the format forms per fp32 product) per
+    second, peak = the dense 16-bit MFMA peak of MI355X_MICROARCH.md; the fp32-equivalent rate beside it."""
+    obs = obs.detach().clone()
+    lins = [m for m in ac.actor if isinstance(m, torch.nn.Linear)][:-1]
+    M = obs.shape[0]
+    flops32 = 2.0 * 2.0 * M * sum(l.in_features * l.out_features for l in lins)
+    split = ac.split_layers and ac._split_applies(M, lins)
+    products = (3 if ac.split_format == "f16x2" else 6) if split else 1
+    with torch.no_grad():
+        for _ in range(8):
+            if ac._fused_hidden(obs, obs) is None:
+                return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 64
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            ac._fused_hidden(obs, obs)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    peak = 2500.0 if split else 157.3
+    achieved = flops32 * products / (ms * 1e-3) / 1e12
+    kernel = ("mms::linear_split16_kernel (2 fp16 planes)" if ac.split_format == "f16x2" else "mms::linear_split_kernel (3 bf16 planes)") if split else "mms::linear_act_fast_kernel (fp32 MFMA)"
+    return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "fp32_equivalent_tflops": flops32 / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flops32 / (ms * 1e-3) / 1e12 / 157.3,
+            "ms_per_pass": ms, "launches_per_pass": len(lins) + (1 if split else 0), "plane_products_per_fp32_product": products, "traffic": None,
+            "note": "both networks' hidden layers [%s] at %d rows: observation split + one launch per layer, eager, back to back, HIP events; "
+                    "achieved counts every plane product the matrix pipe executes; the layers are bound by the L2 -> LDS operand stream "
+                    "(48 KB per 256 x 128 k-step and CU), not by the pipe: DESIGN.md 5.10" % (", ".join(str(l.out_features) for l in lins), M)}
 
 
 def policy_layer_errors(torch, ac, obs):

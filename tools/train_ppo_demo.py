@@ -29,7 +29,8 @@ def main():
     ap.add_argument("--fixed-lr", action="store_true", help="no adaptive KL schedule")
     ap.add_argument("--value-coef", type=float, default=1.0)
     ap.add_argument("--exact-fp32-layers", action="store_true",
-                    help="hidden layers on the exact-fp32 MFMA kernel instead of the three-plane split kernel (which applies when batch and hidden widths are multiples of 128)")
+                    help="hidden layers on the exact-fp32 MFMA kernel instead of the split kernel (which applies when batch and hidden widths are multiples of 128)")
+    ap.add_argument("--split-format", default="f16x2", choices=["f16x2", "bf16x3"], help="planes of the split layer kernel (module default: f16x2)")
     ap.add_argument("--friction-combine", default="average", choices=["average", "min"],
                     help="cfg env.frictionCombine: PhysX's average rule (default) or min = a box that is frictionless against everything")
     args = ap.parse_args()
@@ -57,6 +58,7 @@ def main():
     ac = ActorCritic((obs_dim,), (0,), (act_dim,), 0.8, {"pi_hid_sizes": args.hidden, "vf_hid_sizes": args.hidden, "activation": "elu"},
                      seed=args.seed).to(dev)
     ac.split_layers = not args.exact_fp32_layers
+    ac.split_format = args.split_format
     storage = RolloutStorage(N, T, (obs_dim,), (0,), (act_dim,), device=str(dev))
     opt = torch.optim.Adam(ac.parameters(), lr=args.lr)
     lr = args.lr
