@@ -93,6 +93,8 @@ def main():
                     help="A/B: headline with the hidden layers on the exact-fp32 MFMA kernel (mms_linear2_act) instead of a split kernel")
     ap.add_argument("--split-format", default="f16x2", choices=["f16x2", "bf16x3"],
                     help="planes of the split layer kernel: two scaled fp16 planes (mms_linear_group_act_split16, default) or three exact bf16 planes (mms_linear_group_act_split)")
+    ap.add_argument("--no-obs-planes", action="store_true",
+                    help="A/B: the policy splits the observation rows itself (mms_split_planes16_group) instead of reading the operand planes the step kernel writes beside them (mms_bind_obs_planes16)")
     ap.add_argument("--one-stream", action="store_true", help="A/B: actor and critic MLPs on one stream")
     ap.add_argument("--defer-critic", action="store_true",
                     help="A/B: let the critic pass overlap the sampling kernel and the env step (joined before the GAE); faster, but "
@@ -210,6 +212,10 @@ def main():
     kernel_ms_pre = time_step_kernel()
 
     # ---- PPO rollout series -----------------------------------------------------------------------------------
+    PLANES_SCALE = 2048.0                                                   # clip_obs 5 x 2^11 <= 2^14
+    planes_buf = torch.empty(N * ((obs_dim + 31) // 32) * 128, dtype=torch.uint8, device=device)
+    planes_state = {"used": False}
+
     def measure_rollout(pdtype, K_req, W_req, split=True, fmt=None):
         ac_ = ac if pdtype == torch.float32 else ac_bf16
         ac_.split_layers = bool(split)
@@ -220,6 +226,14 @@ def main():
         ac_.fuse_layers = not args.library_gemms
         ac_.defer_value = args.defer_critic and not args.one_stream
 
+        # The step kernel also leaves the clamped row as the layers' operand planes (two fp16 planes, constant scale 2^11: the row is
+        # bounded by clip_obs = 5): the policy then has no split pass over the observation.  Valid from the first step on.
+        use_planes = (pdtype == torch.float32 and split and ac_.split_format == "f16x2" and not args.no_obs_planes and not args.unfused
+                      and not args.library_gemms and ac_._split_applies(N, [m for m in ac_.actor if isinstance(m, torch.nn.Linear)][:-1]))
+        planes_state["used"] = use_planes
+        planes_valid = [False]
+        eng.bind_obs_planes(planes_buf if use_planes else None, PLANES_SCALE)
+
         def rollout_step_fused():
             # Zero-copy rollout: the engine writes observation t+1, reward t and done t into the storage slots, mms_ppo_act
             # writes the action into the engine and action / log-prob / value / mu / sigma into slot t; add_transitions
@@ -228,18 +242,21 @@ def main():
             obs_t = storage.observations[t]
             if t == 0:
                 obs_t.copy_(obs_clipped)                                     # the first slot of a rollout: the current observation
-            act, logp, value, mu, sigma = ac_.act(obs_t, states)             # module.py:73-87
+            pl = (planes_buf, PLANES_SCALE) if (use_planes and planes_valid[0]) else None
+            act, logp, value, mu, sigma = ac_.act(obs_t, states, obs_planes=pl)   # module.py:73-87
             last = t + 1 == NSTEPS
             eng.bind_obs_out(None if last else storage.observations[t + 1])
             if not args.all_obs_rows:
                 eng.set_obs_outputs(raw=False, clipped=last)                 # one observation row per env-step, not three
             eng.bind_rollout_out(storage.rewards[t].view(-1), storage.dones[t].view(-1))
             eng.step()
+            planes_valid[0] = True
             storage.add_transitions(obs_t, states, act, storage.rewards[t], storage.dones[t], value, logp, mu, sigma)
             if storage.step == NSTEPS:
                 ac_.join()                                                   # deferred critic passes: values are read from here on
                 with torch.no_grad():
-                    last_values = (ac_.critic(obs_clipped.to(pdtype)) if args.library_gemms else ac_.value(obs_clipped.to(pdtype))).float()
+                    last_values = (ac_.critic(obs_clipped.to(pdtype)) if args.library_gemms else
+                                   ac_.value(obs_clipped.to(pdtype), obs_planes=(planes_buf, PLANES_SCALE) if use_planes else None)).float()
                 storage.compute_returns(last_values, GAMMA, LAM)
                 storage.clear()
 
@@ -371,6 +388,7 @@ def main():
     layer_err = policy_layer_errors(torch, ac, obs_clipped) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
     layer_roof = policy_layer_roofline(torch, ac, obs_clipped, args) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
     eng.bind_obs_out(None)
+    eng.bind_obs_planes(None)
     eng.bind_rollout_out(None, None)
     eng.set_obs_outputs(True, True)
     kernel_ms_post = time_step_kernel()
@@ -416,7 +434,7 @@ def main():
             "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
                                    "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else ((("mms_linear_group_act_split16 (2 x fp16 planes, row scales, fp32 accumulate)" if args.split_format == "f16x2" else "mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)") if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "mms_linear2_act (exact fp32 MFMA)") + " + mms_ppo_heads_act"),
+                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "obs_planes_from_step_kernel": bool(planes_state["used"]), "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else ((("mms_linear_group_act_split16 (2 x fp16 planes, row scales, fp32 accumulate)" if args.split_format == "f16x2" else "mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)") if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "mms_linear2_act (exact fp32 MFMA)") + " + mms_ppo_heads_act"),
                        "friction": {"rule": "average" if abs(eng.config.model.boxgnd_mu) > 0 else "min", "gnd_mu": eng.config.model.gnd_mu,
                                     "boxgnd_mu": eng.config.model.boxgnd_mu, "antbox_mu": eng.config.model.antbox_mu,
                                     "note": "this build's modelling choice (PhysX default combine rule), not reference-pinned: DESIGN.md section 4"},

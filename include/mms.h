@@ -169,6 +169,12 @@ int mms_set_state(mms_handle h, const char* name, const void* src, int src_is_ho
  * [T,N,obs_dim]; NULL disables.  The pointer must stay valid until the next bind. */
 int mms_bind_obs_out(mms_handle h, void* dst);
 
+/* Optional extra destination for the clamped observation row AS THE POLICY LAYERS' OPERAND PLANES (format H32 of
+ * mms_linear_group_act_split16 below: f16 [N, ceil(obs_dim / 32), 2, 32], MMS_H32_BYTES(N, obs_dim) bytes, 16-byte aligned): hi and lo
+ * planes of row * scale.  The row is bounded by clip_observations, so the scale is a constant (a power of two, clip_observations * scale
+ * <= 2^14) and the policy needs no split pass over the observation (x_inv = 1 / scale for every row).  NULL disables.  Ant tasks only. */
+int mms_bind_obs_planes16(mms_handle h, void* planes, float scale);
+
 /* Optional source of the actions: mms_step reads `src` (f32 [N, num_actions], on the engine's device) IN PLACE instead of the
  * engine's own "actions" buffer -- the tensor VecTaskPython.step(actions) was handed (vec_task.py:126-131 clamps and copies it into
  * the task; here the clamp is in the kernel and the copy is gone).  NULL returns to the "actions" buffer.  The pointer must stay

@@ -161,7 +161,7 @@ class ActorCritic(nn.Module):
             self._wplanes[("h", id(lin))] = hit
         return hit[1], hit[2], hit[3], hit[0]
 
-    def _split_hidden16(self, nets, inputs, tag):
+    def _split_hidden16(self, nets, inputs, tag, planes=None):
         """As _split_hidden on two scaled fp16 planes per operand (mms_split_planes16_group / mms_linear_group_act_split16).  The
         kernel that splits a network's input also evaluates, per row, the scales of the hidden activations behind it from the
         layers' bound chain."""
@@ -195,6 +195,7 @@ class ActorCritic(nn.Module):
                 grp = next(u for u in users if u[0] == first)
                 src.append((first, len(grp)))
                 grp.append(g)
+        given = planes is not None and len(users) == 1          # the caller's planes of the one input every network reads
         for grp in users:
             g0 = grp[0]
             x = inputs[g0]
@@ -208,10 +209,29 @@ class ActorCritic(nn.Module):
                     hit = (ckey, torch.stack([torch.stack([wpl[g][li][2] for li in range(nl - 1)]) for g in grp]).contiguous())
                     bufs["chain"][g0] = hit
                 chain = hit[1]
+            if given:
+                # rows bounded by 2^14 / scale (the engine clamps them to clip_obs <= that): constant scales, evaluated here with the
+                # kernel's own recurrence -- once per refresh of the weights
+                pl, scale = planes
+                assert pl.dtype == torch.uint8 and pl.numel() == self._h32_bytes(M, x.shape[1]) and pl.device == dev
+                ckey = (float(scale), None if chain is None else hit[0])
+                if bufs.get("given_key") != ckey:
+                    bufs["xi"][g0].fill_(1.0 / float(scale))
+                    if nch:
+                        bound = torch.full((nch,), 16384.0 / float(scale), device=dev)
+                        for li in range(nl - 1):
+                            bound = (chain[:, li, 0] * bound + chain[:, li, 1]) * 1.001
+                            sc = torch.exp2(14.0 - torch.frexp(bound)[1].float())
+                            bufs["cs"][g0][:nch, li] = sc[:, None]
+                            bufs["ci"][g0][:nch, li] = (1.0 / sc)[:, None]
+                    bufs["given_key"] = ckey
+                bufs["x_given"] = pl
+                continue
+            bufs["given_key"] = None
             _lib.check(L.mms_split_planes16_group(idx, 1, M, x.shape[1], x.stride(0), arr([x]), arr([bufs["x"][g0]]), arr([bufs["xs"][g0]]), arr([bufs["xi"][g0]]),
                                                   nch, nl - 1 if nch else 0, arr([chain]) if nch else None, arr([bufs["cs"][g0]]) if nch else None,
                                                   arr([bufs["ci"][g0]]) if nch else None, stream), None, "mms_split_planes16_group", L)
-        cur = [bufs["x"][src[g][0]] for g in range(G)]
+        cur = [bufs["x_given"] if given else bufs["x"][src[g][0]] for g in range(G)]
         cur_inv = [bufs["xi"][src[g][0]] for g in range(G)]
         for li in range(nl):
             lins = [net[li] for net in nets]
@@ -238,12 +258,12 @@ class ActorCritic(nn.Module):
             need = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 1
         return max(networks * (M // 128) * (l.out_features // 128) for l in lins) >= need
 
-    def _split_hidden(self, nets, inputs, tag):
+    def _split_hidden(self, nets, inputs, tag, planes=None):
         """Hidden layers of the networks in `nets` (lists of their hidden Linear layers, the same shapes in every network), one
         mms_linear_group_act_split launch per layer for all of them.  `inputs`: one fp32 [M, K] tensor per network (the same tensor
         twice is split once).  Activations stay in the three-plane format between the layers; the last one leaves fp32 [M, H]."""
         if self.split_format == "f16x2":
-            return self._split_hidden16(nets, inputs, tag)
+            return self._split_hidden16(nets, inputs, tag, planes)
         assert self.split_format == "bf16x3", self.split_format
         x0 = inputs[0]
         dev, M, K = x0.device, x0.shape[0], x0.shape[1]
@@ -281,7 +301,7 @@ class ActorCritic(nn.Module):
             cur = out
         return bufs["out"]
 
-    def _fused_hidden(self, x, critic_in):
+    def _fused_hidden(self, x, critic_in, planes=None):
         """Hidden layers of BOTH networks, one launch per layer (bias + ELU in the epilogue): mms_linear_group_act_split (three-plane
         operands on the bf16 pipe) when the shapes allow, else mms_linear2_act (fp32 MFMA).
         Returns (actor hidden, critic hidden) or None when the two MLPs are not ELU networks of identical hidden shapes."""
@@ -295,7 +315,7 @@ class ActorCritic(nn.Module):
         ha, hc = x.contiguous(), critic_in.contiguous()
         M = ha.shape[0]
         if self._split_applies(M, a_lin[:-1]) and ha.data_ptr() % 16 == 0 and hc.data_ptr() % 16 == 0:
-            out = self._split_hidden([a_lin[:-1], c_lin[:-1]], [ha, hc], "act")
+            out = self._split_hidden([a_lin[:-1], c_lin[:-1]], [ha, hc], "act", planes)
             return out[0], out[1]
         # activations of the hidden layers: allocated once per (batch, device) and reused -- the eager path would otherwise take an
         # allocator round trip per layer and call
@@ -374,12 +394,15 @@ class ActorCritic(nn.Module):
                        None, "mms_ppo_heads_act", L)
         return act, logp.view(-1), val, mu, sigma
 
-    def act(self, observations, states):
+    def act(self, observations, states, obs_planes=None):
+        """module.py:73-87.  obs_planes = (planes, scale), optional and not in the reference: the H32 operand planes of THESE observation
+        rows as the engine wrote them beside the rows (Engine.bind_obs_planes / mms_bind_obs_planes16) -- the split layers then skip
+        their own pass over the observation.  The caller vouches that the planes belong to `observations`; ignored on every other path."""
         with torch.no_grad():
             dtype = self.log_std.dtype                              # a bf16 copy of the module takes fp32 observations
             critic_in = (states if self.asymmetric else observations).to(dtype)
             if self.fuse_layers and observations.is_cuda and dtype == torch.float32 and not self.defer_value:
-                hidden = self._fused_hidden(observations, critic_in)
+                hidden = self._fused_hidden(observations, critic_in, None if self.asymmetric else obs_planes)
                 if hidden is not None:
                     ha, hc = hidden
                     la, lc = self.actor[-1], self.critic[-1]
@@ -430,7 +453,7 @@ class ActorCritic(nn.Module):
         if self._side is not None:
             torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
-    def value(self, critic_in):
+    def value(self, critic_in, obs_planes=None):
         """Not in the reference (ppo.py:163 calls `act` once more for the bootstrap value of a rollout and discards the action): the
         critic alone, [N, 1].  fp32 ELU critics on the GPU run their hidden layers through mms_linear2_act (one network; bias + ELU
         in the epilogue) and the 1-wide output layer as a matrix-vector product; anything else goes through the torch module."""
@@ -448,7 +471,7 @@ class ActorCritic(nn.Module):
             p = lambda t: ctypes.c_void_p(t.data_ptr())
             h, M = x.contiguous(), x.shape[0]
             if self._split_applies(M, lin[:-1], networks=1) and h.data_ptr() % 16 == 0:
-                h = self._split_hidden([lin[:-1]], [h], "value")[0]
+                h = self._split_hidden([lin[:-1]], [h], "value", obs_planes)[0]
             else:
                 key = (M, str(x.device))
                 if self._value_bufs is None or self._value_bufs[0] != key:

@@ -28,6 +28,42 @@ static void store_rigid(float* r, const RigidState& B) {
 }
 static float quad4(const float x[4]) { return (x[0] + x[1]) + (x[2] + x[3]); }
 
+// fp32 <-> fp16 as the device converts (v_cvt_f16_f32: round to nearest even, subnormals kept)
+static inline uint16_t f2h(float f) {                                     // round to nearest even, subnormals kept, as v_cvt_f16_f32
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);               // rounds to 65520 or more: infinity
+    if (u < 0x38800000u) {                                                // below 2^-14: a subnormal half (or zero)
+        if (u < 0x33000000u) return (uint16_t)sign;                       // below 2^-25: zero
+        const int e = (int)(u >> 23);                                     // biased exponent, 102 .. 112
+        uint32_t m = (u & 0x7fffffu) | 0x800000u;                         // 24-bit significand
+        const int shift = 126 - e;                                        // the half's unit is 2^-24: value = m 2^(e - 150) = (m >> shift) 2^-24
+        const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+    }
+    const uint32_t r = u + 0xfffu + ((u >> 13) & 1u);                      // round the 13 dropped bits to nearest even
+    return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
+}
+static inline float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else {
+            const float v = (float)m * 5.9604644775390625e-08f;           // m 2^-24, exact
+            memcpy(&u, &v, 4);
+            u |= sign;
+        }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 // The engine's buffers (include/mms.h: mms_get_tensor names).  obs / obs_clipped / obs_out / rew_out / done_out may be NULL
 // (mms_set_obs_outputs, mms_bind_obs_out, mms_bind_rollout_out); dr is NULL unless mms_set_dr(h, 1).
 struct HostBufs {
@@ -35,6 +71,7 @@ struct HostBufs {
     float* root_states; const float* initial_root_states; float* dof_state; const float* env_origin; float* prev;
     const float* reset_noise; float* foot_sensors; int64_t* reset_count; const float* dr;
     float* obs_out = nullptr; float* rew_out = nullptr; uint8_t* done_out = nullptr;
+    uint16_t* obs_planes = nullptr; float obs_planes_scale = 1.f;      // mms_bind_obs_planes16 (H32 planes of the clamped row)
 };
 
 static void host_ant_env(const mms_config* C, const HostBufs& b, int env, int do_physics, int obs_dim, int prev_dim) {
@@ -198,6 +235,15 @@ static void host_ant_env(const mms_config* C, const HostBufs& b, int env, int do
         if (b.obs) b.obs[(size_t)env * obs_dim + i] = s_obs[i];
         if (b.obs_clipped) b.obs_clipped[(size_t)env * obs_dim + i] = c;
         if (b.obs_out) b.obs_out[(size_t)env * obs_dim + i] = c;
+    }
+    if (b.obs_planes) {                                                 // as the epilogue of ant_step_kernel
+        const int KC = (obs_dim + 31) / 32;
+        for (int k = 0; k < KC * 32; k++) {
+            const float t = k < obs_dim ? clampf(s_obs[k], -C->clip_obs, C->clip_obs) * b.obs_planes_scale : 0.f;
+            uint16_t* c = b.obs_planes + ((size_t)env * KC + k / 32) * 64 + k % 32;
+            c[0] = f2h(t);
+            c[32] = f2h((t - h2f(c[0])) * 2048.f);
+        }
     }
 }
 

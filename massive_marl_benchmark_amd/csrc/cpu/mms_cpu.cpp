@@ -36,6 +36,8 @@ struct mms_engine {
     mms_config cfg;
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
     float* obs_out = nullptr;
+    void* obs_planes = nullptr;
+    float obs_planes_scale = 1.f;
     const float* actions_in = nullptr;
     int write_raw_obs = 1, write_clipped_obs = 1, dr_enabled = 0;
     float* rew_out = nullptr;
@@ -191,6 +193,7 @@ static int do_step(mms_handle h, int physics) {
                     buf<float>(h, "dof_state"), buf<float>(h, "env_origin"), buf<float>(h, "prev"), buf<float>(h, "reset_noise"),
                     buf<float>(h, "foot_sensors"), buf<int64_t>(h, "reset_count"), h->dr_enabled ? buf<float>(h, "dr_params") : nullptr};
     b.obs_out = h->obs_out; b.rew_out = h->rew_out; b.done_out = h->done_out;
+    b.obs_planes = (uint16_t*)h->obs_planes; b.obs_planes_scale = h->obs_planes_scale;
     const mms_config* C = &h->cfg;
 #pragma omp parallel for schedule(static)
     for (int env = 0; env < C->num_envs; env++) {
@@ -225,6 +228,17 @@ MMS_API int mms_set_state(mms_handle h, const char* name, const void* src, int, 
 MMS_API int mms_bind_obs_out(mms_handle h, void* dst) {
     if (!h) return fail(nullptr, "mms_bind_obs_out: null handle");
     h->obs_out = (float*)dst;
+    return 0;
+}
+MMS_API int mms_bind_obs_planes16(mms_handle h, void* planes, float scale) {
+    if (!h) return fail(nullptr, "mms_bind_obs_planes16: null handle");
+    if (!planes) { h->obs_planes = nullptr; return 0; }
+    if (h->cfg.task == MMS_TASK_MULTI_INGENUITY) return fail(h, "mms_bind_obs_planes16: not for the helicopter task (its policies' layers are 256 wide: exact-fp32 kernel)");
+    int e = 0;
+    if (!(scale > 0.f) || frexpf(scale, &e) != 0.5f) return fail(h, "mms_bind_obs_planes16: the scale must be a power of two");
+    if (!(h->cfg.clip_obs * scale <= 16384.f)) return fail(h, "mms_bind_obs_planes16: clip_observations x scale must not exceed 2^14 (fp16 planes)");
+    h->obs_planes = planes;
+    h->obs_planes_scale = scale;
     return 0;
 }
 MMS_API int mms_bind_actions(mms_handle h, const float* src) {
@@ -555,40 +569,8 @@ MMS_API int mms_linear_group_act_split(int device, int32_t groups, int64_t M, in
 }
 
 // ---- the same with two scaled fp16 planes per operand (csrc/split16_kernels.hip), format H32 = f16 [rows, KC, 2, 32] -------------------
-static inline uint16_t f2h(float f) {                                     // round to nearest even, subnormals kept, as v_cvt_f16_f32
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    const uint32_t sign = (u >> 16) & 0x8000u;
-    u &= 0x7fffffffu;
-    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
-    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);               // rounds to 65520 or more: infinity
-    if (u < 0x38800000u) {                                                // below 2^-14: a subnormal half (or zero)
-        if (u < 0x33000000u) return (uint16_t)sign;                       // below 2^-25: zero
-        const int e = (int)(u >> 23);                                     // biased exponent, 102 .. 112
-        uint32_t m = (u & 0x7fffffu) | 0x800000u;                         // 24-bit significand
-        const int shift = 126 - e;                                        // the half's unit is 2^-24: value = m 2^(e - 150) = (m >> shift) 2^-24
-        const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
-        return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
-    }
-    const uint32_t r = u + 0xfffu + ((u >> 13) & 1u);                      // round the 13 dropped bits to nearest even
-    return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
-}
-static inline float h2f(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
-    uint32_t u;
-    if (e == 0) {
-        if (m == 0) u = sign;
-        else {
-            const float v = (float)m * 5.9604644775390625e-08f;           // m 2^-24, exact
-            memcpy(&u, &v, 4);
-            u |= sign;
-        }
-    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
-    else u = sign | ((e + 112u) << 23) | (m << 13);
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
+using mms::f2h;
+using mms::h2f;
 static inline void pow2_scale(float bound, float& scale, float& inv) {    // as split16_kernels.hip
     int e = 14;
     if (bound > 0.f) (void)frexpf(bound, &e);

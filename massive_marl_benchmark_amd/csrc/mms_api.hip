@@ -41,6 +41,8 @@ struct mms_engine {
     mms_config* d_cfg = nullptr;
     int actors = 0, dofs = 0, num_actions = 0, obs_dim = 0, prev_dim = 0;
     float* obs_out = nullptr;
+    void* obs_planes = nullptr;
+    float obs_planes_scale = 1.f;
     const float* actions_in = nullptr;      // mms_bind_actions
     void* scratch = nullptr;                // staging of mms_set_state(env_ids)
     size_t scratch_bytes = 0;
@@ -266,6 +268,7 @@ static mms::StepArgs step_args(mms_handle h, int physics) {
     a.obs = h->write_raw_obs ? (float*)find(h, "obs")->ptr : nullptr;
     a.obs_clipped = h->write_clipped_obs ? (float*)find(h, "obs_clipped")->ptr : nullptr;
     a.obs_out = h->obs_out;
+    a.obs_planes = h->obs_planes; a.obs_planes_scale = h->obs_planes_scale;
     a.rew_out = h->rew_out;
     a.done_out = h->done_out;
     a.rew = (float*)find(h, "rew")->ptr;
@@ -358,6 +361,19 @@ __attribute__((visibility("default"))) int mms_set_state(mms_handle h, const cha
 __attribute__((visibility("default"))) int mms_bind_obs_out(mms_handle h, void* dst) {
     if (!h) return fail(nullptr, "mms_bind_obs_out: null handle");
     h->obs_out = (float*)dst;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_bind_obs_planes16(mms_handle h, void* planes, float scale) {
+    if (!h) return fail(nullptr, "mms_bind_obs_planes16: null handle");
+    if (!planes) { h->obs_planes = nullptr; return 0; }
+    if (h->cfg.task == MMS_TASK_MULTI_INGENUITY) return fail(h, "mms_bind_obs_planes16: not for the helicopter task (its policies' layers are 256 wide: exact-fp32 kernel)");
+    int e = 0;
+    if (!(scale > 0.f) || frexpf(scale, &e) != 0.5f) return fail(h, "mms_bind_obs_planes16: the scale must be a power of two");
+    if (!(h->cfg.clip_obs * scale <= 16384.f)) return fail(h, "mms_bind_obs_planes16: clip_observations x scale must not exceed 2^14 (fp16 planes)");
+    if ((reinterpret_cast<uintptr_t>(planes) & 15) != 0) return fail(h, "mms_bind_obs_planes16: the planes must be 16-byte aligned");
+    h->obs_planes = planes;
+    h->obs_planes_scale = scale;
     return 0;
 }
 

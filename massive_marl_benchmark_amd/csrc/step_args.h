@@ -12,6 +12,8 @@ struct StepArgs {
     float* obs;                       // [N, obs_dim] raw
     float* obs_clipped;               // [N, obs_dim] clamped to +-clip_obs
     float* obs_out;                   // optional bound destination for the clamped row (may be null)
+    void* obs_planes;                 // optional: the clamped row as H32 planes [N, KC, 2, 32] f16 (mms_bind_obs_planes16), or null
+    float obs_planes_scale;           // ... times this power of two
     float* rew;                       // [N]
     float* rew_out;                   // optional bound destination for the reward (may be null)
     uint8_t* done_out;                // optional bound destination for the done flag (may be null)

@@ -550,6 +550,29 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
                 if (obs_out) obs_out[i] = c;
             }
         }
+        // ... and, when bound, the clamped row once more as the policy layers' operand planes (format H32 of split16_kernels.hip: per
+        // 32 k the fp16 hi and lo planes, 128 bytes): the rows are bounded by clip_obs, so their scale is a constant and the separate
+        // split pass over the observation (6 us, one launch) is not needed.  One 8-k piece per thread and trip.
+        if (a.obs_planes) {
+            typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+            const int KC = (obs_dim + 31) >> 5, pieces = KC * 4;
+            const float sc = a.obs_planes_scale;
+            uint8_t* out = reinterpret_cast<uint8_t*>(a.obs_planes) + (size_t)e0 * KC * 128;
+            for (int i = threadIdx.x; i < n_live * pieces; i += BLOCK) {
+                const int e = EPB == 1 ? 0 : i / pieces, p = i - e * pieces, k0 = p * 8;
+                const float* r = rows + (size_t)e * env_stride + k0;
+                f16x8_t hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float t = (k0 + j < obs_dim) ? clampf(r[j], -clip, clip) * sc : 0.f;
+                    hi[j] = (_Float16)t;
+                    lo[j] = (_Float16)((t - (float)hi[j]) * 2048.f);
+                }
+                uint8_t* dst = out + ((size_t)e * KC + (p >> 2)) * 128 + (p & 3) * 16;
+                *reinterpret_cast<f16x8_t*>(dst) = hi;
+                *reinterpret_cast<f16x8_t*>(dst + 64) = lo;
+            }
+        }
     }
 }
 

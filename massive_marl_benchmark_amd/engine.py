@@ -100,6 +100,20 @@ class Engine:
         self._bound = tensor_or_none          # keep it alive
         self._check(self._L.mms_bind_obs_out(self._h, ptr), "mms_bind_obs_out")
 
+    def bind_obs_planes(self, planes_or_none, scale=2048.0):
+        """Extra destination for the clamped observation row as the policy layers' operand planes (H32: uint8 tensor of
+        num_envs * ceil(obs_dim / 32) * 128 bytes, two fp16 planes of row * scale; mms_bind_obs_planes16): ActorCritic.act(obs, states,
+        obs_planes=(planes, scale)) then skips its own split of the observation.  `scale`: a power of two with clip_obs * scale <= 2^14."""
+        if planes_or_none is None:
+            ptr = None
+        else:
+            t = planes_or_none
+            assert t.device.type == self.device.type and t.dtype == torch.uint8 and t.is_contiguous() and \
+                t.numel() == self.num_envs * ((self.obs_dim + 31) // 32) * 128
+            ptr = ctypes.c_void_p(t.data_ptr())
+        self._bound_planes = planes_or_none   # keep it alive
+        self._check(self._L.mms_bind_obs_planes16(self._h, ptr, float(scale)), "mms_bind_obs_planes16")
+
     def bind_actions(self, tensor_or_none):
         """The step reads `tensor` ([N, num_actions] f32 on the engine's device, contiguous) in place instead of the engine's own
         "actions" buffer (mms_bind_actions); None returns to that buffer.  The clamp to +-clip_actions is in the kernel."""

@@ -442,6 +442,13 @@ def test_split16_layers_on_cpu_build():
         assert float((ref - hidden[0]).abs().max()) < 1e-5 * float(ref.abs().max())
 
 
+def test_obs_planes_from_the_step_on_cpu_build():
+    """mms_bind_obs_planes16 on the CPU build: tests/obs_planes_check.py (TenAnt and OneAnt rows)."""
+    from obs_planes_check import check_obs_planes
+    check_obs_planes("cpu")
+    check_obs_planes("cpu", task="OneAnt")
+
+
 def test_reference_learners_drop_in_unchanged(tmp_path):
     """The reference's real learners, imported in place and unmodified, over this build's VecTaskPython / MultiVecTaskPython on the
     CPU build: PPO.run (agents/algorithms/rl/ppo/ppo.py:99-175), Runner.run (agents/algorithms/marl/runner.py:114-151) as mappo, happo

@@ -1432,6 +1432,16 @@ def test_split16_layers_error(torch_cuda):
     assert bad(128, 128, ysc=one(zb), out_mode=1) == 0
 
 
+def test_obs_planes_from_the_step_kernel(torch_cuda):
+    """mms_bind_obs_planes16 on the HIP build, every ant layout of the step kernel's write-out (TenAnt packed 4 / 16 envs per block and
+    one env per block at 6 ants, OneAnt, MultiAntCircle): tests/obs_planes_check.py."""
+    from obs_planes_check import check_obs_planes
+    worst = {}
+    for task, n in (("TenAnt", 128), ("TenAnt", 4096), ("OneAnt", 256), ("MultiAntCircle", 256)):
+        worst["%s/%d" % (task, n)] = check_obs_planes("cuda", task=task, num_envs=n)
+    parity.record("gpu/obs_planes_from_step_kernel", **worst)
+
+
 def test_actor_critic_split_layers(torch_cuda):
     """ActorCritic.act / .value with the hidden layers on the split path (batch and hidden widths multiples of 128) against the torch
     modules and against the exact-fp32 kernel path; an in-place optimizer step is picked up (the weight planes are re-split when the
