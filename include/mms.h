@@ -367,10 +367,12 @@ int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N,
  * scale[g][r] = the row's power of two and inv[g][r] = 1 / scale (f32 [rows]; entries of the two arrays may be NULL).
  * nchains > 0: chain[g] = f32 [nchains, L, 2] of (mult, add) per layer; for each chain c and layer l < L the bound
  * b_{l+1} = (mult_l b_l + add_l) 1.001, b_0 = the row's largest magnitude, gives chain_scale[g][c, l, r] = 2^(14 - e), b_{l+1} <= 2^e, and
- * chain_inv = its inverse (f32 [nchains, L, rows] each): the y_scale / next x_inv of the layers below. */
+ * chain_inv = its inverse (f32 [nchains, L, rows] each): the y_scale / next x_inv of the layers below.
+ * stat != NULL: stat[g] f32 [rows, 2] receives (mean, 1 / sqrt(var + eps)) of every row -- the statistics of an nn.LayerNorm over the
+ * rows (two-pass form), which the grouped MARL inference folds into its first layers: the split reads the rows anyway. */
 int mms_split_planes16_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch, const float* const* x, void* const* planes,
                              float* const* scale, float* const* inv, int32_t nchains, int32_t L, const float* const* chain,
-                             float* const* chain_scale, float* const* chain_inv, void* hip_stream);
+                             float* const* chain_scale, float* const* chain_inv, float* const* stat, float eps, void* hip_stream);
 
 /* mms_linear_group_act_split with x_g, w_g (and, out_mode 1, y_g) in the H32 format.  x_inv[g] f32 [M] and w_inv[g] f32 [N] (16-byte
  * aligned) are the inverse row scales of the operands; y_scale[g] f32 [M] (out_mode 1) is the scale the output rows are stored with --

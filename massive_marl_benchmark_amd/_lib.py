@@ -50,7 +50,7 @@ def _bind(path):
     L.mms_split_planes_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
     L.mms_linear_group_act_split.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32,
                                              vp, vp, vp, vp, vp, ctypes.c_int32, vp]
-    L.mms_split_planes16_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp]
+    L.mms_split_planes16_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, cf, vp]
     L.mms_linear_group_act_split16.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32,
                                                vp, vp, vp, vp, vp, ctypes.c_int32, vp]
     L.mms_row_stats_chan_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, vp, vp, cf, vp]

@@ -230,7 +230,7 @@ class GroupedPolicyInference:
                 src, dst = [Wg[g] for g in range(lo, min(lo + 32, G))], out[lo:lo + 32]
                 if h16:
                     _lib.check(L.mms_split_planes16_group(idx, len(src), N, K, 0, _ptrs(src), up(dst), up(list(scr[lo:lo + 32].unbind(0))),
-                                                          up(list(inv[lo:lo + 32].unbind(0))), 0, 0, None, None, None, stream), None, "mms_split_planes16_group", L)
+                                                          up(list(inv[lo:lo + 32].unbind(0))), 0, 0, None, None, None, None, 0.0, stream), None, "mms_split_planes16_group", L)
                 else:
                     _lib.check(L.mms_split_planes_group(idx, len(src), N, K, 0, _ptrs(src), up(dst), stream), None, "mms_split_planes_group", L)
             return (out, inv) if h16 else out
@@ -382,11 +382,15 @@ class GroupedPolicyInference:
         heads = lambda l, key_w, key_p: (p[key_w], q[key_p], A) if l == depth - 1 else (None, None, 0)
         h16 = self.split_format == "f16x2"
 
-        def split(groups, K, pitch, src, dst, xs, xi):
+        def split(groups, K, pitch, src, dst, xs, xi, stat):
+            """planes of the raw rows + the statistics of their feature LayerNorm (one kernel with two fp16 planes: the split reads
+            the rows anyway; three bf16 planes: mms_row_moments_group beside the split)"""
             if h16:
-                chk(L.mms_split_planes16_group(idx, groups, M, K, pitch, src, q[dst], q[xs], q[xi], 0, 0, None, None, None, stream), "mms_split_planes16_group")
+                chk(L.mms_split_planes16_group(idx, groups, M, K, pitch, src, q[dst], q[xs], q[xi], 0, 0, None, None, None, q[stat], self.eps, stream),
+                    "mms_split_planes16_group")
             else:
                 chk(L.mms_split_planes_group(idx, groups, M, K, pitch, src, q[dst], stream), "mms_split_planes_group")
+                chk(L.mms_row_moments_group(idx, groups, M, K, pitch, src, q[stat], self.eps, stream), "mms_row_moments_group")
 
         def layer(groups, K, x, w, b, y, mode, sv, stat, part, hw, hp, hd, xinv, winv, ysc):
             if h16:
@@ -396,12 +400,10 @@ class GroupedPolicyInference:
                 chk(L.mms_linear_group_act_split(idx, groups, M, H, K, x, w, b, y, 1, mode, sv, stat, part, hw, hp, hd, stream), "mms_linear_group_act_split")
         g16 = lambda table, key: table[key] if h16 else None
         if with_actors:
-            split(n, self.obs_dim, obs_pitch, obs_p, "sx_a", "xs_a", "xi_a")
-            chk(L.mms_row_moments_group(idx, n, M, self.obs_dim, obs_pitch, obs_p, q["stat_a"], self.eps, stream), "mms_row_moments_group")
+            split(n, self.obs_dim, obs_pitch, obs_p, "sx_a", "xs_a", "xi_a", "stat_a")
         shared_rows = len({int(v) for v in sobs_p}) == 1                     # one centralised observation for all critics: one pass
         gs = 1 if shared_rows else n
-        split(gs, self.sobs_dim, self.sobs_dim, sobs_p, "sx_c", "xs_c", "xi_c")
-        chk(L.mms_row_moments_group(idx, gs, M, self.sobs_dim, self.sobs_dim, sobs_p, q["stat_c"], self.eps, stream), "mms_row_moments_group")
+        split(gs, self.sobs_dim, self.sobs_dim, sobs_p, "sx_c", "xs_c", "xi_c", "stat_c")
         if with_actors:
             hw, hp, hd = heads(0, "hwt", "hpart_a")
             hw = None if hw is None else (ctypes.c_void_p * n)(*list(hw)[:n])

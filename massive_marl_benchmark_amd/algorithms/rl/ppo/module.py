@@ -154,7 +154,7 @@ class ActorCritic(nn.Module):
             inv = torch.empty(N, device=w.device) if fresh else hit[2]
             wc = w.contiguous()
             one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
-            _lib.check(L.mms_split_planes16_group(idx, 1, N, K, 0, one(wc), one(planes), one(scale), one(inv), 0, 0, None, None, None, stream),
+            _lib.check(L.mms_split_planes16_group(idx, 1, N, K, 0, one(wc), one(planes), one(scale), one(inv), 0, 0, None, None, None, None, 0.0, stream),
                        None, "mms_split_planes16_group", L)
             bound = torch.stack([wc.abs().sum(1).max(), b.abs().max()])
             hit = (tag, planes, inv, bound, scale)
@@ -230,7 +230,7 @@ class ActorCritic(nn.Module):
             bufs["given_key"] = None
             _lib.check(L.mms_split_planes16_group(idx, 1, M, x.shape[1], x.stride(0), arr([x]), arr([bufs["x"][g0]]), arr([bufs["xs"][g0]]), arr([bufs["xi"][g0]]),
                                                   nch, nl - 1 if nch else 0, arr([chain]) if nch else None, arr([bufs["cs"][g0]]) if nch else None,
-                                                  arr([bufs["ci"][g0]]) if nch else None, stream), None, "mms_split_planes16_group", L)
+                                                  arr([bufs["ci"][g0]]) if nch else None, None, 0.0, stream), None, "mms_split_planes16_group", L)
         cur = [bufs["x_given"] if given else bufs["x"][src[g][0]] for g in range(G)]
         cur_inv = [bufs["xi"][src[g][0]] for g in range(G)]
         for li in range(nl):

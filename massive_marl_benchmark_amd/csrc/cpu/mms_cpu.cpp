@@ -587,7 +587,7 @@ static inline float join2(const uint16_t* chunk, int j) { return h2f(chunk[j]) +
 
 MMS_API int mms_split_planes16_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch, const float* const* x, void* const* planes,
                                      float* const* scale, float* const* inv, int32_t nchains, int32_t L, const float* const* chain,
-                                     float* const* chain_scale, float* const* chain_inv, void*) {
+                                     float* const* chain_scale, float* const* chain_inv, float* const* stat, float eps, void*) {
     if (cpu_only(device)) return 1;
     if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_split_planes16_group: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
     if (x_pitch == 0) x_pitch = K;
@@ -601,6 +601,7 @@ MMS_API int mms_split_planes16_group(int device, int32_t groups, int64_t rows, i
             g_error = "mms_split_planes16_group: null or misaligned pointer in a group (planes 16-byte aligned)";
             return 1;
         }
+        if (stat && !stat[g]) { g_error = "mms_split_planes16_group: null or misaligned stat pointer in a group"; return 1; }
         uint16_t* out = (uint16_t*)planes[g];
         const float* xg = x[g];
 #pragma omp parallel for schedule(static)
@@ -618,6 +619,14 @@ MMS_API int mms_split_planes16_group(int device, int32_t groups, int64_t rows, i
             }
             if (scale[g]) scale[g][r] = sc;
             if (inv[g]) inv[g][r] = iv;
+            if (stat) {                                                   // two-pass LayerNorm statistics of the row
+                float sum = 0.f, m2 = 0.f;
+                for (int k = 0; k < K; k++) sum += xg[r * x_pitch + k];
+                const float mean = sum / (float)K;
+                for (int k = 0; k < K; k++) m2 += (xg[r * x_pitch + k] - mean) * (xg[r * x_pitch + k] - mean);
+                stat[g][2 * r] = mean;
+                stat[g][2 * r + 1] = 1.0f / sqrtf(m2 / (float)K + eps);
+            }
             for (int c = 0; c < nchains; c++) {
                 float bound = big;
                 for (int l = 0; l < L; l++) {

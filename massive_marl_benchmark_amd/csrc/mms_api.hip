@@ -571,7 +571,7 @@ __attribute__((visibility("default"))) int mms_linear_group_act_split(int device
 __attribute__((visibility("default"))) int mms_split_planes16_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch,
                                                                     const float* const* x, void* const* planes, float* const* scale, float* const* inv,
                                                                     int32_t nchains, int32_t L, const float* const* chain, float* const* chain_scale,
-                                                                    float* const* chain_inv, void* s) {
+                                                                    float* const* chain_inv, float* const* stat, float eps, void* s) {
     MMS_DEV(device)
     if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_split_planes16_group: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
     if (x_pitch == 0) x_pitch = K;
@@ -588,8 +588,12 @@ __attribute__((visibility("default"))) int mms_split_planes16_group(int device, 
         }
         a.x[g] = x[g]; a.planes[g] = planes[g]; a.scale[g] = scale[g]; a.inv[g] = inv[g];
         if (nchains > 0) { a.chain[g] = chain[g]; a.chain_scale[g] = chain_scale[g]; a.chain_inv[g] = chain_inv[g]; }
+        if (stat) {
+            if (!stat[g] || (reinterpret_cast<uintptr_t>(stat[g]) & 7) != 0) { g_create_error = "mms_split_planes16_group: null or misaligned stat pointer in a group"; return 1; }
+            a.stat[g] = stat[g];
+        }
     }
-    a.rows = rows; a.K = K; a.x_pitch = x_pitch; a.nchains = nchains; a.L = nchains > 0 ? L : 0;
+    a.rows = rows; a.K = K; a.x_pitch = x_pitch; a.nchains = nchains; a.L = nchains > 0 ? L : 0; a.eps = eps;
     MMS_FREE(mms::launch_split16_planes_group(a, groups, (hipStream_t)s));
     return 0;
 }

@@ -159,9 +159,11 @@ struct Split16PlanesArgs {
     const float* chain[kMaxGroups];
     float* chain_scale[kMaxGroups];
     float* chain_inv[kMaxGroups];
+    float* stat[kMaxGroups];                // optional: (mean, 1 / sqrt(var + eps)) per row, f32 [rows, 2]
     int64_t rows;
     int K, x_pitch;
     int nchains, L;
+    float eps;
 };
 
 hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, hipStream_t s);

@@ -54,15 +54,20 @@ __device__ __forceinline__ void pow2_scale(float bound, float& scale, float& inv
 }
 
 // ---- fp32 [rows, K] -> H32 planes + per-row scales -----------------------------------------------------------------------------
-// One wave per row, two passes over it (largest magnitude, then the planes): the second pass finds the row in L1 / L2.
+// P lanes per row (a power of two, 64 / P rows per wave: a 46-wide row is 8 pieces of 8 k, eight rows share a wave), two passes over
+// the row (largest magnitude and sum, then the planes and the squared deviations): the second pass finds the row in L1 / L2.
+// stat (optional): (mean, 1 / sqrt(var + eps)) of the row, the statistics of a LayerNorm over it (two-pass form) -- the grouped MARL
+// inference folds its feature LayerNorm into the first layer and needs exactly these; one read of the rows serves both.
 template <bool ALIGNED>
-__global__ void __launch_bounds__(256) split16_planes_kernel(Split16PlanesArgs a, int KC) {
+__global__ void __launch_bounds__(256) split16_planes_kernel(Split16PlanesArgs a, int KC, int P) {
     const int g = blockIdx.y;
     const float* __restrict__ x = a.x[g];
     uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(a.planes[g]);
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;                                          // (wave-uniform)
+    const int sub = lane & (P - 1), rpw = 64 / P;
+    const int64_t row_raw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / P;
+    const bool live = row_raw < a.rows;
+    const int64_t row = live ? row_raw : a.rows - 1;                    // (idle lanes stay in the shuffles, on a valid row)
     const int K = a.K;
     const float* src = x + row * (int64_t)a.x_pitch;
     const int pieces = KC * 4;                                          // 8-element pieces of the row
@@ -76,18 +81,22 @@ __global__ void __launch_bounds__(256) split16_planes_kernel(Split16PlanesArgs a
             for (int j = 0; j < 8; j++) v[j] = (k0 + j < K) ? src[k0 + j] : 0.f;
         }
     };
-    float big = 0.f;
-    for (int p = lane; p < pieces; p += 64) {
+    float big = 0.f, sum = 0.f;
+    for (int p = sub; p < pieces; p += P) {
         float v[8];
         load8(p, v);
 #pragma unroll
-        for (int j = 0; j < 8; j++) big = fmaxf(big, fabsf(v[j]));
+        for (int j = 0; j < 8; j++) { big = fmaxf(big, fabsf(v[j])); sum += v[j]; }
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) big = fmaxf(big, __shfl_xor(big, m, 64));
+    for (int m = P >> 1; m >= 1; m >>= 1) {
+        big = fmaxf(big, __shfl_xor(big, m, 64));
+        sum += __shfl_xor(sum, m, 64);
+    }
+    const float mean = sum / (float)K;
     float scale, inv;
     pow2_scale(big, scale, inv);
-    for (int p = lane; p < pieces; p += 64) {
+    float m2 = 0.f;
+    for (int p = sub; p < pieces; p += P) {
         float v[8];
         load8(p, v);
         f16x8 hi, lo;
@@ -96,27 +105,35 @@ __global__ void __launch_bounds__(256) split16_planes_kernel(Split16PlanesArgs a
             const float t = v[j] * scale;
             hi[j] = (_Float16)t;
             lo[j] = (_Float16)((t - (float)hi[j]) * kLoScale);
+            const float d = (p * 8 + j < K) ? v[j] - mean : 0.f;
+            m2 += d * d;
         }
-        uint8_t* dst = out + (row * KC + (p >> 2)) * (int64_t)kChunk16 + (p & 3) * 16;
-        *reinterpret_cast<f16x8*>(dst) = hi;
-        *reinterpret_cast<f16x8*>(dst + 64) = lo;
+        if (live) {
+            uint8_t* dst = out + (row * KC + (p >> 2)) * (int64_t)kChunk16 + (p & 3) * 16;
+            *reinterpret_cast<f16x8*>(dst) = hi;
+            *reinterpret_cast<f16x8*>(dst + 64) = lo;
+        }
     }
-    if (lane == 0) {
+    if (a.stat[g])
+        for (int m = P >> 1; m >= 1; m >>= 1) m2 += __shfl_xor(m2, m, 64);
+    if (sub == 0 && live) {
         if (a.scale[g]) a.scale[g][row] = scale;
         if (a.inv[g]) a.inv[g][row] = inv;
+        if (a.stat[g]) reinterpret_cast<float2*>(a.stat[g])[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)K + a.eps));
     }
-    // the scales of the layers behind this input: one chain per lane
-    for (int c = lane; c < a.nchains; c += 64) {
-        const float* ch = a.chain[g] + (size_t)c * a.L * 2;
-        float bound = big;
-        for (int l = 0; l < a.L; l++) {
-            bound = (ch[2 * l] * bound + ch[2 * l + 1]) * 1.001f;       // (rounding of the bound itself; 2^14 leaves a factor 4 besides)
-            float sc, iv;
-            pow2_scale(bound, sc, iv);
-            a.chain_scale[g][((size_t)c * a.L + l) * a.rows + row] = sc;
-            a.chain_inv[g][((size_t)c * a.L + l) * a.rows + row] = iv;
+    // the scales of the layers behind this input: one chain per lane of the row
+    if (live)
+        for (int c = sub; c < a.nchains; c += P) {
+            const float* ch = a.chain[g] + (size_t)c * a.L * 2;
+            float bound = big;
+            for (int l = 0; l < a.L; l++) {
+                bound = (ch[2 * l] * bound + ch[2 * l + 1]) * 1.001f;   // (rounding of the bound itself; 2^14 leaves a factor 4 besides)
+                float sc, iv;
+                pow2_scale(bound, sc, iv);
+                a.chain_scale[g][((size_t)c * a.L + l) * a.rows + row] = sc;
+                a.chain_inv[g][((size_t)c * a.L + l) * a.rows + row] = iv;
+            }
         }
-    }
 }
 
 hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, hipStream_t s) {
@@ -124,9 +141,12 @@ hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, h
     const int KC = (a.K + 31) / 32;
     bool aligned = (a.x_pitch % 4) == 0;
     for (int g = 0; g < groups; g++) aligned = aligned && (reinterpret_cast<uintptr_t>(a.x[g]) & 15) == 0;
-    const dim3 grid((unsigned)((a.rows + 3) / 4), groups);
-    if (aligned) hipLaunchKernelGGL(split16_planes_kernel<true>, grid, dim3(256), 0, s, a, KC);
-    else hipLaunchKernelGGL(split16_planes_kernel<false>, grid, dim3(256), 0, s, a, KC);
+    int P = 1;
+    while (P < KC * 4 && P < 64) P <<= 1;                               // lanes per row
+    const int64_t rows_per_block = 4 * (64 / P);
+    const dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block), groups);
+    if (aligned) hipLaunchKernelGGL(split16_planes_kernel<true>, grid, dim3(256), 0, s, a, KC, P);
+    else hipLaunchKernelGGL(split16_planes_kernel<false>, grid, dim3(256), 0, s, a, KC, P);
     return hipGetLastError();
 }
 

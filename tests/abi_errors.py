@@ -108,10 +108,10 @@ def check_abi_error_paths(L, device):
     fails(L.mms_linear_group_act_split(device, 1, 100, 128, 32, one, one, one, one, 1, 0, None, None, None, None, None, 0, None), contains="128")
     fails(L.mms_split_planes(device, 8, 8, 4, zp, zp, None))
     fails(L.mms_split_planes(device, 8, 8, 8, None, zp, None))
-    fails(L.mms_split_planes16_group(device, 1, 8, 8, 4, one, one, one, one, 0, 0, None, None, None, None), contains="x_pitch")
-    fails(L.mms_split_planes16_group(device, 0, 8, 8, 8, one, one, one, one, 0, 0, None, None, None, None), contains="groups")
-    fails(L.mms_split_planes16_group(device, 1, 8, 8, 8, one, one, one, one, 2, 3, None, one, one, None), contains="chain")
-    fails(L.mms_split_planes16_group(device, 1, 8, 8, 8, (vp * 1)(None), one, one, one, 0, 0, None, None, None, None), contains="null")
+    fails(L.mms_split_planes16_group(device, 1, 8, 8, 4, one, one, one, one, 0, 0, None, None, None, None, 0.0, None), contains="x_pitch")
+    fails(L.mms_split_planes16_group(device, 0, 8, 8, 8, one, one, one, one, 0, 0, None, None, None, None, 0.0, None), contains="groups")
+    fails(L.mms_split_planes16_group(device, 1, 8, 8, 8, one, one, one, one, 2, 3, None, one, one, None, 0.0, None), contains="chain")
+    fails(L.mms_split_planes16_group(device, 1, 8, 8, 8, (vp * 1)(None), one, one, one, 0, 0, None, None, None, None, 0.0, None), contains="null")
     fails(L.mms_linear_group_act_split16(device, 1, 100, 128, 32, one, one, one, one, one, one, None, 1, 0, None, None, None, None, None, 0, None), contains="128")
     fails(L.mms_linear_group_act_split16(device, 1, 128, 128, 32, one, one, one, one, one, one, None, 1, 1, None, None, None, None, None, 0, None), contains="y_scale")
     fails(L.mms_linear_group_act_split16(device, 1, 128, 128, 32, one, one, one, one, None, one, None, 1, 0, None, None, None, None, None, 0, None), contains="x_inv")

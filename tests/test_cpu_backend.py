@@ -384,7 +384,7 @@ def test_split16_layers_on_cpu_build():
             x[2] = 0.0                                                # an all-zero row keeps scale 1
         planes = torch.full((nbytes(rows, K),), 0xAB, dtype=torch.uint8)
         sc, iv = torch.empty(rows), torch.empty(rows)
-        assert L.mms_split_planes16_group(-1, 1, rows, K, pitch, arr([x]), arr([planes]), arr([sc]), arr([iv]), 0, 0, None, None, None, None) == 0, _lib.last_error(None, L)
+        assert L.mms_split_planes16_group(-1, 1, rows, K, pitch, arr([x]), arr([planes]), arr([sc]), arr([iv]), 0, 0, None, None, None, None, 0.0, None) == 0, _lib.last_error(None, L)
         back, v = join(planes, rows, K, iv)
         ref = x[:, :K].double()
         big = ref.abs().max(1, keepdim=True).values
@@ -402,11 +402,11 @@ def test_split16_layers_on_cpu_build():
     for g in range(2):
         for li in range(2):
             sc = torch.empty(H)
-            assert L.mms_split_planes16_group(-1, 1, H, w[g][li].shape[1], 0, arr([w[g][li]]), arr([wp[g][li]]), arr([sc]), arr([winv[g][li]]), 0, 0, None, None, None, None) == 0
+            assert L.mms_split_planes16_group(-1, 1, H, w[g][li].shape[1], 0, arr([w[g][li]]), arr([wp[g][li]]), arr([sc]), arr([winv[g][li]]), 0, 0, None, None, None, None, 0.0, None) == 0
     chain = torch.stack([torch.stack([torch.stack([w[g][0].abs().sum(1).max(), b[g][0].abs().max()])]) for g in range(2)]).contiguous()    # [2 chains][1 layer][2]
     xp, xs, xi = torch.empty(nbytes(M, K), dtype=torch.uint8), torch.empty(M), torch.empty(M)
     cs, ci = torch.empty(2, 1, M), torch.empty(2, 1, M)
-    assert L.mms_split_planes16_group(-1, 1, M, K, 0, arr([x]), arr([xp]), arr([xs]), arr([xi]), 2, 1, arr([chain]), arr([cs]), arr([ci]), None) == 0, _lib.last_error(None, L)
+    assert L.mms_split_planes16_group(-1, 1, M, K, 0, arr([x]), arr([xp]), arr([xs]), arr([xi]), 2, 1, arr([chain]), arr([cs]), arr([ci]), None, 0.0, None) == 0, _lib.last_error(None, L)
     hp = [torch.empty(nbytes(M, H), dtype=torch.uint8) for _ in range(2)]
     assert L.mms_linear_group_act_split16(-1, 2, M, H, K, arr([xp, xp]), arr([wp[0][0], wp[1][0]]), arr([b[0][0], b[1][0]]), arr(hp), arr([xi, xi]),
                                           arr([winv[0][0], winv[1][0]]), arr([cs[0, 0], cs[1, 0]]), 1, 1, None, None, None, None, None, 0, None) == 0, _lib.last_error(None, L)

@@ -1292,7 +1292,8 @@ def test_split16_planes(torch_cuda):
     arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     torch.manual_seed(2)
-    for (rows, K, pitch) in ((4096, 388, 388), (1024, 1024, 1024), (7, 36, 40), (3, 1, 4), (5, 1028, 1028), (130, 64, 64), (9, 2500, 2500)):
+    for (rows, K, pitch) in ((4096, 388, 388), (1024, 1024, 1024), (7, 36, 40), (3, 1, 4), (5, 1028, 1028), (130, 64, 64), (9, 2500, 2500), (4096, 46, 460), (33, 46, 47),
+                             (100, 100, 100), (13, 200, 203)):
         x = torch.randn(rows, pitch, device="cuda") * torch.exp2(torch.randint(-24, 16, (rows, 1), device="cuda").float())
         if K >= 8:
             x[0, :8] = torch.tensor([0.0, -0.0, 1e-30, -3e4, 1.0 + 2 ** -23, 2 ** -20, 65504.0, -1e-20], device="cuda")
@@ -1300,8 +1301,14 @@ def test_split16_planes(torch_cuda):
             x[2] = 0.0
         planes = torch.full((_h32_bytes(rows, K),), 0xAB, dtype=torch.uint8, device="cuda")
         sc, iv = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
-        _lib.check(L.mms_split_planes16_group(0, 1, rows, K, pitch, arr([x]), arr([planes]), arr([sc]), arr([iv]), 0, 0, None, None, None, stream), None, "split16")
+        st = torch.full((rows, 2), float("nan"), device="cuda")
+        _lib.check(L.mms_split_planes16_group(0, 1, rows, K, pitch, arr([x]), arr([planes]), arr([sc]), arr([iv]), 0, 0, None, None, None, arr([st]), 1e-5, stream), None, "split16")
         torch.cuda.synchronize()
+        # the LayerNorm statistics of the rows ride along (two-pass form), whatever the rows' magnitude
+        xd = x[:, :K].double()
+        mean64, var64 = xd.mean(1), xd.var(1, unbiased=False)
+        assert float(((st[:, 0].double() - mean64).abs() / (xd.abs().max(1).values + 1e-30)).max()) < 1e-6, (rows, K)
+        assert float((st[:, 1].double() * (var64 + 1e-5).sqrt() - 1.0).abs().max()) < 1e-5, (rows, K)
         back, v = _h32_to_f64(torch, planes, rows, K, iv)
         ref = x[:, :K].double()
         big = ref.abs().max(1, keepdim=True).values
@@ -1313,7 +1320,7 @@ def test_split16_planes(torch_cuda):
             assert float(v.permute(0, 1, 3, 2).reshape(rows, KC * 32, 2)[:, K:].abs().max()) == 0.0
         xc = x.cpu()
         pc, scc, ivc = torch.empty(_h32_bytes(rows, K), dtype=torch.uint8), torch.empty(rows), torch.empty(rows)
-        assert C.mms_split_planes16_group(-1, 1, rows, K, pitch, arr([xc]), arr([pc]), arr([scc]), arr([ivc]), 0, 0, None, None, None, None) == 0
+        assert C.mms_split_planes16_group(-1, 1, rows, K, pitch, arr([xc]), arr([pc]), arr([scc]), arr([ivc]), 0, 0, None, None, None, None, 0.0, None) == 0
         # (as values: the device build's no-signed-zeros arithmetic leaves -0 where the host has +0 in the lo plane of a -0 input)
         assert torch.equal(planes.cpu().view(torch.float16), pc.view(torch.float16)) and torch.equal(sc.cpu(), scc), (rows, K)
     # chains: bound_{l+1} = (mult_l bound_l + add_l) 1.001, scale = 2^(14 - e) with bound <= 2^e
@@ -1322,7 +1329,7 @@ def test_split16_planes(torch_cuda):
     chain = torch.tensor([[[20.0, 0.5], [30.0, 0.1], [0.0, 7.0]], [[1e-3, 0.0], [5.0, 5.0], [2.0, 0.0]]], device="cuda")
     planes, sc, iv = torch.empty(_h32_bytes(rows, K), dtype=torch.uint8, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
     cs, ci = torch.empty(2, 3, rows, device="cuda"), torch.empty(2, 3, rows, device="cuda")
-    _lib.check(L.mms_split_planes16_group(0, 1, rows, K, 0, arr([x]), arr([planes]), arr([sc]), arr([iv]), 2, 3, arr([chain]), arr([cs]), arr([ci]), stream), None, "split16 chain")
+    _lib.check(L.mms_split_planes16_group(0, 1, rows, K, 0, arr([x]), arr([planes]), arr([sc]), arr([iv]), 2, 3, arr([chain]), arr([cs]), arr([ci]), None, 0.0, stream), None, "split16 chain")
     torch.cuda.synchronize()
     bound = x.abs().max(1).values
     for c in range(2):
@@ -1331,7 +1338,7 @@ def test_split16_planes(torch_cuda):
             bd = (chain[c, l, 0] * bd + chain[c, l, 1]) * 1.001
             e = torch.frexp(bd)[1].float()
             assert torch.equal(cs[c, l], torch.exp2(14 - e)) and torch.equal(cs[c, l] * ci[c, l], torch.ones(rows, device="cuda"))
-    assert L.mms_split_planes16_group(0, 1, rows, K, 0, arr([x]), arr([planes]), arr([sc]), arr([iv]), 2, 3, None, arr([cs]), arr([ci]), stream) != 0
+    assert L.mms_split_planes16_group(0, 1, rows, K, 0, arr([x]), arr([planes]), arr([sc]), arr([iv]), 2, 3, None, arr([cs]), arr([ci]), None, 0.0, stream) != 0
     assert "chain" in _lib.last_error(None)
 
 
@@ -1367,8 +1374,8 @@ def test_split16_layers_error(torch_cuda):
         xs, xi, ws, wi = [[f32(n) for _ in range(G)] for n in (M, M, N, N)]
         chain = [torch.stack([w[g].abs().sum(1).max(), b[g].abs().max()]).view(1, 1, 2).contiguous() for g in range(G)]
         cs, ci = [f32(1, 1, M) for _ in range(G)], [f32(1, 1, M) for _ in range(G)]
-        _lib.check(L.mms_split_planes16_group(0, G, M, K, 0, arr(x), arr(xp), arr(xs), arr(xi), 1, 1, arr(chain), arr(cs), arr(ci), stream), None, "split16 x")
-        _lib.check(L.mms_split_planes16_group(0, G, N, K, 0, arr(w), arr(wp), arr(ws), arr(wi), 0, 0, None, None, None, stream), None, "split16 w")
+        _lib.check(L.mms_split_planes16_group(0, G, M, K, 0, arr(x), arr(xp), arr(xs), arr(xi), 1, 1, arr(chain), arr(cs), arr(ci), None, 0.0, stream), None, "split16 x")
+        _lib.check(L.mms_split_planes16_group(0, G, N, K, 0, arr(w), arr(wp), arr(ws), arr(wi), 0, 0, None, None, None, None, 0.0, stream), None, "split16 w")
         ys = [torch.full((_h32_bytes(M, N) if planes_out else M * N * 4,), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(G)]
         rc = L.mms_linear_group_act_split16(0, G, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), arr(xi), arr(wi), arr([c[0, 0] for c in cs]) if planes_out else None,
                                             act, planes_out, None, None, None, None, None, 0, stream)
@@ -1411,7 +1418,7 @@ def test_split16_layers_error(torch_cuda):
             w2 = [torch.randn(128, N, device="cuda") / N ** 0.5 for _ in range(G)]
             w2p = [torch.empty(_h32_bytes(128, N), dtype=torch.uint8, device="cuda") for _ in range(G)]
             w2s, w2i = [f32(128) for _ in range(G)], [f32(128) for _ in range(G)]
-            _lib.check(L.mms_split_planes16_group(0, G, 128, N, 0, arr(w2), arr(w2p), arr(w2s), arr(w2i), 0, 0, None, None, None, stream), None, "split16 w2")
+            _lib.check(L.mms_split_planes16_group(0, G, 128, N, 0, arr(w2), arr(w2p), arr(w2s), arr(w2i), 0, 0, None, None, None, None, 0.0, stream), None, "split16 w2")
             y2 = [torch.empty(M, 128, device="cuda") for _ in range(G)]
             b2 = [torch.zeros(128, device="cuda") for _ in range(G)]
             assert L.mms_linear_group_act_split16(0, G, M, 128, N, arr(ys), arr(w2p), arr(b2), arr(y2), arr([c[0, 0] for c in ci]), arr(w2i), None, 0, 0,

@@ -10,10 +10,10 @@ x = torch.randn(rows, K, device="cuda") * torch.exp2(torch.randint(-24, 16, (row
 x[0, :8] = torch.tensor([0.0, -0.0, 1e-30, -3e4, 1.0 + 2 ** -23, 2 ** -20, 65504.0, -1e-20], device="cuda")
 nb = rows * ((K + 31) // 32) * 128
 planes = torch.zeros(nb, dtype=torch.uint8, device="cuda"); sc = torch.empty(rows, device="cuda"); iv = torch.empty(rows, device="cuda")
-L.mms_split_planes16_group(0, 1, rows, K, 0, arr([x]), arr([planes]), arr([sc]), arr([iv]), 0, 0, None, None, None, stream)
+L.mms_split_planes16_group(0, 1, rows, K, 0, arr([x]), arr([planes]), arr([sc]), arr([iv]), 0, 0, None, None, None, None, 0.0, stream)
 torch.cuda.synchronize()
 xc = x.cpu(); pc = torch.zeros(nb, dtype=torch.uint8); scc = torch.empty(rows); ivc = torch.empty(rows)
-C.mms_split_planes16_group(-1, 1, rows, K, 0, arr([xc]), arr([pc]), arr([scc]), arr([ivc]), 0, 0, None, None, None, None)
+C.mms_split_planes16_group(-1, 1, rows, K, 0, arr([xc]), arr([pc]), arr([scc]), arr([ivc]), 0, 0, None, None, None, None, 0.0, None)
 print("scales equal", torch.equal(sc.cpu(), scc))
 g = planes.cpu().view(torch.int16).view(rows, -1, 2, 32); c = pc.view(torch.int16).view(rows, -1, 2, 32)
 d = (g != c)

@@ -24,8 +24,8 @@ for N, planes in ((1024, 1), (512, 0), (1024, 0)):
         xp = [torch.empty(nb(M, K), dtype=torch.uint8, device="cuda") for _ in range(2)]
         wp = [torch.empty(nb(N, K), dtype=torch.uint8, device="cuda") for _ in range(2)]
         xs, xi, ws, wi = [[f32(n) for _ in range(2)] for n in (M, M, N, N)]
-        L.mms_split_planes16_group(d, 2, M, K, 0, arr(x), arr(xp), arr(xs), arr(xi), 0, 0, None, None, None, stream)
-        L.mms_split_planes16_group(d, 2, N, K, 0, arr(w), arr(wp), arr(ws), arr(wi), 0, 0, None, None, None, stream)
+        L.mms_split_planes16_group(d, 2, M, K, 0, arr(x), arr(xp), arr(xs), arr(xi), 0, 0, None, None, None, None, 0.0, stream)
+        L.mms_split_planes16_group(d, 2, N, K, 0, arr(w), arr(wp), arr(ws), arr(wi), 0, 0, None, None, None, None, 0.0, stream)
         b = [torch.zeros(N, device="cuda") for _ in range(2)]
         ysc = [torch.full((M,), 64.0, device="cuda") for _ in range(2)]
         y = [torch.empty(nb(M, N) if planes else M * N * 4, dtype=torch.uint8, device="cuda") for _ in range(2)]

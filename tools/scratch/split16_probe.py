@@ -49,7 +49,7 @@ def main():
             N, K = dims[l + 1], dims[l]
             wp[g][l] = u8(N * ((K + 31) // 32) * 128)
             sc, iv = f32(N), f32(N)
-            _lib.check(L.mms_split_planes16_group(d, 1, N, K, 0, ptrs([Ws[g][l]]), ptrs([wp[g][l]]), ptrs([sc]), ptrs([iv]), 0, 0, None, None, None, stream), what="split16 w", L=L)
+            _lib.check(L.mms_split_planes16_group(d, 1, N, K, 0, ptrs([Ws[g][l]]), ptrs([wp[g][l]]), ptrs([sc]), ptrs([iv]), 0, 0, None, None, None, None, 0.0, stream), what="split16 w", L=L)
             winv[g][l] = iv
             back = h32_to_f64(wp[g][l], N, K, iv)
             rel = float(((back - Ws[g][l].double()).abs() / Ws[g][l].double().abs().clamp_min(1e-30)).max())
@@ -61,7 +61,7 @@ def main():
     cs, ci = f32(nets, 3, M), f32(nets, 3, M)
 
     def split_obs():
-        _lib.check(L.mms_split_planes16_group(d, 1, M, dims[0], 0, ptrs([obs]), ptrs([xp]), ptrs([xs]), ptrs([xi]), nets, 3, ptrs([chain]), ptrs([cs]), ptrs([ci]), stream), what="split16 x", L=L)
+        _lib.check(L.mms_split_planes16_group(d, 1, M, dims[0], 0, ptrs([obs]), ptrs([xp]), ptrs([xs]), ptrs([xi]), nets, 3, ptrs([chain]), ptrs([cs]), ptrs([ci]), None, 0.0, stream), what="split16 x", L=L)
     split_obs()
     torch.cuda.synchronize()
     back = h32_to_f64(xp, M, dims[0], xi)
