@@ -369,26 +369,24 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 const int m = mbase + 16 * mt + r16;
-                float sum = 0.f;
+                f32x4 sum4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
-                    const float ss[4] = {sv[nt].x, sv[nt].y, sv[nt].z, sv[nt].w}, bb[4] = {bias[nt].x, bias[nt].y, bias[nt].z, bias[nt].w};
+                    const f32x4 s4 = f32x4{sv[nt].x, sv[nt].y, sv[nt].z, sv[nt].w}, b4 = f32x4{bias[nt].x, bias[nt].y, bias[nt].z, bias[nt].w};
+                    f32x4 x = (acc[mt][nt] - s4 * st[mt].x) * st[mt].y + b4;        // rstd (W~ h - mean s) + c, four wide (packed fp32)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float x = st[mt].y * (acc[mt][nt][r] - st[mt].x * ss[r]) + bb[r];
-                        x = (x > 0.f) ? x : (expf(x) - 1.f);
-                        acc[mt][nt][r] = x;
-                        sum += x;
-                    }
+                    for (int r = 0; r < 4; r++) x[r] = (x[r] > 0.f) ? x[r] : (expf(x[r]) - 1.f);
+                    acc[mt][nt] = x;
+                    sum4 += x;
                 }
+                float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
                 sum += __shfl_xor(sum, 16, 64);
                 sum += __shfl_xor(sum, 32, 64);
                 const float mean = sum * (1.f / 64.f);
-                float m2 = 0.f;
+                f32x4 q4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { const float d = acc[mt][nt][r] - mean; m2 += d * d; }
+                for (int nt = 0; nt < 4; nt++) { const f32x4 d = acc[mt][nt] - mean; q4 += d * d; }
+                float m2 = (q4[0] + q4[1]) + (q4[2] + q4[3]);
                 m2 += __shfl_xor(m2, 16, 64);
                 m2 += __shfl_xor(m2, 32, 64);
                 if (g4 == 0) part[m] = make_float2(sum, m2);
