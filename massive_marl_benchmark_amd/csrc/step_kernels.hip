@@ -558,7 +558,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
             const int KC = (obs_dim + 31) >> 5, pieces = KC * 4;
             const float sc = a.obs_planes_scale;
             uint8_t* out = reinterpret_cast<uint8_t*>(a.obs_planes) + (size_t)e0 * KC * 128;
-            for (int i = threadIdx.x; i < n_live * pieces; i += BLOCK) {
+            int tix = threadIdx.x;
+            asm volatile("" : "+v"(tix));           // (opaque: nothing of this loop's index math is hoisted across the physics -- one spill otherwise)
+            for (int i = tix; i < n_live * pieces; i += BLOCK) {
                 const int e = EPB == 1 ? 0 : i / pieces, p = i - e * pieces, k0 = p * 8;
                 const float* r = rows + (size_t)e * env_stride + k0;
                 f16x8_t hi, lo;
