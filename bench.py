@@ -454,6 +454,10 @@ def main():
                                          "configuration of the back-to-back launches also writes its raw + clamped observation "
                                          "buffers: %s bytes per launch" % ((tr or {}).get("engine_buffers_configuration") or {}).get("traffic_bytes_per_launch"),
                          "bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N, "launch_ms": kernel_ms,
+                         "obs_planes_bytes_per_launch": (((obs_dim + 31) // 32) * 128 * N) if planes_state["used"] else 0,
+                         "obs_planes_note": "in the rollout the launch also stores the clamped row as the policy layers' operand planes "
+                                            "(mms_bind_obs_planes16): work moved INTO this kernel from the policy's split pass, not counted in the "
+                                            "algorithmic bytes -- the in-rollout duration includes it",
                          "launch_ms_back_to_back": kernel_ms_b2b, "launch_ms_in_rollout": kernel_ms_roll,
                          "launches": {"back_to_back": n_b2b, "in_rollout": n_roll},
                          "frac_back_to_back": ALGO_BYTES_PER_ENV_STEP * N / (kernel_ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
