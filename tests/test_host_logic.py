@@ -318,31 +318,39 @@ def test_kernel_resources_of_the_built_library():
     if not os.path.exists(readelf):
         pytest.skip("llvm-readelf not found")
     data = open(_lib.LIB_PATH, "rb").read()
-    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
-    assert i >= 0
-    n = struct.unpack_from("<Q", data, i + 24)[0]
-    off, code = i + 32, None
-    for _ in range(n):
-        o, s, tl = struct.unpack_from("<QQQ", data, off)
-        off += 24
-        triple = data[off:off + tl].decode()
-        off += tl
-        if "gfx950" in triple:
-            code = data[i + o:i + o + s]
-    assert code, "no gfx950 code object in libmms.so"
     import tempfile
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(code)
-        f.flush()
-        notes = subprocess.check_output([readelf, "--notes", f.name]).decode()
-    kernels = {}
-    for block in notes.split("- .agpr_count:")[1:]:
-        name = re.search(r"\.name:\s+(\S+)", block).group(1)
-        kernels[name] = (int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)), int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)))
+    kernels, pos = {}, 0
+    while True:                                                     # one offload bundle per object file of the library
+        i = data.find(b"__CLANG_OFFLOAD_BUNDLE__", pos)
+        if i < 0:
+            break
+        pos = i + 24
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        off, code = i + 32, None
+        for _ in range(n):
+            o, s, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple:
+                code = data[i + o:i + o + s]
+        if not code:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(code)
+            f.flush()
+            notes = subprocess.check_output([readelf, "--notes", f.name]).decode()
+        for block in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(_Z\S+)", block).group(1)
+            kernels[name] = (int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)), int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)))
+    assert kernels, "no gfx950 code object in libmms.so"
     step = {k: v for k, v in kernels.items() if "ant_step_kernelILi0E" in k}
     assert len(step) >= 8, sorted(kernels)
     for k, (vgpr, scratch) in step.items():
         assert vgpr <= 168 and scratch == 0, (k, vgpr, scratch)
     for k, (vgpr, scratch) in kernels.items():
-        if "linear_act" in k or "marl_heads" in k or "layernorm_rows" in k or "ppo_head_act" in k:
+        if "linear_act" in k or "linear_split" in k or "split16_planes" in k or "split_planes" in k or "marl_heads" in k or "layernorm_rows" in k or "ppo_head_act" in k:
             assert scratch == 0, (k, vgpr, scratch)
+        if "linear_split" in k:                                     # 512-thread blocks, two waves per SIMD: 256 registers is all there is
+            assert vgpr <= 256, (k, vgpr)
+    assert sum(1 for k in kernels if "linear_split16_kernel" in k) >= 12 and sum(1 for k in kernels if "linear_split_kernel" in k) >= 8
