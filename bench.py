@@ -95,6 +95,8 @@ def main():
                     help="planes of the split layer kernel: two scaled fp16 planes (mms_linear_group_act_split16, default) or three exact bf16 planes (mms_linear_group_act_split)")
     ap.add_argument("--no-obs-planes", action="store_true",
                     help="A/B: the policy splits the observation rows itself (mms_split_planes16_group) instead of reading the operand planes the step kernel writes beside them (mms_bind_obs_planes16)")
+    ap.add_argument("--rollouts-per-graph", type=int, default=1,
+                    help="A/B: whole rollouts (8 steps + GAE) per hipGraph replay (default 1: one PPO iteration's collection phase)")
     ap.add_argument("--one-stream", action="store_true", help="A/B: actor and critic MLPs on one stream")
     ap.add_argument("--defer-critic", action="store_true",
                     help="A/B: let the critic pass overlap the sampling kernel and the env step (joined before the GAE); faster, but "
@@ -288,7 +290,8 @@ def main():
         eng.set_obs_outputs(True, True)
         storage.clear()
 
-        graph = None
+        graph, graph_big = None, None
+        RPG = max(1, args.rollouts_per_graph)
         for _ in range(NSTEPS):                      # eager warm-up (allocator, rocBLAS handles)
             rollout_step()
         torch.cuda.synchronize()
@@ -301,6 +304,11 @@ def main():
                 with torch.cuda.graph(graph, stream=side):
                     for _ in range(NSTEPS):
                         rollout_step()
+                if RPG > 1:
+                    graph_big = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_big, stream=side):
+                        for _ in range(RPG * NSTEPS):
+                            rollout_step()
             torch.cuda.current_stream(device).wait_stream(side)
             torch.cuda.synchronize()
 
@@ -324,7 +332,13 @@ def main():
             # the timed K, eagerly otherwise; after a replay the engine's clamped observation row is current, which is what step 0
             # of a rollout starts from)
             if graph is not None:
-                for _ in range(k // NSTEPS):
+                if graph_big is not None:
+                    for _ in range(k // (RPG * NSTEPS)):
+                        graph_big.replay()
+                    k_done = (k // (RPG * NSTEPS)) * RPG * NSTEPS
+                else:
+                    k_done = 0
+                for _ in range((k - k_done) // NSTEPS):
                     graph.replay()
                 if k % NSTEPS and k == K and tail_graph is not None:
                     tail_graph.replay()
@@ -434,7 +448,7 @@ def main():
             "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
                                    "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "hipgraph": bool(graph), "fused_act_and_bound_slots": not args.unfused, "obs_planes_from_step_kernel": bool(planes_state["used"]), "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else ((("mms_linear_group_act_split16 (2 x fp16 planes, row scales, fp32 accumulate)" if args.split_format == "f16x2" else "mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)") if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "mms_linear2_act (exact fp32 MFMA)") + " + mms_ppo_heads_act"),
+                       "hipgraph": bool(graph), "rollouts_per_graph": max(1, args.rollouts_per_graph), "fused_act_and_bound_slots": not args.unfused, "obs_planes_from_step_kernel": bool(planes_state["used"]), "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else ((("mms_linear_group_act_split16 (2 x fp16 planes, row scales, fp32 accumulate)" if args.split_format == "f16x2" else "mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)") if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "mms_linear2_act (exact fp32 MFMA)") + " + mms_ppo_heads_act"),
                        "friction": {"rule": "average" if abs(eng.config.model.boxgnd_mu) > 0 else "min", "gnd_mu": eng.config.model.gnd_mu,
                                     "boxgnd_mu": eng.config.model.boxgnd_mu, "antbox_mu": eng.config.model.antbox_mu,
                                     "note": "this build's modelling choice (PhysX default combine rule), not reference-pinned: DESIGN.md section 4"},
