@@ -381,6 +381,7 @@ class GroupedPolicyInference:
         last_mode = lambda l: 2 if l == depth - 1 else 1
         heads = lambda l, key_w, key_p: (p[key_w], q[key_p], A) if l == depth - 1 else (None, None, 0)
         h16 = self.split_format == "f16x2"
+        self._cond = []
 
         def split(groups, K, pitch, src, dst, xs, xi, stat):
             """planes of the raw rows + the statistics of their feature LayerNorm (one kernel with two fp16 planes: the split reads
@@ -415,6 +416,9 @@ class GroupedPolicyInference:
         cur = 0
         for l in range(1, depth):
             chk(L.mms_row_stats_chan_group(idx, G, M, slots, q["part" + sfx], q["stat" + sfx], self.eps, stream), "mms_row_stats_chan_group")
+            if self.track_conditioning:
+                st = self.stat[(0 if with_actors else n):]
+                self._cond.append((st[..., 0].abs() * st[..., 1]).max())
             hw, hp, hd = heads(l, "hwt" + sfx, "hpart" + sfx)
             layer(G, H, q["sh%d%s" % (cur, sfx)], p["sw%d%s" % (l, sfx)], p["fc%d%s" % (l, sfx)], q["sh%d%s" % (1 - cur, sfx)], last_mode(l),
                   p["fs%d%s" % (l, sfx)], q["stat" + sfx], q["part" + sfx], hw, hp, hd, g16(q, "yinv%d%s" % (l - 1, sfx)), g16(p, "swi%d%s" % (l, sfx)),
@@ -543,6 +547,29 @@ class GroupedPolicyInference:
                [shared.action_log_probs[s][:, k] for k in range(n)])
         self.get_actions([sobs] * n, [obs[:, k] for k in range(n)], deterministic=deterministic, out=out)
         return shared.actions[s]
+
+    # Diagnostics (off the hot path): with track_conditioning = True every folded pass records, per hidden LayerNorm, the largest
+    # |mean| / std of the rows it normalised (three small torch kernels per layer: not for timed runs)
+    track_conditioning = False
+
+    @torch.no_grad()
+    def fold_conditioning(self):
+        """Largest |mean| / std over the rows a folded hidden LayerNorm normalised in the previous pass (a device scalar; None before the
+        first folded pass): over ALL hidden LayerNorms when `track_conditioning` was set for that pass, else of the last one only.  The
+        folded layer evaluates W~ h - mean s, which amplifies whatever its operands lack by this ratio: with two fp16 planes (operands
+        kept to 2^-22) the layer's relative error is ~ratio x 2^-22, with three bf16 planes or the exact-fp32 kernel ~ratio x 2^-24 (the
+        rounding of h itself).  Ordinary networks sit below 10; choose split_format="bf16x3" when this reports hundreds
+        (tests/test_marl_policy.py: the stress case at 1000)."""
+        if self._chunks is not None:
+            vals = [c.fold_conditioning() for c in self._chunks]
+            vals = [v for v in vals if v is not None]
+            return torch.stack(vals).max() if vals else None
+        if self._M is None or not hasattr(self, "stat"):
+            return None
+        if getattr(self, "_cond", None):
+            return torch.stack(self._cond).max()
+        st = self.stat                                                  # [2n, M, 2] = (mean, 1 / sqrt(var + eps)) of the last hidden LayerNorm's input
+        return (st[..., 0].abs() * st[..., 1]).max()
 
     @torch.no_grad()
     def get_values(self, share_obs, out=None):
