@@ -1439,6 +1439,45 @@ def test_split16_layers_error(torch_cuda):
     assert bad(128, 128, ysc=one(zb), out_mode=1) == 0
 
 
+def test_split16_layers_repeatable(torch_cuda):
+    """Race screen for the three-stage LDS-DMA pipeline of linear_split16_kernel (counted vmcnt + raw barriers, persistent tiles with
+    the next tile's slices prefetched under the epilogue): the kernel has no atomics, so every launch on the same operands must
+    reproduce the first one BIT FOR BIT -- 300 launches each of a one-tile-per-CU shape, a five-tiles-per-CU grouped shape (stores in
+    flight across tiles), a short-K shape (K = 64: two k-steps, the prefetch path dominates) and K = 32 (one step), planes and fp32 out."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    L = _lib.lib()
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(11)
+    f32 = lambda *sh: torch.empty(*sh, device="cuda")
+    for (G, M, N, K, planes_out) in ((2, 4096, 1024, 1024, 1), (20, 4096, 512, 512, 1), (20, 2560, 512, 64, 0), (6, 1024, 256, 32, 1), (3, 384, 128, 96, 0)):
+        x = [torch.randn(M, K, device="cuda") for _ in range(G)]
+        w = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(G)]
+        b = [torch.randn(N, device="cuda") * 0.1 for _ in range(G)]
+        xp = [torch.empty(_h32_bytes(M, K), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        wp = [torch.empty(_h32_bytes(N, K), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        xs, xi, ws, wi = [[f32(n) for _ in range(G)] for n in (M, M, N, N)]
+        _lib.check(L.mms_split_planes16_group(0, G, M, K, 0, arr(x), arr(xp), arr(xs), arr(xi), 0, 0, None, None, None, None, 0.0, stream), None, "split16 x")
+        _lib.check(L.mms_split_planes16_group(0, G, N, K, 0, arr(w), arr(wp), arr(ws), arr(wi), 0, 0, None, None, None, None, 0.0, stream), None, "split16 w")
+        ysc = [torch.full((M,), 256.0, device="cuda") for _ in range(G)]
+        nbytes = _h32_bytes(M, N) if planes_out else M * N * 4
+        ys = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(G)]
+        run = lambda: L.mms_linear_group_act_split16(0, G, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), arr(xi), arr(wi), arr(ysc) if planes_out else None, 1, planes_out,
+                                                     None, None, None, None, None, 0, stream)
+        assert run() == 0, _lib.last_error(None)
+        torch.cuda.synchronize()
+        first = [t.clone() for t in ys]
+        bad = torch.zeros((), dtype=torch.int64, device="cuda")
+        for it in range(300):
+            for t in ys:
+                t.zero_()
+            assert run() == 0
+            for t, f in zip(ys, first):
+                bad += (t != f).sum()
+        assert int(bad) == 0, (G, M, N, K, planes_out, int(bad))
+
+
 def test_obs_planes_from_the_step_kernel(torch_cuda):
     """mms_bind_obs_planes16 on the HIP build, every ant layout of the step kernel's write-out (TenAnt packed 4 / 16 envs per block and
     one env per block at 6 ants, OneAnt, MultiAntCircle): tests/obs_planes_check.py."""
