@@ -1580,6 +1580,14 @@ def test_bench_under_torchrun_single_rank(torch_cuda):
     assert out["n_gpus"] == 1 and out["steps"] == 16 and out["warmup"] == 8 and out["scaling"] == "weak" and out["value"] > 1e6
     assert out["config"]["distributed"] == {"backend": "nccl", "world_size": 1}
     assert out["roofline"]["frac"] > 0 and out["config"]["finite"]
+    # the default path and its A/Bs are all in the line: two fp16 planes (headline), three bf16 planes, exact fp32; the layers' roofline
+    assert out["config"]["obs_planes_from_step_kernel"] is True and "mms_linear_group_act_split16" in out["config"]["policy_layers"]
+    assert out["rollout_bf16x3_layers"]["value"] > 1e6 and out["rollout_exact_fp32_layers"]["value"] > 1e6
+    assert out["value"] > out["rollout_bf16x3_layers"]["value"] > out["rollout_exact_fp32_layers"]["value"]
+    err = out["policy_layers_error_vs_f64"]
+    assert err["split_2xf16"]["rms"] < err["exact_fp32_mfma"]["rms"] and err["split_3xbf16"]["rms"] < err["exact_fp32_mfma"]["rms"]
+    roof = out["roofline_policy_layers"]
+    assert roof["bound"] == "mfma" and roof["peak"] == 2500.0 and 0.05 < roof["frac"] < 1.0 and roof["plane_products_per_fp32_product"] == 3
 
 
 def test_fused_act_and_bound_rollout(torch_cuda):
