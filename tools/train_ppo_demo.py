@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--exact-fp32-layers", action="store_true",
                     help="hidden layers on the exact-fp32 MFMA kernel instead of the split kernel (which applies when batch and hidden widths are multiples of 128)")
     ap.add_argument("--split-format", default="f16x2", choices=["f16x2", "bf16x3"], help="planes of the split layer kernel (module default: f16x2)")
+    ap.add_argument("--obs-planes", action="store_true",
+                    help="the step kernel also writes the observation's operand planes (Engine.bind_obs_planes) and act() reads them instead of splitting the rows")
     ap.add_argument("--friction-combine", default="average", choices=["average", "min"],
                     help="cfg env.frictionCombine: PhysX's average rule (default) or min = a box that is frictionless against everything")
     args = ap.parse_args()
@@ -69,10 +71,16 @@ def main():
     done_ret, done_len, done_cnt = 0.0, 0.0, 0
     t0 = time.time()
     print("task %s, %d envs, obs %d, actions %d, hidden %s" % (args.task, N, obs_dim, act_dim, args.hidden), flush=True)
+    planes, planes_ok = None, False
+    if args.obs_planes:
+        planes = torch.empty(N * ((obs_dim + 31) // 32) * 128, dtype=torch.uint8, device=dev)
+        env.task.engine.bind_obs_planes(planes, 2048.0)                 # clip_observations 5 x 2^11 <= 2^14
     for it in range(args.iterations):
         for _ in range(T):
-            actions, logp, values, mu, sigma = ac.act(obs, states)
+            # (`obs` holds a copy of the row the engine clamped in its last step: the planes it wrote beside that row are its planes)
+            actions, logp, values, mu, sigma = ac.act(obs, states, obs_planes=(planes, 2048.0) if planes_ok else None)
             next_obs, rew, dones, _ = env.step(actions)
+            planes_ok = planes is not None
             storage.add_transitions(obs, states, actions, rew, dones, values, logp, mu, sigma)
             obs.copy_(next_obs)
             ep_ret += rew
