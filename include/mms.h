@@ -339,13 +339,15 @@ int mms_split_planes_group(int device, int32_t groups, int64_t rows, int32_t K, 
  * LayerNorm folds (ln_s, ln_stat_in, ln_part_out: all NULL or all given; act must be ELU): as mms_linear_group_act's, except that
  *   ln_part_out[g] [N/64, M, 2] receives per row and 64-column slot (sum, sum of squared deviations FROM THE SLOT'S OWN MEAN) -- the
  *   two-pass form, free of E[x^2] - mean^2 cancellation; mms_row_stats_chan_group combines the slots (Chan's formula).
- * out_mode 2 (needs the folds): head_w[g] [head_dim, N] f32 = the output head's weight with the last LayerNorm's gamma folded in,
- *   head_dim <= 16; head_part[g] [N/64, M, 16] receives sum over the slot's columns of y[r, n] head_w[j, n]: the head of every network
- *   is finished by mms_marl_heads_finish without the activations ever being written. */
+ * out_mode 2 (needs the folds): head_w[g] [head_dims[g], N] f32 = the output head's weight with the last LayerNorm's gamma folded in,
+ *   head_dims[g] <= 16 (host array, one entry per network: an actor's action count, 1 for a critic); head_part[g] [N/64, M, stride_g],
+ *   stride_g = head_dims[g] rounded up to 4, receives sum over the slot's columns of y[r, n] head_w[j, n]: the head of every network is
+ *   finished by mms_marl_heads_finish (whose A[g] = head_dims[g]) without the activations ever being written.  head_dims may be NULL in
+ *   the other output modes. */
 int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
                                const float* const* b, void* const* y, int32_t act, int32_t out_mode, const float* const* ln_s,
                                const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
-                               int32_t head_dim, void* hip_stream);
+                               const int32_t* head_dims, void* hip_stream);
 
 /* ---- ... and with two scaled fp16 planes per operand (csrc/split16_kernels.hip): the default of the policy modules -----------------
  * x s = hi + lo 2^-11 with s a power of two per ROW, hi = f16(x s), lo = f16((x s - hi) 2^11): the operand is kept to 2^-22 |x| (worst
@@ -382,7 +384,7 @@ int mms_linear_group_act_split16(int device, int32_t groups, int64_t M, int32_t 
                                  const float* const* b, void* const* y, const float* const* x_inv, const float* const* w_inv,
                                  const float* const* y_scale, int32_t act, int32_t out_mode, const float* const* ln_s,
                                  const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
-                                 int32_t head_dim, void* hip_stream);
+                                 const int32_t* head_dims, void* hip_stream);
 
 /* stat_g[r] = (mean, 1 / sqrt(var + eps)) of row r from mms_linear_group_act_split's ln_part_out (`slots` = N / 64 slots of 64). */
 int mms_row_stats_chan_group(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part, float* const* stat, float eps,

@@ -49,10 +49,10 @@ def _bind(path):
     L.mms_split_planes.argtypes = [ci, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
     L.mms_split_planes_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
     L.mms_linear_group_act_split.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32,
-                                             vp, vp, vp, vp, vp, ctypes.c_int32, vp]
+                                             vp, vp, vp, vp, vp, vp, vp]
     L.mms_split_planes16_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, cf, vp]
     L.mms_linear_group_act_split16.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32,
-                                               vp, vp, vp, vp, vp, ctypes.c_int32, vp]
+                                               vp, vp, vp, vp, vp, vp, vp]
     L.mms_row_stats_chan_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, vp, vp, cf, vp]
     L.mms_marl_heads_finish.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, c64, cf, vp]
     L.mms_row_moments_group.argtypes = [ci, ctypes.c_int32, c64, ctypes.c_int32, ctypes.c_int32, vp, vp, cf, vp]

@@ -310,6 +310,7 @@ class GroupedPolicyInference:
             self.p["hwt"], self.p["hs"], self.p["hc"] = arr(list(sp["heads"][0].unbind(0))), arr(list(sp["heads"][1].unbind(0))), arr(list(sp["heads"][2].unbind(0)))
         self._A = (ctypes.c_int32 * (2 * self.n))(*([self.act_dim] * self.n + [1] * self.n))
         self._A1 = (ctypes.c_int32 * self.n)(*([1] * self.n))
+        self._Aa = (ctypes.c_int32 * self.n)(*([self.act_dim] * self.n))
         _critic_halves(self.p, self.n)
 
     def _buffers(self, M):
@@ -345,11 +346,13 @@ class GroupedPolicyInference:
             self.sx_a, self.sx_c = u8(n, M, self.obs_dim), u8(n, M, self.sobs_dim)
             self.sh = [u8(2 * n, M, H), u8(2 * n, M, H)]
             self.stat_a = z(n, M, 2)
-            self.head_part = z(2 * n, max(1, H // 64), M, 16)
+            # per-slot partial dot products of the output heads, rows of A rounded up to 4 floats: an actor's and a critic's differ
+            self.head_part_a = z(n, max(1, H // 64), M, (self.act_dim + 3) & ~3)
+            self.head_part_c = z(n, max(1, H // 64), M, 4)
             up = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
             self.q.update({"sx_a": up(self.sx_a), "sx_c": up(self.sx_c), "sx_c0": up([self.sx_c[0]] * n), "sh0": up(self.sh[0]), "sh1": up(self.sh[1]),
                            "sh0_a": up(self.sh[0][:n]), "sh0_c": up(self.sh[0][n:]), "stat_a": _ptrs(ub(self.stat_a)),
-                           "hpart": _ptrs(ub(self.head_part)), "hpart_a": _ptrs(ub(self.head_part[:n])), "hpart_c": _ptrs(ub(self.head_part[n:]))})
+                           "hpart": _ptrs(ub(self.head_part_a) + ub(self.head_part_c)), "hpart_a": _ptrs(ub(self.head_part_a)), "hpart_c": _ptrs(ub(self.head_part_c))})
             if h16:
                 # row scales of the raw inputs (written by the split) and of the hidden activations (constants of the refresh, one per
                 # network and layer, laid out per row because that is what the kernel reads)
@@ -379,7 +382,7 @@ class GroupedPolicyInference:
         sfx = "" if with_actors else "/c"
         G = 2 * n if with_actors else n
         last_mode = lambda l: 2 if l == depth - 1 else 1
-        heads = lambda l, key_w, key_p: (p[key_w], q[key_p], A) if l == depth - 1 else (None, None, 0)
+        heads = lambda l, key_w, key_p, dims: (p[key_w], q[key_p], dims) if l == depth - 1 else (None, None, None)
         h16 = self.split_format == "f16x2"
         self._cond = []
 
@@ -406,11 +409,11 @@ class GroupedPolicyInference:
         gs = 1 if shared_rows else n
         split(gs, self.sobs_dim, self.sobs_dim, sobs_p, "sx_c", "xs_c", "xi_c", "stat_c")
         if with_actors:
-            hw, hp, hd = heads(0, "hwt", "hpart_a")
+            hw, hp, hd = heads(0, "hwt", "hpart_a", self._Aa)
             hw = None if hw is None else (ctypes.c_void_p * n)(*list(hw)[:n])
             layer(n, self.obs_dim, q["sx_a"], p["sw_a1"], p["fc1_a"], q["sh0_a"], last_mode(0), p["fs1_a"], q["stat_a"], q["part_a"], hw, hp, hd,
                   g16(q, "xi_a"), g16(p, "swi_a1"), g16(q, "ysc0_a"))
-        hw, hp, hd = heads(0, "hwt/c", "hpart_c")
+        hw, hp, hd = heads(0, "hwt/c", "hpart_c", self._A1)
         layer(n, self.sobs_dim, q["sx_c0"] if shared_rows else q["sx_c"], p["sw_c1"], p["fc1_c"], q["sh0_c"], last_mode(0), p["fs1_c"],
               q["stat_c0"] if shared_rows else q["stat_c"], q["part_c"], hw, hp, hd, g16(q, "xi_c0" if shared_rows else "xi_c"), g16(p, "swi_c1"), g16(q, "ysc0/c"))
         cur = 0
@@ -419,7 +422,7 @@ class GroupedPolicyInference:
             if self.track_conditioning:
                 st = self.stat[(0 if with_actors else n):]
                 self._cond.append((st[..., 0].abs() * st[..., 1]).max())
-            hw, hp, hd = heads(l, "hwt" + sfx, "hpart" + sfx)
+            hw, hp, hd = heads(l, "hwt" + sfx, "hpart" + sfx, self._A if with_actors else self._A1)
             layer(G, H, q["sh%d%s" % (cur, sfx)], p["sw%d%s" % (l, sfx)], p["fc%d%s" % (l, sfx)], q["sh%d%s" % (1 - cur, sfx)], last_mode(l),
                   p["fs%d%s" % (l, sfx)], q["stat" + sfx], q["part" + sfx], hw, hp, hd, g16(q, "yinv%d%s" % (l - 1, sfx)), g16(p, "swi%d%s" % (l, sfx)),
                   g16(q, "ysc%d%s" % (l, sfx)) if l < depth - 1 else None)

@@ -501,7 +501,7 @@ static void split_layer_rows(int64_t M, int32_t N, int KC, const std::vector<flo
                 for (int j = 0; j < head_dim; j++) {
                     float p = 0.f;
                     for (int n = 64 * sl; n < 64 * sl + 64; n++) p += row[n] * head_w[(size_t)j * N + n];
-                    head_part[((size_t)sl * M + m) * 16 + j] = p;
+                    head_part[((size_t)sl * M + m) * ((head_dim + 3) & ~3) + j] = p;
                 }
         } else {
             encode_y(m, row.data());
@@ -511,7 +511,7 @@ static void split_layer_rows(int64_t M, int32_t N, int KC, const std::vector<flo
 
 static int split_layer_check(const char* fn, int32_t groups, const void* x, const void* w, const void* b, int64_t M, int32_t N, int32_t K, int32_t act,
                              int32_t out_mode, const void* y, const void* ln_s, const void* ln_stat_in, const void* ln_part_out, const void* head_w,
-                             const void* head_part, int32_t head_dim) {
+                             const void* head_part, const int32_t* head_dims) {
     const std::string f(fn);
     if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = f + ": groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
     if (!x || !w || !b || M < 0 || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3 || out_mode < 0 || out_mode > 2 || (out_mode != 2 && !y)) {
@@ -523,19 +523,22 @@ static int split_layer_check(const char* fn, int32_t groups, const void* x, cons
         g_error = f + ": the LayerNorm folds come together (ln_s, ln_stat_in, ln_part_out), with act = ELU and out_mode 1 or 2";
         return 1;
     }
-    if (out_mode == 2 && (!ln || !head_w || !head_part || head_dim < 1 || head_dim > 16)) {
-        g_error = f + ": out_mode 2 needs the LayerNorm folds, head_w, head_part and 1 <= head_dim <= 16";
+    if (out_mode == 2 && (!ln || !head_w || !head_part || !head_dims)) {
+        g_error = f + ": out_mode 2 needs the LayerNorm folds, head_w, head_part and head_dims";
         return 1;
     }
+    if (out_mode == 2)
+        for (int g = 0; g < groups; g++)
+            if (head_dims[g] < 1 || head_dims[g] > 16) { g_error = "split layer, out_mode 2: 1 <= head_dims[g] <= 16"; return 1; }
     return 0;
 }
 
 MMS_API int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
                                        const float* const* b, void* const* y, int32_t act, int32_t out_mode, const float* const* ln_s,
                                        const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
-                                       int32_t head_dim, void*) {
+                                       const int32_t* head_dims, void*) {
     if (cpu_only(device)) return 1;
-    if (split_layer_check("mms_linear_group_act_split", groups, x, w, b, M, N, K, act, out_mode, y, ln_s, ln_stat_in, ln_part_out, head_w, head_part, head_dim)) return 1;
+    if (split_layer_check("mms_linear_group_act_split", groups, x, w, b, M, N, K, act, out_mode, y, ln_s, ln_stat_in, ln_part_out, head_w, head_part, head_dims)) return 1;
     const bool ln = ln_s != nullptr;
     const int KC = (K + 31) / 32, NC = N / 32;
     for (int g = 0; g < groups; g++) {
@@ -551,7 +554,7 @@ MMS_API int mms_linear_group_act_split(int device, int32_t groups, int64_t M, in
             for (int k = 0; k < KC * 32; k++) wf[n * KC * 32 + k] = join3(wp + (n * KC + k / 32) * 96, k % 32);
         void* yg = out_mode != 2 ? y[g] : nullptr;
         split_layer_rows(M, N, KC, wf, b[g], act, out_mode, ln ? ln_s[g] : nullptr, ln ? ln_stat_in[g] : nullptr, ln ? ln_part_out[g] : nullptr,
-                         out_mode == 2 ? head_w[g] : nullptr, out_mode == 2 ? head_part[g] : nullptr, head_dim,
+                         out_mode == 2 ? head_w[g] : nullptr, out_mode == 2 ? head_part[g] : nullptr, out_mode == 2 ? head_dims[g] : 0,
                          [&](int64_t m, float* xr) { for (int k = 0; k < KC * 32; k++) xr[k] = join3(xp + (m * KC + k / 32) * 96, k % 32); },
                          [](int64_t, int) { return 1.f; },
                          [&](int64_t m, const float* row) {
@@ -646,9 +649,9 @@ MMS_API int mms_linear_group_act_split16(int device, int32_t groups, int64_t M, 
                                          const float* const* b, void* const* y, const float* const* x_inv, const float* const* w_inv,
                                          const float* const* y_scale, int32_t act, int32_t out_mode, const float* const* ln_s,
                                          const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
-                                         int32_t head_dim, void*) {
+                                         const int32_t* head_dims, void*) {
     if (cpu_only(device)) return 1;
-    if (split_layer_check("mms_linear_group_act_split16", groups, x, w, b, M, N, K, act, out_mode, y, ln_s, ln_stat_in, ln_part_out, head_w, head_part, head_dim)) return 1;
+    if (split_layer_check("mms_linear_group_act_split16", groups, x, w, b, M, N, K, act, out_mode, y, ln_s, ln_stat_in, ln_part_out, head_w, head_part, head_dims)) return 1;
     if (!x_inv || !w_inv || (out_mode == 1 && !y_scale)) { g_error = "mms_linear_group_act_split16: bad arguments (x_inv, w_inv, y_scale with out_mode 1)"; return 1; }
     const bool ln = ln_s != nullptr;
     const int KC = (K + 31) / 32, NC = N / 32;
@@ -668,7 +671,7 @@ MMS_API int mms_linear_group_act_split16(int device, int32_t groups, int64_t M, 
         const float* wi = w_inv[g];
         const float* ys = out_mode == 1 ? y_scale[g] : nullptr;
         split_layer_rows(M, N, KC, wf, b[g], act, out_mode, ln ? ln_s[g] : nullptr, ln ? ln_stat_in[g] : nullptr, ln ? ln_part_out[g] : nullptr,
-                         out_mode == 2 ? head_w[g] : nullptr, out_mode == 2 ? head_part[g] : nullptr, head_dim,
+                         out_mode == 2 ? head_w[g] : nullptr, out_mode == 2 ? head_part[g] : nullptr, out_mode == 2 ? head_dims[g] : 0,
                          [&](int64_t m, float* xr) { for (int k = 0; k < KC * 32; k++) xr[k] = join2(xp + (m * KC + k / 32) * 64, k % 32); },
                          [&](int64_t m, int n) { return wi[n] * xi[m]; },
                          [&](int64_t m, const float* row) {
@@ -734,7 +737,7 @@ MMS_API int mms_marl_heads_finish(int device, int32_t groups, int64_t M, int32_t
             const int64_t c = cnt ? cnt[r] : 0;
             for (int j = 0; j < A[g]; j++) {
                 float dot = 0.f;
-                for (int k = 0; k < slots; k++) dot += head_part[g][((size_t)k * M + r) * 16 + j];
+                for (int k = 0; k < slots; k++) dot += head_part[g][((size_t)k * M + r) * ((A[g] + 3) & ~3) + j];
                 const float mu = rstd * (dot - mean * hs[g][j]) + hc[g][j];
                 if (!sd) { out[g][r * pitch + j] = mu; continue; }
                 const float z = mms::rand_normal(seed + (uint64_t)g, (uint64_t)(row_offset + r), (uint64_t)c, (uint32_t)j);

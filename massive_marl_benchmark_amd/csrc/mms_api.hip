@@ -530,7 +530,7 @@ __attribute__((visibility("default"))) int mms_linear_group_act_split(int device
                                                                       const void* const* w, const float* const* b, void* const* y, int32_t act,
                                                                       int32_t out_mode, const float* const* ln_s, const float* const* ln_stat_in,
                                                                       float* const* ln_part_out, const float* const* head_w, float* const* head_part,
-                                                                      int32_t head_dim, void* s) {
+                                                                      const int32_t* head_dims, void* s) {
     MMS_DEV(device)
     if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_linear_group_act_split: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
     if (!x || !w || !b || M < 0 || M > 0x7fffffff || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3 || out_mode < 0 || out_mode > 2 ||
@@ -543,8 +543,8 @@ __attribute__((visibility("default"))) int mms_linear_group_act_split(int device
         g_create_error = "mms_linear_group_act_split: the LayerNorm folds come together (ln_s, ln_stat_in, ln_part_out), with act = ELU and out_mode 1 or 2";
         return 1;
     }
-    if (out_mode == 2 && (!ln || !head_w || !head_part || head_dim < 1 || head_dim > 16)) {
-        g_create_error = "mms_linear_group_act_split: out_mode 2 needs the LayerNorm folds, head_w, head_part and 1 <= head_dim <= 16";
+    if (out_mode == 2 && (!ln || !head_w || !head_part || !head_dims)) {
+        g_create_error = "mms_linear_group_act_split: out_mode 2 needs the LayerNorm folds, head_w, head_part and head_dims";
         return 1;
     }
     mms::SplitLinearArgs a = {};
@@ -560,9 +560,12 @@ __attribute__((visibility("default"))) int mms_linear_group_act_split(int device
         if ((bits & 15) != 0) { g_create_error = "mms_linear_group_act_split: operands must be 16-byte aligned"; return 1; }
         a.x[g] = x[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.y[g] = out_mode != 2 ? y[g] : nullptr;
         if (ln) { a.s[g] = ln_s[g]; a.stat_in[g] = ln_stat_in[g]; a.part_out[g] = ln_part_out[g]; }
-        if (out_mode == 2) { a.head_w[g] = head_w[g]; a.head_part[g] = head_part[g]; }
+        if (out_mode == 2) {
+            if (head_dims[g] < 1 || head_dims[g] > 16) { g_create_error = "split layer, out_mode 2: 1 <= head_dims[g] <= 16"; return 1; }
+            a.head_w[g] = head_w[g]; a.head_part[g] = head_part[g]; a.hdims[g] = head_dims[g];
+        }
     }
-    a.M = (int)M; a.N = N; a.KC = (K + 31) / 32; a.act = act; a.out_mode = out_mode; a.head_dim = out_mode == 2 ? head_dim : 0;
+    a.M = (int)M; a.N = N; a.KC = (K + 31) / 32; a.act = act; a.out_mode = out_mode; /* head dims: per group, below */
     MMS_FREE(mms::launch_linear_split(a, groups, (hipStream_t)s));
     return 0;
 }
@@ -603,7 +606,7 @@ __attribute__((visibility("default"))) int mms_linear_group_act_split16(int devi
                                                                         const float* const* x_inv, const float* const* w_inv, const float* const* y_scale,
                                                                         int32_t act, int32_t out_mode, const float* const* ln_s,
                                                                         const float* const* ln_stat_in, float* const* ln_part_out,
-                                                                        const float* const* head_w, float* const* head_part, int32_t head_dim, void* s) {
+                                                                        const float* const* head_w, float* const* head_part, const int32_t* head_dims, void* s) {
     MMS_DEV(device)
     if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_linear_group_act_split16: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
     if (!x || !w || !b || !x_inv || !w_inv || M < 0 || M > 0x7fffffff || (M % 128) != 0 || N <= 0 || (N % 128) != 0 || K <= 0 || act < 0 || act > 3 ||
@@ -616,8 +619,8 @@ __attribute__((visibility("default"))) int mms_linear_group_act_split16(int devi
         g_create_error = "mms_linear_group_act_split16: the LayerNorm folds come together (ln_s, ln_stat_in, ln_part_out), with act = ELU and out_mode 1 or 2";
         return 1;
     }
-    if (out_mode == 2 && (!ln || !head_w || !head_part || head_dim < 1 || head_dim > 16)) {
-        g_create_error = "mms_linear_group_act_split16: out_mode 2 needs the LayerNorm folds, head_w, head_part and 1 <= head_dim <= 16";
+    if (out_mode == 2 && (!ln || !head_w || !head_part || !head_dims)) {
+        g_create_error = "mms_linear_group_act_split16: out_mode 2 needs the LayerNorm folds, head_w, head_part and head_dims";
         return 1;
     }
     mms::Split16LinearArgs a = {};
@@ -634,9 +637,12 @@ __attribute__((visibility("default"))) int mms_linear_group_act_split16(int devi
         a.x[g] = x[g]; a.w[g] = w[g]; a.b[g] = b[g]; a.y[g] = out_mode != 2 ? y[g] : nullptr;
         a.xinv[g] = x_inv[g]; a.winv[g] = w_inv[g]; a.yscale[g] = out_mode == 1 ? y_scale[g] : nullptr;
         if (ln) { a.s[g] = ln_s[g]; a.stat_in[g] = ln_stat_in[g]; a.part_out[g] = ln_part_out[g]; }
-        if (out_mode == 2) { a.head_w[g] = head_w[g]; a.head_part[g] = head_part[g]; }
+        if (out_mode == 2) {
+            if (head_dims[g] < 1 || head_dims[g] > 16) { g_create_error = "split layer, out_mode 2: 1 <= head_dims[g] <= 16"; return 1; }
+            a.head_w[g] = head_w[g]; a.head_part[g] = head_part[g]; a.hdims[g] = head_dims[g];
+        }
     }
-    a.M = (int)M; a.N = N; a.KC = (K + 31) / 32; a.act = act; a.out_mode = out_mode; a.head_dim = out_mode == 2 ? head_dim : 0;
+    a.M = (int)M; a.N = N; a.KC = (K + 31) / 32; a.act = act; a.out_mode = out_mode; /* head dims: per group, below */
     MMS_FREE(mms::launch_linear_split16(a, groups, (hipStream_t)s));
     return 0;
 }

@@ -87,11 +87,12 @@ struct SplitLinearArgs {
     const float* s[kMaxGroups];
     const float* stat_in[kMaxGroups];
     float* part_out[kMaxGroups];
-    // out_mode 2: head_w[g] [head_dim, N] f32 (the output head's weight, the last LayerNorm's gamma folded in);
-    //   head_part[g][(slot * M + row) * 16 + j] = sum over the slot's 64 columns of y[row, n] head_w[j, n], j < head_dim <= 16
+    // out_mode 2: head_w[g] [hdims[g], N] f32 (the output head's weight, the last LayerNorm's gamma folded in);
+    //   head_part[g][(slot * M + row) * stride_g + j] = sum over the slot's 64 columns of y[row, n] head_w[j, n], j < hdims[g] <= 16,
+    //   stride_g = hdims[g] rounded up to 4 (a critic's one value: 16 bytes per row and slot, an 8-action actor's: 32)
     const float* head_w[kMaxGroups];
     float* head_part[kMaxGroups];
-    int head_dim;
+    int hdims[kMaxGroups];
     int tiles;          // (set by the launcher) output tiles of the launch: the persistent grid walks them
 };
 
@@ -142,7 +143,7 @@ struct Split16LinearArgs {
     float* part_out[kMaxGroups];
     const float* head_w[kMaxGroups];
     float* head_part[kMaxGroups];
-    int head_dim;
+    int hdims[kMaxGroups];
     int tiles;
 };
 

@@ -632,15 +632,16 @@ __global__ void __launch_bounds__(256) marl_heads_finish_kernel(HeadsFinishArgs 
     const int A = a.A[g];
     float* out = a.out[g] + row * a.out_pitch[g];
     const int64_t c = (a.std[g] && a.counters[g]) ? a.counters[g][row] : 0;
-    float dots[16];                                                      // a row's partials of one slot are 64 contiguous bytes: 16-byte loads
+    float dots[16];                                                      // a row's partials of one slot are contiguous: 16-byte loads, coalesced over the rows
 #pragma unroll
     for (int j = 0; j < 16; j++) dots[j] = 0.f;
     const float4* hp = reinterpret_cast<const float4*>(a.head_part[g]);
+    const int HQ = (A + 3) >> 2;                                         // float4 pieces per row and slot (the partials' stride is A rounded up to 4)
     for (int k = 0; k < a.slots; k++) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
             if (4 * q < A) {
-                const float4 v = hp[((size_t)k * a.M + row) * 4 + q];
+                const float4 v = hp[((size_t)k * a.M + row) * HQ + q];
                 dots[4 * q] += v.x; dots[4 * q + 1] += v.y; dots[4 * q + 2] += v.z; dots[4 * q + 3] += v.w;
             }
     }

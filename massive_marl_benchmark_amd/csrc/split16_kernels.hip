@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
             }
         }
         if constexpr (OUT == 2) {
-            const int A = a.head_dim;
+            const int A = a.hdims[e_gi], HS = (A + 3) & ~3;           // this network's head rows; its partials' row stride
             float* hw = reinterpret_cast<float*>(lds + G::HW_OFF);                           // [A][128], a region of its own
             const float* __restrict__ HW = a.head_w[e_gi];
             for (int i = t; i < A * 128; i += 512) hw[i] = HW[(size_t)(i >> 7) * N + e_n0 + (i & 127)];
@@ -421,12 +421,12 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
                     }
                 }
             }
-            float* __restrict__ hp = a.head_part[e_gi] + (size_t)(2 * e_tn + wn) * a.M * 16;
+            float* __restrict__ hp = a.head_part[e_gi] + (size_t)(2 * e_tn + wn) * a.M * HS;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    if (4 * i + g4 < A) hp[(size_t)(mbase + 16 * mt + r16) * 16 + 4 * i + g4] = keep[mt][i];
+                    if (4 * i + g4 < A) hp[(size_t)(mbase + 16 * mt + r16) * HS + 4 * i + g4] = keep[mt][i];
             __syncthreads();                                            // (hw is restaged by the next tile)
         } else if constexpr (OUT == 1) {
             constexpr int RS = 2 * kChunk16 + 16;                        // scratch row: this wave's two chunks (64 n) of one m, padded
