@@ -101,7 +101,7 @@ struct SplitLinearArgs {
 // out[r, j] = rstd (dot_j - mean hs[j]) + hc[j]   (hs = head_w 1, hc = w beta + b), then the Gaussian sample exactly as HeadsArgs.
 struct HeadsFinishArgs {
     const float* part[kMaxGroups];          // [slots, M, 2]
-    const float* head_part[kMaxGroups];     // [slots, M, 16]
+    const float* head_part[kMaxGroups];     // [slots, M, A_g rounded up to 4]
     const float* hs[kMaxGroups];            // [A_g]
     const float* hc[kMaxGroups];            // [A_g]
     const float* std[kMaxGroups];
