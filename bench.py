@@ -218,7 +218,7 @@ def main():
     planes_buf = torch.empty(N * ((obs_dim + 31) // 32) * 128, dtype=torch.uint8, device=device)
     planes_state = {"used": False}
 
-    def measure_rollout(pdtype, K_req, W_req, split=True, fmt=None):
+    def measure_rollout(pdtype, K_req, W_req, split=True, fmt=None, use_graph=True):
         ac_ = ac if pdtype == torch.float32 else ac_bf16
         ac_.split_layers = bool(split)
         ac_.split_format = fmt or args.split_format
@@ -295,8 +295,11 @@ def main():
         for _ in range(NSTEPS):                      # eager warm-up (allocator, rocBLAS handles)
             rollout_step()
         torch.cuda.synchronize()
-        if not args.no_graph:
-            # one graph = one full PPO iteration's rollout (8 steps + GAE): launch-bound inner loop -> hipGraph
+        if use_graph and not args.no_graph:
+            # one graph = one full PPO iteration's rollout (ActorCritic.refresh + 8 steps + GAE): launch-bound inner loop -> hipGraph.
+            # The first act of a rollout (storage.step == 0) re-derives the layers' operand planes, scales and bound chain from the
+            # parameters on the device (refresh: device work at stable addresses), so it is part of the captured graph and of the
+            # timed region: a replay after an optimizer step computes with the updated parameters.
             side = torch.cuda.Stream(device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
@@ -397,8 +400,24 @@ def main():
         ex_elapsed, ex_K, _, _ = measure_rollout(torch.float32, min(args.steps, 128), 16, split=False)
         if args.split_format != "bf16x3":
             b3_elapsed, b3_K, _, _ = measure_rollout(torch.float32, min(args.steps, 128), 16, fmt="bf16x3")
+    # the same K steps launched eagerly from Python, the way the reference's loop drives the path (ppo.py:126-161: act -> step ->
+    # add_transitions per step) -- what a swapped-import PPO.run obtains without capturing anything
+    eg_elapsed, eg_K = 0.0, 0
+    if not args.no_graph:
+        eg_elapsed, eg_K, _, _ = measure_rollout(pdtype, min(args.steps, 512), 16, split=not args.exact_fp32_layers, use_graph=False)
     elapsed, K, W, graphed = measure_rollout(pdtype, args.steps, args.warmup, split=not args.exact_fp32_layers)
     graph = graphed or None
+    refresh_us = None
+    if pdtype == torch.float32 and not args.library_gemms:
+        for _ in range(4):
+            ac.refresh()
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(32):
+            ac.refresh()
+        ev1.record()
+        torch.cuda.synchronize()
+        refresh_us = 1e3 * ev0.elapsed_time(ev1) / 32
     layer_err = policy_layer_errors(torch, ac, obs_clipped) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
     layer_roof = policy_layer_roofline(torch, ac, obs_clipped, args) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
     eng.bind_obs_out(None)
@@ -448,7 +467,7 @@ def main():
             "config": {"workload": "TenAnt num_envs=%d per GPU, PPO rollout: ActorCritic MLP [1024,1024,512]x2 (%s) + fused sim step "
                                    "(dt 0.0166, 2 substeps) + RolloutStorage + GAE every %d steps" % (N, args.policy_dtype, NSTEPS),
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d, no data-path collective" % world,
-                       "hipgraph": bool(graph), "rollouts_per_graph": max(1, args.rollouts_per_graph), "fused_act_and_bound_slots": not args.unfused, "obs_planes_from_step_kernel": bool(planes_state["used"]), "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else ((("mms_linear_group_act_split16 (2 x fp16 planes, row scales, fp32 accumulate)" if args.split_format == "f16x2" else "mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)") if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "mms_linear2_act (exact fp32 MFMA)") + " + mms_ppo_heads_act"),
+                       "hipgraph": bool(graph), "refresh_in_graph": bool(graph) and not args.unfused, "rollouts_per_graph": max(1, args.rollouts_per_graph), "fused_act_and_bound_slots": not args.unfused, "obs_planes_from_step_kernel": bool(planes_state["used"]), "critic_stream": not args.one_stream, "policy_layers": "library GEMMs" if args.library_gemms else ((("mms_linear_group_act_split16 (2 x fp16 planes, row scales, fp32 accumulate)" if args.split_format == "f16x2" else "mms_linear_group_act_split (3 x bf16 planes, fp32 accumulate)") if (not args.exact_fp32_layers and not args.library_gemms and args.policy_dtype == "fp32") else "mms_linear2_act (exact fp32 MFMA)") + " + mms_ppo_heads_act"),
                        "friction": {"rule": "average" if abs(eng.config.model.boxgnd_mu) > 0 else "min", "gnd_mu": eng.config.model.gnd_mu,
                                     "boxgnd_mu": eng.config.model.boxgnd_mu, "antbox_mu": eng.config.model.antbox_mu,
                                     "note": "this build's modelling choice (PhysX default combine rule), not reference-pinned: DESIGN.md section 4"},
@@ -489,6 +508,17 @@ def main():
             line["rollout_bf16x3_layers"] = {"value": world * N * b3_K / b3_elapsed, "unit": "env-steps/s", "steps": b3_K, "ms_per_step": 1e3 * b3_elapsed / b3_K,
                                              "note": "the same rollout with the hidden layers on the three-bf16-plane kernel (mms_linear_group_act_split: every operand exact, "
                                                      "six products): the headline path of this round's first half, kept as an A/B"}
+        if eg_K:
+            line["rollout_eager"] = {"value": world * N * eg_K / eg_elapsed, "unit": "env-steps/s", "steps": eg_K, "ms_per_step": 1e3 * eg_elapsed / eg_K,
+                                     "ratio_to_graph": (eg_elapsed / eg_K) / (elapsed / K),
+                                     "note": "the same rollout step launched eagerly from Python, no hipGraph: what the reference's own loop (ppo.py:126-161) "
+                                             "obtains with the imports swapped; `value` above is the hipGraph replay of the same launches (INTEGRATION.md: "
+                                             "how to capture it)"}
+        if refresh_us is not None:
+            line["policy_refresh"] = {"us_per_refresh": refresh_us, "per_step_share_us": refresh_us / NSTEPS,
+                                      "note": "ActorCritic.refresh(): the hidden layers' operand planes, row scales and bound chain re-derived from the "
+                                              "fp32 parameters on the device; runs at the first act of every rollout, INSIDE the captured graph and the "
+                                              "timed region (eager back-to-back figure here)"}
         if layer_err is not None:
             line["policy_layers_error_vs_f64"] = layer_err
         if layer_roof is not None:
@@ -539,7 +569,8 @@ def policy_layer_roofline(torch, ac, obs, args):
 
 def policy_layer_errors(torch, ac, obs):
     """Both networks' last hidden activations (three layers deep) on the bench's own observation rows and weights: the two split
-    kernels and the exact-fp32 MFMA kernel, each against the same layers evaluated in float64."""
+    kernels, the exact-fp32 MFMA kernel and torch's fp32 nn.Linear + nn.ELU (the reference's arithmetic), each against the same layers
+    evaluated in float64."""
     import copy
     obs = obs.detach().clone()
     out = {}
@@ -557,6 +588,13 @@ def policy_layer_errors(torch, ac, obs):
                 return None
             e = torch.cat([hid[g].double() - ref[g] for g in range(2)])
             out[name] = {"rms": float(e.pow(2).mean().sqrt()) / scale, "max": float(e.abs().max()) / scale, "mean": float(e.mean()) / scale}
+        # the reference's own arithmetic on this box: torch's fp32 nn.Linear (F.linear -> the library's fp32 GEMM) + nn.ELU, the modules as
+        # the reference builds them (agents/algorithms/rl/ppo/module.py:27-52), on the same rows and weights
+        hid = [net[:-1](obs) for net in (ac.actor, ac.critic)]
+        e = torch.cat([hid[g].double() - ref[g] for g in range(2)])
+        out["torch_fp32_linear"] = {"rms": float(e.pow(2).mean().sqrt()) / scale, "max": float(e.abs().max()) / scale, "mean": float(e.mean()) / scale}
+        out["split_2xf16_over_torch_fp32"] = {"rms": out["split_2xf16"]["rms"] / out["torch_fp32_linear"]["rms"],
+                                              "max": out["split_2xf16"]["max"] / out["torch_fp32_linear"]["max"]}
     out["unit"] = "rms of the float64 activations (%.4f)" % scale
     out["note"] = ("error of the last hidden layer's activations [2 x %d x %d], three layers deep, against the same layers in float64, on the "
                    "observation rows and weights of this run" % (obs.shape[0], ref[0].shape[1]))

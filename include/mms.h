@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define MMS_ABI_VERSION 3
+#define MMS_ABI_VERSION 4
 #define MMS_DR_FLOATS 33       /* per-ant physical domain-randomisation block, see mms_set_dr */
 
 enum mms_task { MMS_TASK_TEN_ANT = 0, MMS_TASK_ONE_ANT = 1, MMS_TASK_MULTI_INGENUITY = 2,
@@ -214,6 +214,12 @@ int mms_gae_ppo(int device, const float* rewards, const uint8_t* dones, const fl
                 int32_t T, int64_t N, float gamma, float lam, void* hip_stream);
 /* advantages := (advantages - mean) / (std + 1e-8) with the unbiased std from stats. */
 int mms_adv_normalize(int device, float* advantages, const double* stats, int64_t count, void* hip_stream);
+/* mms_gae_ppo + mms_adv_normalize for ONE rank (nothing to all-reduce in between), the whole of storage.py:51-65: up to 65536
+ * transitions in a single launch with a fixed summation order (bit-reproducible; stats need no zeroing), larger rollouts as the two
+ * launches above.  stats[0..2] receives {sum(adv), sum(adv^2), count} of the un-normalised advantages. */
+int mms_gae_ppo_normalized(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values,
+                           float* returns, float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam,
+                           void* hip_stream);
 
 /* MARL GAE (separated_buffer.py:153-164, use_proper_time_limits=False): value_preds [T+1,N]
  * (row T already holds next_value), masks [T+1,N], rewards [T,N], returns [T+1,N];
@@ -375,6 +381,23 @@ int mms_linear_group_act_split(int device, int32_t groups, int64_t M, int32_t N,
 int mms_split_planes16_group(int device, int32_t groups, int64_t rows, int32_t K, int32_t x_pitch, const float* const* x, void* const* planes,
                              float* const* scale, float* const* inv, int32_t nchains, int32_t L, const float* const* chain,
                              float* const* chain_scale, float* const* chain_inv, float* const* stat, float eps, void* hip_stream);
+
+/* The weights' side of the same layers, refreshed ON THE DEVICE after every parameter update (no host synchronisation, every output at
+ * the caller's address: the two calls may sit at the head of a captured hipGraph of a rollout, so that a replay after an optimizer step
+ * computes with the updated parameters -- ActorCritic.refresh(), algorithms/rl/ppo/module.py; the reference re-reads its nn.Linear
+ * parameters in every forward, agents/algorithms/rl/ppo/module.py:73-87):
+ * mms_weight_planes16_group: planes_g / scale_g / inv_g <- split of w_g [N[g], K[g]] f32 (contiguous; N, K: HOST arrays, the shapes may
+ *   differ from group to group: all hidden layers of both networks in ONE launch) exactly as mms_split_planes16_group, and
+ *   l1[g][n] = sum_k |w_g[n, k]| (f32 [N[g]]; l1 or l1[g] NULL: not written);
+ * mms_chain_refresh16: entry e = c L + l of the bound chain, chain[e] = (max_i l1[e][i], max_i |bias[e][i]|), i < n[e] (bias or bias[e]
+ *   NULL: 0) -- `chain` [nchains, L, 2] is what mms_split_planes16_group takes; l1, bias, n: HOST arrays of nchains * L <= MMS_MAX_GROUPS
+ *   entries.  rows > 0: also the chain's scales for rows whose input bound is the CONSTANT bound0 (observation rows clamped to clip_obs
+ *   whose planes the step kernel wrote, mms_bind_obs_planes16: bound0 = 2^14 / scale): chain_scale / chain_inv [nchains, L, rows] as
+ *   mms_split_planes16_group would leave them for a row whose largest magnitude is bound0. */
+int mms_weight_planes16_group(int device, int32_t groups, const int64_t* N, const int32_t* K, const float* const* w, void* const* planes,
+                              float* const* scale, float* const* inv, float* const* l1, void* hip_stream);
+int mms_chain_refresh16(int device, int32_t nchains, int32_t L, const float* const* l1, const float* const* bias, const int32_t* n,
+                        float* chain, float bound0, int64_t rows, float* chain_scale, float* chain_inv, void* hip_stream);
 
 /* mms_linear_group_act_split with x_g, w_g (and, out_mode 1, y_g) in the H32 format.  x_inv[g] f32 [M] and w_inv[g] f32 [N] (16-byte
  * aligned) are the inverse row scales of the operands; y_scale[g] f32 [M] (out_mode 1) is the scale the output rows are stored with --

@@ -60,8 +60,27 @@ class ActorCritic(nn.Module):
         self._act_bufs = None
         self._value_bufs = None
         self._one_bufs = None
-        self._wplanes = None    # id(Linear) -> (version tag, P32 planes of its weight)
+        self._wplanes = None    # id(Linear) -> (version tag, P32 planes of its weight, the Linear)
         self._split_bufs = None
+        self._nets = None       # (actor hidden Linears, critic hidden Linears)
+        self._h16 = None        # the f16x2 layers' weight-side state (planes, scales, bound chain): _h16_state
+        self._addr_tag = None   # addresses / version counters of the parameters the derived buffers were built from
+        self._ver_tag = None
+        self._calls = None      # prebuilt launch lists of the f16x2 hidden layers, per (buffers, input addresses)
+        self._sample_calls = None
+        self._qualify = None
+
+    _DERIVED = ("_counters", "_side", "_trunk", "_act_bufs", "_value_bufs", "_one_bufs", "_wplanes", "_split_bufs", "_nets", "_h16", "_addr_tag",
+                "_ver_tag", "_calls", "_sample_calls", "_qualify", "_bound")
+
+    def __deepcopy__(self, memo):
+        """A copy starts without derived state: the caches hold device addresses of THIS module's parameters and buffers."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in self._DERIVED else copy.deepcopy(v, memo)
+        return new
 
     @staticmethod
     def init_weights(sequential, scales):
@@ -103,33 +122,38 @@ class ActorCritic(nn.Module):
 
     def _fp32_layers_qualify(self):
         """mms_linear2_act applies: fp32 ELU networks, actor and critic with the same hidden shapes, input widths multiples of 4."""
+        dt = self.log_std.dtype
+        if self._qualify is not None and self._qualify[0] == dt:
+            return self._qualify[1]
         a_lin = [m for m in self.actor if isinstance(m, nn.Linear)]
         c_lin = [m for m in self.critic if isinstance(m, nn.Linear)]
         acts = [m for m in list(self.actor) + list(self.critic) if not isinstance(m, nn.Linear)]
-        return (len(a_lin) == len(c_lin) and len(a_lin) >= 2 and all(isinstance(m, nn.ELU) and m.alpha == 1.0 for m in acts)
-                and all(la.weight.shape == lc.weight.shape and la.weight.dtype == torch.float32 and la.in_features % 4 == 0
-                        and la.bias is not None and lc.bias is not None for la, lc in zip(a_lin[:-1], c_lin[:-1])))
+        ok = (len(a_lin) == len(c_lin) and len(a_lin) >= 2 and all(isinstance(m, nn.ELU) and m.alpha == 1.0 for m in acts)
+              and all(la.weight.shape == lc.weight.shape and la.weight.dtype == torch.float32 and la.in_features % 4 == 0
+                      and la.bias is not None and lc.bias is not None for la, lc in zip(a_lin[:-1], c_lin[:-1])))
+        self._qualify = (dt, ok)
+        return ok
 
     # -- split-operand layers ------------------------------------------------------------------
     @staticmethod
     def _p32_bytes(rows, K):
         return rows * ((K + 31) // 32) * 192               # MMS_P32_BYTES (include/mms.h)
 
-    def _weight_planes(self, lin, L, idx, stream):
-        """P32 planes of a Linear layer's weight, re-split when the parameter has changed (its version counter moves with every
-        in-place optimizer step) or moved."""
+    def _weight_planes(self, lin, L, idx, stream, force=False):
+        """P32 planes of a Linear layer's weight (a buffer allocated once per layer), re-split when the parameter has changed (its version
+        counter moves with every in-place optimizer step), has moved, or refresh() asks (force)."""
         if self._wplanes is None:
             self._wplanes = {}
         w = lin.weight.detach()
         tag = (w._version, w.data_ptr(), str(w.device))
         hit = self._wplanes.get(id(lin))
-        if hit is None or hit[0] != tag:
+        if force or hit is None or hit[0] != tag:
             planes = hit[1] if hit is not None and hit[1].device == w.device else \
                 torch.empty(self._p32_bytes(lin.out_features, lin.in_features), dtype=torch.uint8, device=w.device)
             wc = w.contiguous()
             _lib.check(L.mms_split_planes(idx, lin.out_features, lin.in_features, 0, ctypes.c_void_p(wc.data_ptr()),
                                           ctypes.c_void_p(planes.data_ptr()), stream), None, "mms_split_planes", L)
-            self._wplanes[id(lin)] = (tag, planes)
+            self._wplanes[id(lin)] = (tag, planes, lin)
             return planes
         return hit[1]
 
@@ -137,52 +161,185 @@ class ActorCritic(nn.Module):
     def _h32_bytes(rows, K):
         return rows * ((K + 31) // 32) * 128               # MMS_H32_BYTES (include/mms.h)
 
-    def _weight_planes16(self, lin, L, idx, stream):
-        """H32 planes of a Linear layer's weight, the inverse of its row scales, and the layer's entry of the bound chain
-        (largest row 1-norm, largest |bias|: |act(W x + b)| <= that norm max|x| + that bias) as a device tensor [2]; refreshed when the
-        weight or the bias has changed (version counters) or moved."""
-        if self._wplanes is None:
-            self._wplanes = {}
-        w, b = lin.weight.detach(), lin.bias.detach()
-        tag = (w._version, w.data_ptr(), b._version, b.data_ptr(), str(w.device))
-        hit = self._wplanes.get(("h", id(lin)))
-        if hit is None or hit[0] != tag:
-            N, K = lin.out_features, lin.in_features
-            fresh = hit is None or hit[1].device != w.device
-            planes = torch.empty(self._h32_bytes(N, K), dtype=torch.uint8, device=w.device) if fresh else hit[1]
-            scale = torch.empty(N, device=w.device) if fresh else hit[4]
-            inv = torch.empty(N, device=w.device) if fresh else hit[2]
-            wc = w.contiguous()
-            one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
-            _lib.check(L.mms_split_planes16_group(idx, 1, N, K, 0, one(wc), one(planes), one(scale), one(inv), 0, 0, None, None, None, None, 0.0, stream),
-                       None, "mms_split_planes16_group", L)
-            bound = torch.stack([wc.abs().sum(1).max(), b.abs().max()])
-            hit = (tag, planes, inv, bound, scale)
-            self._wplanes[("h", id(lin))] = hit
-        return hit[1], hit[2], hit[3], hit[0]
+    # -- two scaled fp16 planes per operand: everything derived from the parameters lives at a STABLE address and is rebuilt by device
+    #    work only (refresh), so that a hipGraph of a rollout that starts with refresh() follows every optimizer step ---------------------
+    def _networks(self):
+        """(hidden Linear layers of the actor, of the critic): every Linear but the last of each Sequential (cached; the modules'
+        structure is fixed after construction)."""
+        if self._nets is None:
+            self._nets = [[m for m in net if isinstance(m, nn.Linear)][:-1] for net in (self.actor, self.critic)]
+        return self._nets
+
+    def _param_tags(self):
+        """(version counters, addresses) of every parameter a derived buffer or a cached launch depends on."""
+        ps = [q for net in self._networks() for l in net for q in (l.weight, l.bias) if q is not None]
+        ps += [q for q in (self.actor[-1].weight, self.actor[-1].bias, self.critic[-1].weight, self.critic[-1].bias, self.log_std) if q is not None]
+        return tuple(q._version for q in ps), tuple(q.data_ptr() for q in ps)
+
+    def _h16_state(self, dev):
+        """The weights' side of the f16x2 layers on device `dev`: per hidden Linear its H32 planes, row scales and row 1-norms, and per
+        network the bound chain's (mult, add) pairs -- one flat tensor [actor L x 2 | critic L x 2], so that the chains of networks that
+        share an input are one contiguous [nchains, L, 2] block the split kernel reads where it lies.  Allocated once; refreshed in place."""
+        st = self._h16
+        if st is not None and st["dev"] == dev:
+            return st
+        L, idx, _ = _lib.for_device(dev)
+        nets = self._networks()
+        recs, off, slices = [], 0, []
+        for net in nets:
+            rs = []
+            for l in net:
+                assert l.weight.dtype == torch.float32 and l.weight.is_contiguous() and l.bias is not None and l.weight.device == dev
+                N, K = l.out_features, l.in_features
+                rs.append({"lin": l, "N": N, "K": K, "planes": torch.empty(self._h32_bytes(N, K), dtype=torch.uint8, device=dev),
+                           "scale": torch.empty(N, device=dev), "inv": torch.empty(N, device=dev), "l1": torch.empty(N, device=dev)})
+            recs.append(rs)
+            slices.append((off, max(len(net) - 1, 0)))
+            off += 2 * max(len(net) - 1, 0)
+        bounds = torch.zeros(max(off, 2), device=dev)
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        # the refresh launches, arguments prebuilt: the planes, row scales and row 1-norms of ALL hidden layers' weights in one launch ...
+        flat = [r for rs in recs for r in rs]
+        calls = []
+        if flat:
+            calls.append((L.mms_weight_planes16_group, (idx, len(flat), (ctypes.c_int64 * len(flat))(*[r["N"] for r in flat]),
+                                                        (ctypes.c_int32 * len(flat))(*[r["K"] for r in flat]), arr([r["lin"].weight for r in flat]),
+                                                        arr([r["planes"] for r in flat]), arr([r["scale"] for r in flat]), arr([r["inv"] for r in flat]),
+                                                        arr([r["l1"] for r in flat])), "mms_weight_planes16_group"))
+        st = {"dev": dev, "L": L, "idx": idx, "recs": recs, "bounds": bounds, "slices": slices, "calls": calls, "given": {}, "chain_args": {}}
+        self._h16 = st
+        return st
+
+    def _chain_args(self, st, members):
+        """(nchains, L, l1 pointers, bias pointers, counts, chain) of mms_chain_refresh16 for the chains of networks `members`."""
+        members = tuple(members)
+        hit = st["chain_args"].get(members)
+        if hit is None:
+            chain, Lh = self._chain(st, list(members))
+            ent = [st["recs"][g][li] for g in members for li in range(Lh)]
+            arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            hit = (len(members), Lh, arr([r["l1"] for r in ent]), arr([r["lin"].bias for r in ent]), (ctypes.c_int32 * len(ent))(*[r["N"] for r in ent]),
+                   ctypes.c_void_p(chain.data_ptr())) if Lh else None
+            st["chain_args"][members] = hit
+        return hit
+
+    def _chain(self, st, members):
+        """The contiguous [nchains, L, 2] block of the bound chains of networks `members` (indices into (actor, critic)), or None when
+        they have a single hidden layer (nothing is stored as planes)."""
+        o0, Lh = st["slices"][members[0]]
+        if Lh == 0:
+            return None, 0
+        for j, g in enumerate(members):
+            assert st["slices"][g] == (o0 + 2 * Lh * j, Lh), "networks that share an input must be adjacent and equally deep"
+        return st["bounds"][o0: o0 + 2 * Lh * len(members)], Lh
+
+    def refresh(self):
+        """Rebuild everything the fused paths derive from the parameters -- the hidden layers' operand planes, their row scales, the bound
+        chain and the hidden activations' scales of the given-planes path -- from the parameters as they are NOW.  Device work only, on
+        the caller's current stream, into buffers whose addresses never change: it may be captured at the head of a hipGraph of a rollout
+        (bench.py does), and a replay after an optimizer step then computes with the updated parameters.
+
+        When it runs by itself: at the first `act` of every rollout when a RolloutStorage is bound (bind_rollout: storage.step == 0),
+        unconditionally -- a parameter update of ANY kind between two rollouts is followed, also one through `param.data`, which moves no
+        version counter (agents/algorithms/marl/hatrpo_trainer.py:122 updates that way; PPO's optimizer.step() does not); on every other
+        call of act / value when a parameter's version counter or address has changed.  Call it yourself after writing parameters through
+        `.data` without a bound storage, and before replaying a captured graph that does not contain it."""
+        if True:
+            dev = self.log_std.device
+            vers, addrs = self._param_tags()
+            if self._addr_tag is not None and self._addr_tag != (addrs, str(dev)):
+                # the parameters moved (.to(device), a new storage): every cached address is void
+                self._h16, self._wplanes, self._split_bufs, self._calls, self._sample_calls = None, None, None, None, None
+            self._addr_tag, self._ver_tag = (addrs, str(dev)), vers
+            st = self._h16
+            if st is not None:
+                stream = _lib.for_device(st["dev"])[2]
+                for fn, args, what in st["calls"]:
+                    _lib.check(fn(*args, stream), None, what, st["L"])
+                # ... then the bound chain: one launch per set of constant-bound scales (it also stores the chain entries of its
+                # networks), and one without rows for networks no such set covers
+                covered = set()
+                for (members, rows, scale), (_, cs, ci, alias) in st["given"].items():
+                    ca = self._chain_args(st, members)
+                    if ca is None or alias:
+                        continue
+                    _lib.check(st["L"].mms_chain_refresh16(st["idx"], *ca, 16384.0 / scale, rows, ctypes.c_void_p(cs.data_ptr()), ctypes.c_void_p(ci.data_ptr()), stream),
+                               None, "mms_chain_refresh16", st["L"])
+                    covered.update(members)
+                depths = {Lh for _, Lh in st["slices"]}
+                rest = [tuple(range(len(st["recs"])))] if len(depths) == 1 else [(g,) for g in range(len(st["recs"]))]
+                for grp in rest:
+                    if not set(grp) <= covered:
+                        ca = self._chain_args(st, grp)
+                        if ca is not None:
+                            _lib.check(st["L"].mms_chain_refresh16(st["idx"], *ca, 0.0, 0, None, None, stream), None, "mms_chain_refresh16", st["L"])
+            if self._wplanes:                                # the three-plane format's weights (no scales, no chain)
+                for key in list(self._wplanes):
+                    tag, planes, lin = self._wplanes[key]
+                    if self.split_format == "bf16x3":
+                        self._weight_planes(lin, *_lib.for_device(lin.weight.device), force=True)
+                    else:
+                        self._wplanes[key] = (None, planes, lin)    # not in use now: re-split at their next use
+
+    def _ensure_fresh(self):
+        """refresh() when a parameter's version counter or address has moved since the derived buffers were built (see refresh for what
+        that does and does not see), and at the first act of a bound rollout."""
+        storage = self._bound[0] if self._bound is not None else None
+        if storage is not None and storage.step == 0:
+            return self.refresh()
+        vers, addrs = self._param_tags()
+        if self._ver_tag != vers or self._addr_tag != (addrs, str(self.log_std.device)):
+            self.refresh()
 
     def _split_hidden16(self, nets, inputs, tag, planes=None):
         """As _split_hidden on two scaled fp16 planes per operand (mms_split_planes16_group / mms_linear_group_act_split16).  The
         kernel that splits a network's input also evaluates, per row, the scales of the hidden activations behind it from the
-        layers' bound chain."""
+        layers' bound chain.  Buffers per (tag, shapes), launch arguments per (buffers, input addresses): built once, then a call is a
+        handful of prebuilt ctypes launches."""
+        self._ensure_fresh()
         x0 = inputs[0]
         dev, M = x0.device, x0.shape[0]
-        L, idx, stream = _lib.for_device(dev)
+        mine = self._networks()
+        members = [next(j for j, n in enumerate(mine) if n and n[0] is net[0]) for net in nets]
+        fresh = self._h16 is None or self._h16["dev"] != dev
+        st = self._h16_state(dev)
+        if fresh:
+            self.refresh()
         G, nl = len(nets), len(nets[0])
-        key = (tag, "h", M, tuple(x.shape[1] for x in inputs), str(dev), G, tuple(l.out_features for l in nets[0]))
+        given = planes is not None and all(x.data_ptr() == x0.data_ptr() and x.shape == x0.shape for x in inputs)
+        ckey = (tag, "h", M, tuple((x.data_ptr(), x.shape[1], x.stride(0)) for x in inputs), tuple(members),
+                (planes[0].data_ptr(), float(planes[1])) if given else None)
+        if self._calls is None:
+            self._calls = {}
+        hit = self._calls.get(ckey)
+        if hit is None:
+            hit = self._build_calls16(st, members, inputs, tag, planes if given else None)
+            self._calls[ckey] = hit
+        calls, out = hit
+        stream = _lib.for_device(dev)[2]
+        for fn, args, what in calls:
+            _lib.check(fn(*args, stream), None, what, st["L"])
+        return out
+
+    def _build_calls16(self, st, members, inputs, tag, planes):
+        x0 = inputs[0]
+        dev, M = x0.device, x0.shape[0]
+        L, idx = st["L"], st["idx"]
+        recs = [st["recs"][g] for g in members]
+        G, nl = len(recs), len(recs[0])
+        key = (tag, "h", M, tuple(x.shape[1] for x in inputs), str(dev), tuple(members))
         if self._split_bufs is None:
             self._split_bufs = {}
         bufs = self._split_bufs.get(key)
         f32 = lambda *sh: torch.empty(*sh, device=dev)
+        u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
         if bufs is None:
-            u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
             bufs = {"x": [u8(self._h32_bytes(M, x.shape[1])) for x in inputs], "xs": [f32(M) for _ in range(G)], "xi": [f32(M) for _ in range(G)],
                     "cs": [f32(G, max(nl - 1, 1), M) for _ in range(G)], "ci": [f32(G, max(nl - 1, 1), M) for _ in range(G)],
-                    "h": [[u8(self._h32_bytes(M, l.out_features)) for _ in range(G)] for l in nets[0][:-1]],
-                    "out": [f32(M, nets[0][-1].out_features) for _ in range(G)], "chain": {}}
+                    "h": [[u8(self._h32_bytes(M, r["N"])) for _ in range(G)] for r in recs[0][:-1]],
+                    "out": [f32(M, recs[0][-1]["N"]) for _ in range(G)], "keep": []}
             self._split_bufs[key] = bufs
         arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        wpl = [[self._weight_planes16(l, L, idx, stream) for l in net] for net in nets]
         # distinct inputs: each is split once, with one bound chain per network it feeds
         src, users = [], []                    # src[g] = (index of the input's first user, chain slot)
         for g, x in enumerate(inputs):
@@ -195,55 +352,59 @@ class ActorCritic(nn.Module):
                 grp = next(u for u in users if u[0] == first)
                 src.append((first, len(grp)))
                 grp.append(g)
-        given = planes is not None and len(users) == 1          # the caller's planes of the one input every network reads
+        calls = []
+        x_planes = {}
         for grp in users:
             g0 = grp[0]
             x = inputs[g0]
             assert x.dtype == torch.float32 and x.stride(1) == 1
-            nch = len(grp) if nl > 1 else 0
-            chain = None
-            if nch:
-                ckey = tuple(wpl[g][li][3] for g in grp for li in range(nl - 1))
-                hit = bufs["chain"].get(g0)
-                if hit is None or hit[0] != ckey:
-                    hit = (ckey, torch.stack([torch.stack([wpl[g][li][2] for li in range(nl - 1)]) for g in grp]).contiguous())
-                    bufs["chain"][g0] = hit
-                chain = hit[1]
-            if given:
-                # rows bounded by 2^14 / scale (the engine clamps them to clip_obs <= that): constant scales, evaluated here with the
-                # kernel's own recurrence -- once per refresh of the weights
+            chain, Lh = self._chain(st, [members[g] for g in grp])
+            nch = len(grp) if Lh else 0
+            if planes is not None:
+                # rows bounded by 2^14 / scale (the engine clamps them to clip_obs <= that): constant scales from the kernels' own
+                # recurrence (mms_chain_scales16), re-evaluated by refresh(); the buffers belong to (networks, rows, scale)
                 pl, scale = planes
+                scale = float(scale)
                 assert pl.dtype == torch.uint8 and pl.numel() == self._h32_bytes(M, x.shape[1]) and pl.device == dev
-                ckey = (float(scale), None if chain is None else hit[0])
-                if bufs.get("given_key") != ckey:
-                    bufs["xi"][g0].fill_(1.0 / float(scale))
-                    if nch:
-                        bound = torch.full((nch,), 16384.0 / float(scale), device=dev)
-                        for li in range(nl - 1):
-                            bound = (chain[:, li, 0] * bound + chain[:, li, 1]) * 1.001
-                            sc = torch.exp2(14.0 - torch.frexp(bound)[1].float())
-                            bufs["cs"][g0][:nch, li] = sc[:, None]
-                            bufs["ci"][g0][:nch, li] = (1.0 / sc)[:, None]
-                    bufs["given_key"] = ckey
-                bufs["x_given"] = pl
+                gm = tuple(members[g] for g in grp)
+                gkey = (gm, M, scale)
+                if gkey not in st["given"]:
+                    # a subset of networks of an existing set with the same rows and scale (the critic alone, for `value`, beside the set of
+                    # actor + critic of `act`) shares that set's buffers: one refresh launch serves both
+                    host = next(((k, v) for k, v in st["given"].items() if k[1:] == (M, scale) and not v[3] and
+                                 any(k[0][j:j + len(gm)] == gm for j in range(len(k[0]) - len(gm) + 1))), None)
+                    if host is not None and nch:
+                        j = next(j for j in range(len(host[0][0]) - len(gm) + 1) if host[0][0][j:j + len(gm)] == gm)
+                        st["given"][gkey] = (host[1][0], host[1][1][j:j + len(gm)], host[1][2][j:j + len(gm)], True)
+                    else:
+                        xi = torch.full((M,), 1.0 / scale, device=dev)
+                        cs, ci = f32(max(nch, 1), max(Lh, 1), M), f32(max(nch, 1), max(Lh, 1), M)
+                        st["given"][gkey] = (xi, cs, ci, False)
+                        if nch:
+                            _lib.check(L.mms_chain_refresh16(idx, *self._chain_args(st, gm), 16384.0 / scale, M, ctypes.c_void_p(cs.data_ptr()),
+                                                             ctypes.c_void_p(ci.data_ptr()), _lib.for_device(dev)[2]), None, "mms_chain_refresh16", L)
+                xi, cs, ci, _ = st["given"][gkey]
+                x_planes[g0] = (pl, xi, cs, ci)
+                bufs["keep"].append(pl)
                 continue
-            bufs["given_key"] = None
-            _lib.check(L.mms_split_planes16_group(idx, 1, M, x.shape[1], x.stride(0), arr([x]), arr([bufs["x"][g0]]), arr([bufs["xs"][g0]]), arr([bufs["xi"][g0]]),
-                                                  nch, nl - 1 if nch else 0, arr([chain]) if nch else None, arr([bufs["cs"][g0]]) if nch else None,
-                                                  arr([bufs["ci"][g0]]) if nch else None, None, 0.0, stream), None, "mms_split_planes16_group", L)
-        cur = [bufs["x_given"] if given else bufs["x"][src[g][0]] for g in range(G)]
-        cur_inv = [bufs["xi"][src[g][0]] for g in range(G)]
+            x_planes[g0] = (bufs["x"][g0], bufs["xi"][g0], bufs["cs"][g0], bufs["ci"][g0])
+            calls.append((L.mms_split_planes16_group, (idx, 1, M, x.shape[1], x.stride(0), arr([x]), arr([bufs["x"][g0]]), arr([bufs["xs"][g0]]), arr([bufs["xi"][g0]]),
+                                                       nch, Lh if nch else 0, arr([chain]) if nch else None, arr([bufs["cs"][g0]]) if nch else None,
+                                                       arr([bufs["ci"][g0]]) if nch else None, None, 0.0), "mms_split_planes16_group"))
+            bufs["keep"].append(x)
+        cur = [x_planes[src[g][0]][0] for g in range(G)]
+        cur_inv = [x_planes[src[g][0]][1] for g in range(G)]
         for li in range(nl):
-            lins = [net[li] for net in nets]
             last = li == nl - 1
             out = bufs["out"] if last else bufs["h"][li]
-            ysc = None if last else arr([bufs["cs"][src[g][0]][src[g][1], li] for g in range(G)])
-            _lib.check(L.mms_linear_group_act_split16(idx, G, M, lins[0].out_features, lins[0].in_features, arr(cur), arr([wpl[g][li][0] for g in range(G)]),
-                                                      arr([l.bias.detach() for l in lins]), arr(out), arr(cur_inv), arr([wpl[g][li][1] for g in range(G)]), ysc,
-                                                      1, 0 if last else 1, None, None, None, None, None, 0, stream), None, "mms_linear_group_act_split16", L)
+            ysc = None if last else arr([x_planes[src[g][0]][2][src[g][1], li] for g in range(G)])
+            calls.append((L.mms_linear_group_act_split16, (idx, G, M, recs[0][li]["N"], recs[0][li]["K"], arr(cur), arr([recs[g][li]["planes"] for g in range(G)]),
+                                                           arr([recs[g][li]["lin"].bias for g in range(G)]), arr(out), arr(cur_inv),
+                                                           arr([recs[g][li]["inv"] for g in range(G)]), ysc, 1, 0 if last else 1, None, None, None, None, None, 0),
+                          "mms_linear_group_act_split16"))
             if not last:
-                cur, cur_inv = out, [bufs["ci"][src[g][0]][src[g][1], li] for g in range(G)]
-        return bufs["out"]
+                cur, cur_inv = out, [x_planes[src[g][0]][3][src[g][1], li] for g in range(G)]
+        return calls, bufs["out"]
 
     def _split_applies(self, M, lins, networks=2):
         """Shapes the split kernel takes (batch and widths multiples of 128) AND is worth taking: the widest layer must give each CU at
@@ -367,6 +528,20 @@ class ActorCritic(nn.Module):
         if self._counters is None or self._counters.numel() != N or self._counters.device != dev:
             self._counters = torch.zeros(N, dtype=torch.int64, device=dev)
         storage, actions_out = self._bound if self._bound is not None else (None, None)
+        # a bound rollout slot with both heads in the kernel (the rollout's hot path): the launch arguments of slot s are built once
+        ckey = None
+        if storage is not None and mean is None and value is None and hidden.is_contiguous() and (vhidden is None or vhidden.is_contiguous()):
+            la, lc = self.actor[-1], self.critic[-1]
+            ckey = (storage.actions.data_ptr(), storage.values.data_ptr(), storage.step, hidden.data_ptr(), None if vhidden is None else vhidden.data_ptr(),
+                    None if actions_out is None else actions_out.data_ptr(), N, la.weight.data_ptr(), la.bias.data_ptr(), lc.weight.data_ptr(),
+                    lc.bias.data_ptr(), self.log_std.data_ptr(), self._counters.data_ptr())
+            if self._sample_calls is None:
+                self._sample_calls = {}
+            hit = self._sample_calls.get(ckey)
+            if hit is not None:
+                args, ret = hit
+                _lib.check(L.mms_ppo_heads_act(*args, stream), None, "mms_ppo_heads_act", L)
+                return ret
         if storage is not None:
             s = storage.step
             act, logp, val = storage.actions[s], storage.actions_log_prob[s], storage.values[s]
@@ -387,11 +562,13 @@ class ActorCritic(nn.Module):
             hidden = hidden.contiguous()
             vlast = self.critic[-1]
             vh = None if vhidden is None else vhidden.contiguous()
-            _lib.check(L.mms_ppo_heads_act(idx, p(hidden), p(last.weight.detach()), p(last.bias.detach()), last.in_features, p(value), p(vh),
-                                           None if vh is None else p(vlast.weight.detach()), None if vh is None else p(vlast.bias.detach()),
-                                           0 if vh is None else vlast.in_features, p(log_std), self.seed, p(self._counters), self.row_offset, 1,
-                                           p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A, stream),
-                       None, "mms_ppo_heads_act", L)
+            args = (idx, p(hidden), p(last.weight.detach()), p(last.bias.detach()), last.in_features, p(value), p(vh),
+                    None if vh is None else p(vlast.weight.detach()), None if vh is None else p(vlast.bias.detach()),
+                    0 if vh is None else vlast.in_features, p(log_std), self.seed, p(self._counters), self.row_offset, 1,
+                    p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A)
+            _lib.check(L.mms_ppo_heads_act(*args, stream), None, "mms_ppo_heads_act", L)
+            if ckey is not None and self.log_std.dtype == torch.float32:
+                self._sample_calls[ckey] = (args, (act, logp.view(-1), val, mu, sigma))
         return act, logp.view(-1), val, mu, sigma
 
     def act(self, observations, states, obs_planes=None):

@@ -70,10 +70,14 @@ class RolloutStorage:
         T, N = self.num_transitions_per_env, self.num_envs
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         last_values = last_values.contiguous().view(-1).float()
+        if self.process_group is None:
+            # one rank: scan + normalisation in one launch (fixed summation order, nothing to zero; up to 64 K transitions)
+            _lib.check(L.mms_gae_ppo_normalized(idx, p(self.rewards), p(self.dones), p(self.values), p(last_values), p(self.returns),
+                                                p(self.advantages), p(self._stats), T, N, float(gamma), float(lam), stream), None, "mms_gae_ppo_normalized", L)
+            return
         _lib.check(L.mms_gae_ppo(idx, p(self.rewards), p(self.dones), p(self.values), p(last_values), p(self.returns),
                                  p(self.advantages), p(self._stats), T, N, float(gamma), float(lam), stream), None, "mms_gae_ppo", L)
-        if self.process_group is not None:
-            torch.distributed.all_reduce(self._stats, group=self.process_group)   # sum, sum of squares, count
+        torch.distributed.all_reduce(self._stats, group=self.process_group)       # sum, sum of squares, count
         _lib.check(L.mms_adv_normalize(idx, p(self.advantages), p(self._stats), T * N, stream), None, "mms_adv_normalize", L)
 
     def get_statistics(self):

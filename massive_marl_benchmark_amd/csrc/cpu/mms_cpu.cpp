@@ -294,6 +294,16 @@ MMS_API int mms_adv_normalize(int device, float* advantages, const double* stats
     for (int64_t i = 0; i < count; i++) advantages[i] = (advantages[i] - fm) * inv;
     return 0;
 }
+MMS_API int mms_gae_ppo_normalized(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
+                                   float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam, void*) {
+    if (cpu_only(device)) return 1;
+    if (!rewards || !dones || !values || !last_values || !returns || !advantages || !stats || T < 1 || N < 1) {
+        g_error = "mms_gae_ppo_normalized: bad arguments (null pointer, T < 1 or N < 1)";
+        return 1;
+    }
+    if (mms_gae_ppo(device, rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam, nullptr)) return 1;
+    return mms_adv_normalize(device, advantages, stats, (int64_t)T * N, nullptr);
+}
 MMS_API int mms_gae_marl(int device, const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int64_t N,
                          float gamma, float lam, int32_t use_norm, const float* norm_mean, const float* norm_var, void*) {
     if (cpu_only(device)) return 1;
@@ -639,6 +649,78 @@ MMS_API int mms_split_planes16_group(int device, int32_t groups, int64_t rows, i
                     chain_scale[g][((size_t)c * L + l) * rows + r] = s2;
                     chain_inv[g][((size_t)c * L + l) * rows + r] = i2;
                 }
+            }
+        }
+    }
+    return 0;
+}
+
+// The device-side refresh of the weights' planes and of the bound chain (include/mms.h).  l1 follows the kernel's summation order
+// (split16_planes_kernel: P lanes per row walk the row's 8-element pieces p = lane, lane + P, ...; xor butterfly over the lanes), so
+// that the bound -- and with it every hidden activation's power-of-two scale -- is the same number on both builds.
+MMS_API int mms_weight_planes16_group(int device, int32_t groups, const int64_t* N, const int32_t* K, const float* const* w, void* const* planes,
+                                      float* const* scale, float* const* inv, float* const* l1, void*) {
+    if (cpu_only(device)) return 1;
+    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_weight_planes16_group: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
+    if (!N || !K || !w || !planes || !scale || !inv) { g_error = "mms_weight_planes16_group: bad arguments (null array)"; return 1; }
+    for (int g = 0; g < groups; g++) {
+        if (N[g] < 0 || K[g] <= 0) { g_error = "mms_weight_planes16_group: bad shape in a group (N >= 0, K > 0)"; return 1; }
+        if (!w[g] || !planes[g] || !scale[g] || !inv[g]) { g_error = "mms_weight_planes16_group: null or misaligned pointer in a group (planes and inv 16-byte aligned)"; return 1; }
+    }
+    for (int g = 0; g < groups; g++) {
+        if (N[g] == 0) continue;
+        if (mms_split_planes16_group(device, 1, N[g], K[g], K[g], w + g, planes + g, scale + g, inv + g, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr)) return 1;
+        if (!l1 || !l1[g]) continue;
+        const int Kg = K[g], KC = (Kg + 31) / 32, pieces = KC * 4;
+        int P = 1;
+        while (P < pieces && P < 64) P <<= 1;
+#pragma omp parallel for schedule(static)
+        for (int64_t r = 0; r < N[g]; r++) {
+            float lane[64];
+            for (int sub = 0; sub < P; sub++) {
+                float a = 0.f;
+                for (int p = sub; p < pieces; p += P)
+                    for (int j = 0; j < 8; j++) { const int k = p * 8 + j; a += (k < Kg) ? fabsf(w[g][r * Kg + k]) : 0.f; }
+                lane[sub] = a;
+            }
+            for (int m = P >> 1; m >= 1; m >>= 1) {
+                float nxt[64];
+                for (int i = 0; i < P; i++) nxt[i] = lane[i] + lane[i ^ m];
+                for (int i = 0; i < P; i++) lane[i] = nxt[i];
+            }
+            l1[g][r] = lane[0];
+        }
+    }
+    return 0;
+}
+
+MMS_API int mms_chain_refresh16(int device, int32_t nchains, int32_t L, const float* const* l1, const float* const* bias, const int32_t* n, float* chain,
+                                float bound0, int64_t rows, float* chain_scale, float* chain_inv, void*) {
+    if (cpu_only(device)) return 1;
+    if (nchains < 1 || L < 1 || (int64_t)nchains * L > MMS_MAX_GROUPS || !l1 || !n || !chain || rows < 0 || (rows > 0 && (!chain_scale || !chain_inv || !(bound0 >= 0.f)))) {
+        g_error = "mms_chain_refresh16: bad arguments (nchains, L >= 1, nchains * L <= " + std::to_string(MMS_MAX_GROUPS) + "; rows > 0 needs chain_scale, chain_inv, bound0 >= 0)";
+        return 1;
+    }
+    for (int e = 0; e < nchains * L; e++)
+        if (!l1[e] || n[e] < 0) { g_error = "mms_chain_refresh16: null pointer or negative count in an entry"; return 1; }
+    for (int e = 0; e < nchains * L; e++) {
+        float m = 0.f, b = 0.f;
+        for (int i = 0; i < n[e]; i++) {
+            m = fmaxf(m, l1[e][i]);
+            if (bias && bias[e]) b = fmaxf(b, fabsf(bias[e][i]));
+        }
+        chain[2 * e] = m;
+        chain[2 * e + 1] = b;
+    }
+    for (int c = 0; c < nchains && rows > 0; c++) {
+        float bound = bound0;
+        for (int l = 0; l < L; l++) {
+            bound = (chain[((size_t)c * L + l) * 2] * bound + chain[((size_t)c * L + l) * 2 + 1]) * 1.001f;
+            float sc, iv;
+            pow2_scale(bound, sc, iv);
+            for (int64_t r = 0; r < rows; r++) {
+                chain_scale[((size_t)c * L + l) * rows + r] = sc;
+                chain_inv[((size_t)c * L + l) * rows + r] = iv;
             }
         }
     }

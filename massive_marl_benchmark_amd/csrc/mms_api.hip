@@ -18,6 +18,7 @@ namespace mms {
 hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream);
 hipError_t launch_gae_ppo(const float*, const uint8_t*, const float*, const float*, float*, float*, double*, int, int64_t, float, float, hipStream_t);
 hipError_t launch_adv_normalize(float*, const double*, int64_t, hipStream_t);
+hipError_t launch_gae_ppo_normalized(const float*, const uint8_t*, const float*, const float*, float*, float*, double*, int, int64_t, float, float, hipStream_t);
 hipError_t launch_gae_marl(const float*, const float*, const float*, float*, int, int64_t, float, float, int, const float*, const float*, hipStream_t);
 hipError_t launch_marl_views(const float*, float*, int64_t, int, int, int, hipStream_t);
 hipError_t launch_gae_marl_agents(const float*, const float*, const float*, float*, int, int64_t, int, float, float, int, const float*, const float*, hipStream_t);
@@ -426,6 +427,16 @@ __attribute__((visibility("default"))) int mms_gae_ppo(int device, const float* 
     MMS_FREE(mms::launch_gae_ppo(rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam, (hipStream_t)s));
     return 0;
 }
+__attribute__((visibility("default"))) int mms_gae_ppo_normalized(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values,
+                                                                  float* returns, float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam, void* s) {
+    MMS_DEV(device)
+    if (!rewards || !dones || !values || !last_values || !returns || !advantages || !stats || T < 1 || N < 1) {
+        g_create_error = "mms_gae_ppo_normalized: bad arguments (null pointer, T < 1 or N < 1)";
+        return 1;
+    }
+    MMS_FREE(mms::launch_gae_ppo_normalized(rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam, (hipStream_t)s));
+    return 0;
+}
 __attribute__((visibility("default"))) int mms_adv_normalize(int device, float* advantages, const double* stats, int64_t count, void* s) {
     MMS_DEV(device)
     MMS_FREE(mms::launch_adv_normalize(advantages, stats, count, (hipStream_t)s));
@@ -598,6 +609,50 @@ __attribute__((visibility("default"))) int mms_split_planes16_group(int device, 
     }
     a.rows = rows; a.K = K; a.x_pitch = x_pitch; a.nchains = nchains; a.L = nchains > 0 ? L : 0; a.eps = eps;
     MMS_FREE(mms::launch_split16_planes_group(a, groups, (hipStream_t)s));
+    return 0;
+}
+
+// The weights' side of the split16 layers, refreshed on the device after every parameter update: planes, row scales and row 1-norms of
+// `groups` weight matrices of ANY shapes in one launch ...
+__attribute__((visibility("default"))) int mms_weight_planes16_group(int device, int32_t groups, const int64_t* N, const int32_t* K, const float* const* w,
+                                                                     void* const* planes, float* const* scale, float* const* inv,
+                                                                     float* const* l1, void* s) {
+    MMS_DEV(device)
+    if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_weight_planes16_group: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
+    if (!N || !K || !w || !planes || !scale || !inv) { g_create_error = "mms_weight_planes16_group: bad arguments (null array)"; return 1; }
+    mms::Split16PlanesArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (N[g] < 0 || K[g] <= 0) { g_create_error = "mms_weight_planes16_group: bad shape in a group (N >= 0, K > 0)"; return 1; }
+        if (!w[g] || !planes[g] || !scale[g] || !inv[g] || (reinterpret_cast<uintptr_t>(planes[g]) & 15) != 0 || (reinterpret_cast<uintptr_t>(w[g]) & 3) != 0 ||
+            (reinterpret_cast<uintptr_t>(inv[g]) & 15) != 0) {
+            g_create_error = "mms_weight_planes16_group: null or misaligned pointer in a group (planes and inv 16-byte aligned)";
+            return 1;
+        }
+        a.x[g] = w[g]; a.planes[g] = planes[g]; a.scale[g] = scale[g]; a.inv[g] = inv[g];
+        a.l1[g] = l1 ? l1[g] : nullptr;
+        a.rows_g[g] = N[g]; a.K_g[g] = K[g];
+    }
+    a.per_group = 1;
+    MMS_FREE(mms::launch_split16_planes_group(a, groups, (hipStream_t)s));
+    return 0;
+}
+
+// ... and the bound chain (+ the scales of a constant-bound input) from them, one launch.
+__attribute__((visibility("default"))) int mms_chain_refresh16(int device, int32_t nchains, int32_t L, const float* const* l1, const float* const* bias,
+                                                               const int32_t* n, float* chain, float bound0, int64_t rows, float* chain_scale,
+                                                               float* chain_inv, void* s) {
+    MMS_DEV(device)
+    if (nchains < 1 || L < 1 || (int64_t)nchains * L > mms::kMaxGroups || !l1 || !n || !chain || rows < 0 || (rows > 0 && (!chain_scale || !chain_inv || !(bound0 >= 0.f)))) {
+        g_create_error = "mms_chain_refresh16: bad arguments (nchains, L >= 1, nchains * L <= " + std::to_string(mms::kMaxGroups) + "; rows > 0 needs chain_scale, chain_inv, bound0 >= 0)";
+        return 1;
+    }
+    mms::ChainRefreshArgs a = {};
+    for (int e = 0; e < nchains * L; e++) {
+        if (!l1[e] || n[e] < 0) { g_create_error = "mms_chain_refresh16: null pointer or negative count in an entry"; return 1; }
+        a.l1[e] = l1[e]; a.bias[e] = bias ? bias[e] : nullptr; a.n[e] = n[e];
+    }
+    a.chain = chain; a.nchains = nchains; a.L = L; a.bound0 = bound0; a.rows = rows; a.chain_scale = chain_scale; a.chain_inv = chain_inv;
+    MMS_FREE(mms::launch_chain_refresh16(a, (hipStream_t)s));
     return 0;
 }
 

@@ -161,13 +161,36 @@ struct Split16PlanesArgs {
     float* chain_scale[kMaxGroups];
     float* chain_inv[kMaxGroups];
     float* stat[kMaxGroups];                // optional: (mean, 1 / sqrt(var + eps)) per row, f32 [rows, 2]
+    float* l1[kMaxGroups];                  // optional: the row's 1-norm sum_k |x[r, k]|, f32 [rows] (a weight matrix: its layer's entry of the bound chain)
     int64_t rows;
     int K, x_pitch;
     int nchains, L;
     float eps;
+    // per_group != 0: matrices of DIFFERENT shapes in one launch (the weights of all hidden layers at a refresh): group g is
+    // [rows_g[g], K_g[g]], dense (pitch K_g[g]); rows / K / x_pitch above are then unused and the chain / stat outputs are not available
+    int per_group;
+    int64_t rows_g[kMaxGroups];
+    int K_g[kMaxGroups];
+};
+
+// The bound chain refreshed on the device (no atomics, no host synchronisation: graph-capturable): entry e = c * L + l of the chain is
+// (max_i l1[e][i], max_i |bias[e][i]|), i < n[e] -- layer l of chain c's (mult, add) pair from the row 1-norms its weight split left
+// (Split16PlanesArgs::l1) and its bias; written to chain[e * 2 + {0, 1}] by block 0.  rows > 0: every block also evaluates the chain's
+// scales for rows whose input bound is the constant bound0 (chain_scale / chain_inv [nchains, L, rows]).
+struct ChainRefreshArgs {
+    const float* l1[kMaxGroups];
+    const float* bias[kMaxGroups];
+    int n[kMaxGroups];
+    float* chain;
+    int nchains, L;
+    float bound0;
+    int64_t rows;
+    float* chain_scale;
+    float* chain_inv;
 };
 
 hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, hipStream_t s);
+hipError_t launch_chain_refresh16(const ChainRefreshArgs& a, hipStream_t s);
 hipError_t launch_linear_split16(const Split16LinearArgs& a, int groups, hipStream_t s);
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
 hipError_t launch_row_stats_chan(const RowStatsArgs& a, int groups, hipStream_t s);

@@ -15,8 +15,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include "mms_lane.h"
 #include "rollout_lane.h"
+
+#ifndef MMS_HEAD_RT_DEFAULT
+#define MMS_HEAD_RT_DEFAULT 1
+#endif
 
 namespace mms {
 
@@ -46,6 +52,36 @@ __global__ void __launch_bounds__(256) gae_ppo_kernel(const float* __restrict__ 
         atomicAdd(&stats[1], b);
         if (blockIdx.x == 0) stats[2] = (double)T * (double)N;
     }
+}
+
+// Both steps in ONE launch for rollouts of at most 64 K transitions on one rank (TenAnt 4096 envs x 8 steps = 32 K): a single
+// 1024-thread block scans its columns, reduces the advantage statistics in a fixed order (per-thread, wave butterfly, wave order:
+// deterministic, no atomics, nothing to zero beforehand -- the two-launch form pays a 24-byte memset that the runtime turns into two
+// fill kernels, ~9.5 us, and a second launch) and normalises what it wrote.  stats receives {sum, sum of squares, count} as well.
+__global__ void __launch_bounds__(1024) gae_ppo_norm_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ dones,
+                                                            const float* __restrict__ values, const float* __restrict__ last_values,
+                                                            float* __restrict__ returns, float* __restrict__ advantages,
+                                                            double* __restrict__ stats, int T, int64_t N, float gamma, float lam) {
+    __shared__ double s_sum[16], s_sq[16], s_tot[3];
+    double lsum = 0.0, lsq = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 1024)
+        gae_ppo_column(rewards, dones, values, last_values, returns, advantages, T, N, i, gamma, lam, lsum, lsq);
+    lsum = wave_sum(lsum);
+    lsq = wave_sum(lsq);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_sum[wave] = lsum; s_sq[wave] = lsq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < 16; w++) { a += s_sum[w]; b += s_sq[w]; }
+        s_tot[0] = a; s_tot[1] = b; s_tot[2] = (double)T * (double)N;
+        stats[0] = a; stats[1] = b; stats[2] = s_tot[2];
+    }
+    __syncthreads();
+    float fm, inv;
+    adv_norm_params(s_tot, fm, inv);
+    for (int64_t i = threadIdx.x; i < N; i += 1024)          // (each thread re-reads only what it stored itself)
+        for (int t = 0; t < T; t++) advantages[t * N + i] = (advantages[t * N + i] - fm) * inv;
 }
 
 // advantages := (advantages - mean) / (std + 1e-8), std unbiased (torch.std default)
@@ -135,32 +171,41 @@ __global__ void __launch_bounds__(256) ppo_act_kernel(const float* __restrict__ 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // NCT = number of 16-column tiles (compile time: the accumulators must be plain registers), A <= 16 NCT.
 // Rows past N and columns past A are computed from clamped (valid) addresses and never read back.
-template <int NCT, int WAVES>
+// RT = 16-row tiles per block (the block's waves still split K): with RT = 2 the head's weight fragments feed two row tiles, i.e. the
+// launch reads the 164 KB of head weights once per 32 rows instead of once per 16 (L2 -> CU traffic 42 -> 21 MB at 4096 rows) in half
+// as many blocks.
+template <int NCT, int WAVES, int RT>
 __global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* __restrict__ hidden, const float* __restrict__ weight,
                                                            const float* __restrict__ bias, int H, const float* __restrict__ value,
                                                            const float* __restrict__ vhidden, const float* __restrict__ vweight,
                                                            const float* __restrict__ vbias, int VH,
                                                            const float* __restrict__ log_std, uint64_t seed, int64_t* __restrict__ counters,
                                                            int64_t row_offset, int ref_scale, PpoActOut o, int64_t N, int A) {
-    extern __shared__ __attribute__((aligned(16))) float s_part[];      // [WAVES][16 rows][AP], then [16][AP] means
-    constexpr int AP = NCT * 16;
+    extern __shared__ __attribute__((aligned(16))) float s_part[];      // [WAVES][16 RT rows][AP], then [16 RT][AP] means
+    constexpr int AP = NCT * 16, ROWS = 16 * RT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * 16;
-    const int64_t row_a = r0 + i < N ? r0 + i : N - 1;
-    const float* hrow = hidden + row_a * (int64_t)H + 4 * g;
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+    const float* hrow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        const int64_t row_a = r0 + 16 * rt + i < N ? r0 + 16 * rt + i : N - 1;
+        hrow[rt] = hidden + row_a * (int64_t)H + 4 * g;
+    }
     const float* wrow[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ct++) {
         const int j = ct * 16 + i;
         wrow[ct] = weight + (int64_t)(j < A ? j : A - 1) * H + 4 * g;
     }
-    f32x4 acc[NCT];
+    f32x4 acc[RT][NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     // The critic's last layer (module.py:49: nn.Linear(hidden, 1)) for the rows this wave samples below: one dot product per row,
     // evaluated here so that its loads travel with the actor head's operands instead of costing a round trip after the barriers.
-    constexpr int RPW = 16 / WAVES;                                          // rows sampled per wave (WAVES in 1, 2, 4, 8)
+    constexpr int RPW = ROWS / WAVES;                                        // rows sampled per wave (WAVES in 1, 2, 4, 8)
     float v_rows[RPW];
 #pragma unroll
     for (int q = 0; q < RPW; q++) {
@@ -180,42 +225,47 @@ __global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* _
     }
     const int kq = H / WAVES;
     const int kbeg = wave * kq;
-    // 64 k per trip (the launcher picks WAVES so that H / WAVES is a multiple of 64): the 4 x (1 + NCT) float4 loads of a
-    // trip are issued together, then its 16 NCT MFMAs
+    // 64 k per trip (the launcher picks WAVES so that H / WAVES is a multiple of 64): the 4 x (RT + NCT) float4 loads of a
+    // trip are issued together, then its 16 RT NCT MFMAs
     for (int kc = kbeg; kc < kbeg + kq; kc += 64) {
-        float4 a[4], b[4][NCT];
+        float4 a[RT][4], b[4][NCT];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            a[u] = *reinterpret_cast<const float4*>(hrow + kc + 16 * u);
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) a[rt][u] = *reinterpret_cast<const float4*>(hrow[rt] + kc + 16 * u);
 #pragma unroll
             for (int ct = 0; ct < NCT; ct++) b[u][ct] = *reinterpret_cast<const float4*>(wrow[ct] + kc + 16 * u);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u][ct].x, acc[ct], 0, 0, 0);
+            for (int u = 0; u < 4; u++) {
 #pragma unroll
-            for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u][ct].y, acc[ct], 0, 0, 0);
+                for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][u].x, b[u][ct].x, acc[rt][ct], 0, 0, 0);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u][ct].z, acc[ct], 0, 0, 0);
+                for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][u].y, b[u][ct].y, acc[rt][ct], 0, 0, 0);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u][ct].w, acc[ct], 0, 0, 0);
-        }
+                for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][u].z, b[u][ct].z, acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][u].w, b[u][ct].w, acc[rt][ct], 0, 0, 0);
+            }
     }
     // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
-    float* mine = s_part + (size_t)wave * 16 * AP;
+    float* mine = s_part + (size_t)wave * ROWS * AP;
 #pragma unroll
-    for (int ct = 0; ct < NCT; ct++) {
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) mine[(4 * g + r) * AP + ct * 16 + i] = acc[ct][r];
-    }
+        for (int ct = 0; ct < NCT; ct++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) mine[(16 * rt + 4 * g + r) * AP + ct * 16 + i] = acc[rt][ct][r];
+        }
     __syncthreads();
-    float* s_mean = s_part + (size_t)WAVES * 16 * AP;
-    for (int e = threadIdx.x; e < 16 * AP; e += 64 * WAVES) {
+    float* s_mean = s_part + (size_t)WAVES * ROWS * AP;
+    for (int e = threadIdx.x; e < ROWS * AP; e += 64 * WAVES) {
         const int j = e % AP;
         float sum = s_part[e];
 #pragma unroll
-        for (int w = 1; w < WAVES; w++) sum += s_part[w * 16 * AP + e];      // wave order
+        for (int w = 1; w < WAVES; w++) sum += s_part[w * ROWS * AP + e];    // wave order
         s_mean[e] = sum + bias[j < A ? j : 0];
     }
     __syncthreads();
@@ -228,6 +278,7 @@ __global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* _
     }
 }
 
+hipError_t launch_adv_normalize(float* advantages, const double* stats, int64_t count, hipStream_t s);
 static int grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -239,6 +290,15 @@ hipError_t launch_gae_ppo(const float* rewards, const uint8_t* dones, const floa
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gae_ppo_kernel, dim3(grid_for(N)), dim3(256), 0, s, rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam);
     return hipGetLastError();
+}
+hipError_t launch_gae_ppo_normalized(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
+                                     float* advantages, double* stats, int T, int64_t N, float gamma, float lam, hipStream_t s) {
+    if ((int64_t)T * N <= 65536) {
+        hipLaunchKernelGGL(gae_ppo_norm_kernel, dim3(1), dim3(1024), 0, s, rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam);
+        return hipGetLastError();
+    }
+    if (hipError_t e = launch_gae_ppo(rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam, s); e != hipSuccess) return e;
+    return launch_adv_normalize(advantages, stats, (int64_t)T * N, s);
 }
 hipError_t launch_adv_normalize(float* advantages, const double* stats, int64_t count, hipStream_t s) {
     hipLaunchKernelGGL(adv_normalize_kernel, dim3(grid_for(count)), dim3(256), 0, s, advantages, stats, count);
@@ -270,12 +330,34 @@ hipError_t launch_ppo_head_act(const float* hidden, const float* weight, const f
     PpoActOut o{actions_out, act_slot, logp_slot, value_slot, mu_slot, sigma_slot};
     const int nct = (A + 15) / 16;
     int waves = (H % 512 == 0) ? 8 : (H % 256 == 0) ? 4 : (H % 128 == 0) ? 2 : 1;            // H / waves is a multiple of 64
-    if ((size_t)(waves + 1) * 16 * (nct * 16) * sizeof(float) > 64 * 1024) waves = 4;        // (8 waves x 8 column tiles: 73.7 KB) stay within the default 64 KB
-    const size_t lds = (size_t)(waves + 1) * 16 * (nct * 16) * sizeof(float);
-    const dim3 grid((unsigned)((N + 15) / 16));
+    // 32 rows per block (MMS_HEAD_RT=2) when eight waves split K: see the kernel's note; the default is what measured faster
+    static const int rt_env = getenv("MMS_HEAD_RT") ? atoi(getenv("MMS_HEAD_RT")) : MMS_HEAD_RT_DEFAULT;
+    const int rt = (waves == 8 && rt_env == 2 && N >= 32) ? 2 : 1;
+    size_t lds = (size_t)(waves + 1) * 16 * rt * (nct * 16) * sizeof(float);
+    if (rt == 1 && lds > 64 * 1024) {                                                        // (8 waves x 8 column tiles: 73.7 KB) stay within the default 64 KB
+        waves = 4;
+        lds = (size_t)(waves + 1) * 16 * (nct * 16) * sizeof(float);
+    }
+    const dim3 grid((unsigned)((N + 16 * rt - 1) / (16 * rt)));
 #define MMS_HEAD_W(NCT, W)                                                                                                                        \
-    hipLaunchKernelGGL((ppo_head_act_kernel<NCT, W>), grid, dim3(64 * W), lds, s, hidden, weight, bias, H, value, vhidden, vweight, vbias, VH, \
+    hipLaunchKernelGGL((ppo_head_act_kernel<NCT, W, 1>), grid, dim3(64 * W), lds, s, hidden, weight, bias, H, value, vhidden, vweight, vbias, VH, \
                        log_std, seed, counters, row_offset, ref_scale, o, N, A)
+#define MMS_HEAD2(NCT)                                                                                                                             \
+    case NCT: {                                                                                                                                    \
+        auto kern = ppo_head_act_kernel<NCT, 8, 2>;                                                                                                \
+        if (lds > 64 * 1024) {                                                                                                                     \
+            static bool done[64] = {};                                                                                                             \
+            int dev = 0;                                                                                                                           \
+            if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;                                                                      \
+            if (dev < 0 || dev >= 64 || !done[dev]) {                                                                                              \
+                if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e; \
+                if (dev >= 0 && dev < 64) done[dev] = true;                                                                                        \
+            }                                                                                                                                      \
+        }                                                                                                                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, hidden, weight, bias, H, value, vhidden, vweight, vbias, VH, log_std, seed, counters,    \
+                           row_offset, ref_scale, o, N, A);                                                                                        \
+        break;                                                                                                                                     \
+    }
 #define MMS_HEAD(NCT)                                                                                                                              \
     case NCT:                                                                                                                                      \
         if (waves == 8) MMS_HEAD_W(NCT, 8);                                                                                                        \
@@ -283,11 +365,19 @@ hipError_t launch_ppo_head_act(const float* hidden, const float* weight, const f
         else if (waves == 2) MMS_HEAD_W(NCT, 2);                                                                                                   \
         else MMS_HEAD_W(NCT, 1);                                                                                                                   \
         break;
+    if (rt == 2) {
+        switch (nct) {
+            MMS_HEAD2(1) MMS_HEAD2(2) MMS_HEAD2(3) MMS_HEAD2(4) MMS_HEAD2(5) MMS_HEAD2(6) MMS_HEAD2(7) MMS_HEAD2(8)
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (nct) {
         MMS_HEAD(1) MMS_HEAD(2) MMS_HEAD(3) MMS_HEAD(4) MMS_HEAD(5) MMS_HEAD(6) MMS_HEAD(7) MMS_HEAD(8)
         default: return hipErrorInvalidValue;
     }
 #undef MMS_HEAD
+#undef MMS_HEAD2
 #undef MMS_HEAD_W
     return hipGetLastError();
 }

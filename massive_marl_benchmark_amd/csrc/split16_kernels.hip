@@ -64,12 +64,22 @@ __global__ void __launch_bounds__(256) split16_planes_kernel(Split16PlanesArgs a
     const float* __restrict__ x = a.x[g];
     uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(a.planes[g]);
     const int lane = threadIdx.x & 63;
+    int K = a.K, pitch = a.x_pitch;
+    int64_t rows = a.rows;
+    if (a.per_group) {                                                  // this group's own shape (uniform per block)
+        K = a.K_g[g];
+        pitch = K;
+        rows = a.rows_g[g];
+        KC = (K + 31) / 32;
+        P = 1;
+        while (P < KC * 4 && P < 64) P <<= 1;
+        if (rows == 0) return;
+    }
     const int sub = lane & (P - 1), rpw = 64 / P;
     const int64_t row_raw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / P;
-    const bool live = row_raw < a.rows;
-    const int64_t row = live ? row_raw : a.rows - 1;                    // (idle lanes stay in the shuffles, on a valid row)
-    const int K = a.K;
-    const float* src = x + row * (int64_t)a.x_pitch;
+    const bool live = row_raw < rows;
+    const int64_t row = live ? row_raw : rows - 1;                      // (idle lanes stay in the shuffles, on a valid row)
+    const float* src = x + row * (int64_t)pitch;
     const int pieces = KC * 4;                                          // 8-element pieces of the row
     auto load8 = [&](int p, float* v) {
         const int k0 = p * 8;
@@ -81,16 +91,17 @@ __global__ void __launch_bounds__(256) split16_planes_kernel(Split16PlanesArgs a
             for (int j = 0; j < 8; j++) v[j] = (k0 + j < K) ? src[k0 + j] : 0.f;
         }
     };
-    float big = 0.f, sum = 0.f;
+    float big = 0.f, sum = 0.f, asum = 0.f;
     for (int p = sub; p < pieces; p += P) {
         float v[8];
         load8(p, v);
 #pragma unroll
-        for (int j = 0; j < 8; j++) { big = fmaxf(big, fabsf(v[j])); sum += v[j]; }
+        for (int j = 0; j < 8; j++) { big = fmaxf(big, fabsf(v[j])); sum += v[j]; asum += fabsf(v[j]); }
     }
     for (int m = P >> 1; m >= 1; m >>= 1) {
         big = fmaxf(big, __shfl_xor(big, m, 64));
         sum += __shfl_xor(sum, m, 64);
+        asum += __shfl_xor(asum, m, 64);
     }
     const float mean = sum / (float)K;
     float scale, inv;
@@ -120,6 +131,7 @@ __global__ void __launch_bounds__(256) split16_planes_kernel(Split16PlanesArgs a
         if (a.scale[g]) a.scale[g][row] = scale;
         if (a.inv[g]) a.inv[g][row] = inv;
         if (a.stat[g]) reinterpret_cast<float2*>(a.stat[g])[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)K + a.eps));
+        if (a.l1[g]) a.l1[g][row] = asum;
     }
     // the scales of the layers behind this input: one chain per lane of the row
     if (live)
@@ -130,14 +142,34 @@ __global__ void __launch_bounds__(256) split16_planes_kernel(Split16PlanesArgs a
                 bound = (ch[2 * l] * bound + ch[2 * l + 1]) * 1.001f;   // (rounding of the bound itself; 2^14 leaves a factor 4 besides)
                 float sc, iv;
                 pow2_scale(bound, sc, iv);
-                a.chain_scale[g][((size_t)c * a.L + l) * a.rows + row] = sc;
-                a.chain_inv[g][((size_t)c * a.L + l) * a.rows + row] = iv;
+                a.chain_scale[g][((size_t)c * a.L + l) * rows + row] = sc;
+                a.chain_inv[g][((size_t)c * a.L + l) * rows + row] = iv;
             }
         }
 }
 
 hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, hipStream_t s) {
-    if (a.rows == 0 || groups == 0) return hipSuccess;
+    if (groups == 0) return hipSuccess;
+    if (a.per_group) {
+        // matrices of different shapes: dense rows (16-byte aligned when K is a multiple of 4), the grid sized for the group with the
+        // most blocks; the other groups' surplus blocks redo their last row without storing
+        bool aligned = true;
+        unsigned blocks = 0;
+        for (int g = 0; g < groups; g++) {
+            aligned = aligned && (a.K_g[g] % 4) == 0 && (reinterpret_cast<uintptr_t>(a.x[g]) & 15) == 0;
+            const int KCg = (a.K_g[g] + 31) / 32;
+            int Pg = 1;
+            while (Pg < KCg * 4 && Pg < 64) Pg <<= 1;
+            const int64_t rpb = 4 * (64 / Pg);
+            const unsigned need = (unsigned)((a.rows_g[g] + rpb - 1) / rpb);
+            blocks = need > blocks ? need : blocks;
+        }
+        if (blocks == 0) return hipSuccess;
+        if (aligned) hipLaunchKernelGGL(split16_planes_kernel<true>, dim3(blocks, groups), dim3(256), 0, s, a, 0, 1);
+        else hipLaunchKernelGGL(split16_planes_kernel<false>, dim3(blocks, groups), dim3(256), 0, s, a, 0, 1);
+        return hipGetLastError();
+    }
+    if (a.rows == 0) return hipSuccess;
     const int KC = (a.K + 31) / 32;
     bool aligned = (a.x_pitch % 4) == 0;
     for (int g = 0; g < groups; g++) aligned = aligned && (reinterpret_cast<uintptr_t>(a.x[g]) & 15) == 0;
@@ -147,6 +179,55 @@ hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, h
     const dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block), groups);
     if (aligned) hipLaunchKernelGGL(split16_planes_kernel<true>, grid, dim3(256), 0, s, a, KC, P);
     else hipLaunchKernelGGL(split16_planes_kernel<false>, grid, dim3(256), 0, s, a, KC, P);
+    return hipGetLastError();
+}
+
+// ---- the bound chain, refreshed on the device ----------------------------------------------------------------------------------
+// Entry e = c L + l of the chain = (largest weight-row 1-norm, largest |bias|) of layer l of chain c, from the row norms the weight
+// split left: every block reduces all entries (a few thousand floats: cheaper than a second launch and a dependency), block 0 stores
+// them; then the chain's scales for rows whose input bound is a CONSTANT (observation rows clamped to clip_obs, whose planes the step
+// kernel writes) -- the recurrence of split16_planes_kernel with b_0 = bound0, the same value for every row.
+__global__ void __launch_bounds__(256) chain_refresh16_kernel(ChainRefreshArgs a) {
+    __shared__ float s_part[2][4];
+    __shared__ float s_chain[2 * kMaxGroups];
+    const int E = a.nchains * a.L;
+    for (int e = 0; e < E; e++) {
+        float m = 0.f, b = 0.f;
+        for (int i = threadIdx.x; i < a.n[e]; i += 256) {
+            m = fmaxf(m, a.l1[e][i]);
+            if (a.bias[e]) b = fmaxf(b, fabsf(a.bias[e][i]));
+        }
+        for (int k = 32; k >= 1; k >>= 1) {
+            m = fmaxf(m, __shfl_xor(m, k, 64));
+            b = fmaxf(b, __shfl_xor(b, k, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { s_part[0][threadIdx.x >> 6] = m; s_part[1][threadIdx.x >> 6] = b; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_chain[2 * e] = fmaxf(fmaxf(s_part[0][0], s_part[0][1]), fmaxf(s_part[0][2], s_part[0][3]));
+            s_chain[2 * e + 1] = fmaxf(fmaxf(s_part[1][0], s_part[1][1]), fmaxf(s_part[1][2], s_part[1][3]));
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * E) a.chain[threadIdx.x] = s_chain[threadIdx.x];
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.rows) return;
+    for (int c = 0; c < a.nchains; c++) {
+        float bound = a.bound0;
+        for (int l = 0; l < a.L; l++) {
+            bound = (s_chain[2 * (c * a.L + l)] * bound + s_chain[2 * (c * a.L + l) + 1]) * 1.001f;
+            float sc, iv;
+            pow2_scale(bound, sc, iv);
+            a.chain_scale[((size_t)c * a.L + l) * a.rows + row] = sc;
+            a.chain_inv[((size_t)c * a.L + l) * a.rows + row] = iv;
+        }
+    }
+}
+
+hipError_t launch_chain_refresh16(const ChainRefreshArgs& a, hipStream_t s) {
+    if (a.nchains * a.L == 0) return hipSuccess;
+    const unsigned blocks = a.rows > 0 ? (unsigned)((a.rows + 255) / 256) : 1u;
+    hipLaunchKernelGGL(chain_refresh16_kernel, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -498,9 +579,15 @@ hipError_t launch_linear_split16(const Split16LinearArgs& a, int groups, hipStre
     if (a.M == 0 || a.N == 0 || groups == 0) return hipSuccess;
     int cus = 256;
     {
+        static int cached[64] = {};                                     // (hipGetDeviceProperties per launch is host time an eager rollout step pays)
         int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (cached[dev] == 0) {
+                int n = 0;
+                cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+            }
+            cus = cached[dev];
+        }
     }
     static const int force_mt = getenv("MMS_SPLIT_MT") ? atoi(getenv("MMS_SPLIT_MT")) : 0;
     const int64_t tiles256 = (a.M % 256 == 0) ? (int64_t)groups * (a.M / 256) * (a.N / 128) : 0;

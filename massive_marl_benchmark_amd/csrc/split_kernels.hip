@@ -440,9 +440,15 @@ hipError_t launch_linear_split(const SplitLinearArgs& a, int groups, hipStream_t
     if (a.M == 0 || a.N == 0 || groups == 0) return hipSuccess;
     int cus = 256;
     {
+        static int cached[64] = {};
         int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (cached[dev] == 0) {
+                int n = 0;
+                cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+            }
+            cus = cached[dev];
+        }
     }
     static const int force_mt = getenv("MMS_SPLIT_MT") ? atoi(getenv("MMS_SPLIT_MT")) : 0;
     const int64_t tiles256 = (a.M % 256 == 0) ? (int64_t)groups * (a.M / 256) * (a.N / 128) : 0;

@@ -16,7 +16,7 @@ import ctypes
 import math
 import xml.etree.ElementTree as ET
 
-MMS_ABI_VERSION = 3
+MMS_ABI_VERSION = 4
 TASK_IDS = {"TenAnt": 0, "OneAnt": 1, "MultiIngenuity": 2, "MultiAntCircle": 3}
 
 

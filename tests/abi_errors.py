@@ -116,9 +116,22 @@ def check_abi_error_paths(L, device):
     fails(L.mms_linear_group_act_split16(device, 1, 128, 128, 32, one, one, one, one, one, one, None, 1, 1, None, None, None, None, None, 0, None), contains="y_scale")
     fails(L.mms_linear_group_act_split16(device, 1, 128, 128, 32, one, one, one, one, None, one, None, 1, 0, None, None, None, None, None, 0, None), contains="x_inv")
     fails(L.mms_linear_group_act_split16(device, 1, 128, 128, 32, one, one, one, one, one, one, None, 1, 2, None, None, None, None, None, 0, None), contains="out_mode 2")
+    n8, k8 = (ctypes.c_int64 * 1)(8), (ctypes.c_int32 * 1)(8)
+    fails(L.mms_weight_planes16_group(device, 0, n8, k8, one, one, one, one, None, None), contains="groups")
+    fails(L.mms_weight_planes16_group(device, 1, n8, k8, one, one, (vp * 1)(None), one, None, None), contains="null")
+    fails(L.mms_weight_planes16_group(device, 1, n8, (ctypes.c_int32 * 1)(0), one, one, one, one, None, None), contains="shape")
+    fails(L.mms_weight_planes16_group(device, 1, None, k8, one, one, one, one, None, None), contains="null array")
+    c8 = (ctypes.c_int32 * 1)(8)
+    fails(L.mms_chain_refresh16(device, 0, 1, one, None, c8, zp, 0.0, 0, None, None, None), contains="nchains")
+    fails(L.mms_chain_refresh16(device, 8, 8, one, None, c8, zp, 0.0, 0, None, None, None), contains="nchains")
+    fails(L.mms_chain_refresh16(device, 1, 1, one, None, (ctypes.c_int32 * 1)(-1), zp, 0.0, 0, None, None, None), contains="negative")
+    fails(L.mms_chain_refresh16(device, 1, 1, one, None, c8, zp, 1.0, 8, None, zp, None), contains="chain_scale")
+    fails(L.mms_chain_refresh16(device, 1, 1, one, None, c8, zp, -1.0, 8, zp, zp, None), contains="bound0")
     fails(L.mms_layernorm_group(device, 0, 8, 8, 8, 8, one, one, one, one, 1e-5, None), contains="groups")
     fails(L.mms_row_stats_group(device, 1, 8, 0, 8, one, one, 1e-5, None))
     fails(L.mms_marl_heads_act(device, 1, 8, 8, one, one, one, one, one, (ctypes.c_int32 * 1)(17), None, one, None, None, None, 0, 0, 1e-5, None))
+    fails(L.mms_gae_ppo_normalized(device, zp, zp, zp, zp, zp, zp, zp, 0, 1, 0.9, 0.9, None), contains="T < 1")
+    fails(L.mms_gae_ppo_normalized(device, zp, zp, zp, None, zp, zp, zp, 1, 1, 0.9, 0.9, None), contains="null")
     other = 0 if device < 0 else -1
     fails(L.mms_gae_ppo(other, zp, zp, zp, zp, zp, zp, zp, 1, 1, 0.9, 0.9, None))       # the other library's device
     return n_checked[0]

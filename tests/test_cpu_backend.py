@@ -465,3 +465,11 @@ def test_reference_learners_drop_in_unchanged(tmp_path):
     assert text.count(": ok") == 13 and "GroupedPolicyInference as Runner.collect: ok" in text
     for learner, n in (("PPO.run", 2), ("mappo, unmodified", 3), ("happo, unmodified", 2), ("hatrpo, unmodified", 2), ("DDPG.run", 2), ("TD3.run", 2)):
         assert text.count(learner) == n, (learner, text)
+
+
+def test_refresh_entry_points_and_module_refresh_on_cpu_build():
+    """The device-side refresh of the f16x2 layers' weight planes / bound chain (mms_weight_planes16_group, mms_layer_bounds16,
+    mms_chain_scales16) and ActorCritic.refresh() on the CPU build: tests/refresh_check.py (the HIP build runs the same list)."""
+    import refresh_check
+    refresh_check.check_refresh_entry_points("cpu")
+    assert refresh_check.check_module_refresh("cpu") > 1e-3

@@ -11,7 +11,7 @@ f = sorted(glob.glob(R + "/gpurun_out/trace_gaps/*/*kernel_trace.csv"))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # find the last 3 occurrences of the GAE kernel and print the span between the last two
-idx = [i for i, r in enumerate(rows) if "gae_ppo_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "gae_ppo" in r["Kernel_Name"]]
 # the tightest rollout (graph replay) whose layers are the default kernel
 best = None
 for a, b in zip(idx[:-1], idx[1:]):
