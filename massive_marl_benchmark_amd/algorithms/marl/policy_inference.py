@@ -21,9 +21,13 @@ step for TenAnt.  The networks are independent and of the same shape, so here ev
 attributes: `.base.feature_norm`, `.base.mlp.fc1`, `.base.mlp.fc2`, `.act.action_out.{fc_mean, log_std, std_x_coef, std_y_coef}`,
 `.v_out`; any number of agents: more than sixteen run as chunks of sixteen).  Biases, LayerNorm affines and head weights are read in
 place; DERIVED copies exist of the zero-padded first actor weights (46 -> 48 columns), the folded weights `W diag(gamma)` with their
-`s` / `c` vectors, and the action standard deviations -- `refresh()` rebuilds them, and every inference call checks the parameters'
-version counters (an in-place optimizer step moves them) and refreshes by itself when they have changed, so a stale network is never run.  Recurrent policies (use_recurrent_policy / use_naive_recurrent_policy) and
-non-Box action spaces are not covered: the constructor raises, nothing falls back silently.
+`s` / `c` vectors, their operand planes, and the action standard deviations -- `refresh()` rebuilds them.  WHEN it runs by itself:
+(1) at step 0 of every rollout in both collect forms (`collect(buffers, 0)`, `collect_into(shared)` with `shared.step == 0`),
+unconditionally -- the trainers update between rollouts, and the reference's HATRPO does it through `params.data.copy_(...)`
+(agents/algorithms/marl/hatrpo_trainer.py:122), which moves NO version counter; (2) in every other inference call when a parameter's
+version counter or address has moved (an in-place optimizer step moves them).  What it cannot see: a write through `.data` outside a
+collect loop -- call `refresh()` after it (tests/test_marl_policy.py pins all three).  Recurrent policies
+(use_recurrent_policy / use_naive_recurrent_policy) and non-Box action spaces are not covered: the constructor raises, nothing falls back silently.
 
 The noise stream is this build's counter-based generator (seed + agent, global env row, per-row draw counter), as in
 rl/ppo/module.py: the sampled actions differ from torch's draw for the same torch seed, their distribution and the returned
@@ -545,11 +549,17 @@ class GroupedPolicyInference:
         written straight into `shared.actions[step]`, `shared.action_log_probs[step]`, `shared.value_preds[step]`.  Returns the
         [N, agents, act_dim] action slot (what `shared.env_step` takes)."""
         s, n = shared.step, self.n
+        if s == 0 and self.refresh_every_rollout:
+            self.refresh()                                  # the trainers updated in between, possibly through .data (no version counter moves)
         obs, sobs = shared.obs[s], shared.share_obs[s]
         out = ([shared.value_preds[s][:, k:k + 1] for k in range(n)], [shared.actions[s][:, k] for k in range(n)],
                [shared.action_log_probs[s][:, k] for k in range(n)])
         self.get_actions([sobs] * n, [obs[:, k] for k in range(n)], deterministic=deterministic, out=out)
         return shared.actions[s]
+
+    # collect_into refreshes at step 0 of every rollout (see the module docstring); False leaves only the version-counter check -- for
+    # callers that never write parameters through .data and want the ~ms of derived-copy rebuilding only when an optimizer stepped
+    refresh_every_rollout = True
 
     # Diagnostics (off the hot path): with track_conditioning = True every folded pass records, per hidden LayerNorm, the largest
     # |mean| / std of the rows it normalised (three small torch kernels per layer: not for timed runs)

@@ -834,6 +834,53 @@ def test_ingenuity_full_size_properties(torch_cuda):
     assert float(a["root_states"][:, 10:13].norm(dim=-1).max()) <= 4 * np.pi + 1e-3      # max_angular_velocity (multi_ingenuity.py:149)
 
 
+def test_ingenuity_in_flight_full_size_properties(torch_cuda):
+    """BASELINE configs[2] with the helicopters actually FLYING: MultiIngenuity, 8192 envs, envSpacing 0 -- every env
+    sits at the global origin, so the reference's global-frame reset rule (multi_ingenuity.py:381-453: any helicopter more than 8 m from
+    its goal, or below 0.5 m) fires only when a helicopter really leaves, not on every step of every env away from the origin as under
+    the default env grid.  Near-hover actions (thrust around weight / 2 per rotor, small lateral fractions): finite, speeds bounded,
+    resets on fewer than 5 % of the env-steps, and the flight is not a standstill (the helicopters move)."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.engine import Engine
+    from massive_marl_benchmark_amd.model import default_cfg
+    N, steps = 8192, 200
+    cfg = default_cfg("MultiIngenuity")
+    cfg["env"]["envSpacing"] = 0.0
+    eng = Engine("MultiIngenuity", cfg=cfg, num_envs=N, device=0, seed=2)
+    hover = 1.5 * 3.721 / (2.0 * 2000.0 * eng.config.dt)             # per-rotor action whose thrust carries half the 1.5 kg on Mars
+    g = torch.Generator().manual_seed(9)
+    ring = []
+    for _ in range(8):
+        a = (torch.rand(N, 24, generator=g) * 2 - 1) * 0.1
+        a[:, 2::3] = hover * (1.0 + 0.2 * (torch.rand(N, 8, generator=g) * 2 - 1))
+        ring.append(a.cuda())
+    eng.reset_all()
+    eng.tensor("actions").copy_(ring[0])
+    eng.step()                                                        # (whatever reset_all leaves pending has happened by now)
+    torch.cuda.synchronize()
+    base = int(eng.tensor("reset_count").sum())
+    start = eng.tensor("root_states").clone()
+    vmax, moved = 0.0, 0.0
+    for t in range(steps):
+        eng.tensor("actions").copy_(ring[t % 8])
+        eng.step()
+        if t % 20 == 19:
+            rs = eng.tensor("root_states")
+            assert torch.isfinite(rs).all() and torch.isfinite(eng.tensor("obs")).all() and torch.isfinite(eng.tensor("rew")).all()
+            vmax = max(vmax, float(rs[:, 7:10].norm(dim=-1).max()))
+            moved = max(moved, float((rs[:, 0:3] - start[:, 0:3]).norm(dim=-1).median()))
+            assert float(rs[:, 10:13].norm(dim=-1).max()) <= 4 * np.pi + 1e-3
+    torch.cuda.synchronize()
+    resets = int(eng.tensor("reset_count").sum()) - base
+    frac = resets / float(N * steps)
+    assert vmax < 30.0, vmax
+    assert moved > 0.01, moved
+    assert 0 <= frac < 0.05, frac
+    assert float(eng.tensor("rew").min()) >= 0.0
+    parity.record("gpu/ingenuity_in_flight_8192", resets_per_env_step=frac, max_speed=vmax, median_displacement=moved)
+    eng.close()
+
+
 def test_shared_rollout_buffers_equal_separated_buffers(torch_cuda):
     """Rollout-buffer fusion: SharedRolloutBuffers driven through env_step / insert_step holds exactly
     what ten SeparatedReplayBuffers hold when driven the reference's way (runner.py:128-255), with share_obs stored once."""
@@ -1644,6 +1691,37 @@ def test_actor_critic_graph_follows_parameter_updates(torch_cuda):
             n_cases += 1
     eng.close()
     assert n_cases == 4
+
+
+def test_ppo_training_loop_on_the_hip_path(torch_cuda):
+    """a training loop where the kernels are.  tools/train_ppo_demo.py's learner (this build's restatement of
+    agents/algorithms/rl/ppo/ppo.py:243-317 with cfg/ppo/config.yaml's hyper-parameters; the reference's own learner classes run in
+    tests/test_cpu_backend.py on the CPU build) for 24 iterations at 1024 OneAnt envs through VecTaskPython + ActorCritic with the
+    split layers FORCED on (hidden widths multiples of 128, split_min_tiles 0) + RolloutStorage: everything stays finite, the mean
+    reward per step rises, and the layers' operand planes follow EVERY optimizer step (120 Adam steps) -- after the last update `act`
+    agrees with the torch modules evaluated on the updated parameters."""
+    torch = torch_cuda
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train_ppo_demo
+    for use_planes in (False, True):
+        args = train_ppo_demo.parse(["--task", "OneAnt", "--num-envs", "1024", "--iterations", "24", "--hidden", "256", "128", "128", "--split-min-tiles", "0",
+                                     "--log-every", "1000"] + (["--obs-planes"] if use_planes else []))
+        lines = []
+        out = train_ppo_demo.train(args, log=lines.append)
+        ac, obs, states, hist = out["ac"], out["obs"], out["states"], out["reward_per_step"]
+        assert ac._split_bufs and ac._h16 is not None, "the split path did not run"
+        assert all(np.isfinite(hist)) and bool(torch.isfinite(obs).all())
+        first, last = float(np.mean(hist[:4])), float(np.mean(hist[-4:]))
+        assert last > first, (first, last, hist)
+        with torch.no_grad():
+            _, _, v, mu, _ = ac.act(obs, states)
+            mu_t, v_t = ac.actor(obs), ac.critic(obs)
+        rel = lambda a, b: float((a - b).abs().max() / (1.0 + b.abs().max()))
+        assert rel(mu, mu_t) < 1e-5 and rel(v, v_t) < 1e-5, (rel(mu, mu_t), rel(v, v_t))
+        parity.record("gpu/ppo_training_loop/%s" % ("obs_planes" if use_planes else "own_split"), reward_per_step_first4=first, reward_per_step_last4=last,
+                      act_vs_torch_after_last_update=max(rel(mu, mu_t), rel(v, v_t)))
+        out["env"].task.engine.close()
 
 
 def test_abi_error_paths_and_indexed_set_state(torch_cuda):

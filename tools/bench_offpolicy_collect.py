@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--replay-size", type=int, default=1024)
     ap.add_argument("--library-actor", action="store_true", help="A/B: the actor's layers as library GEMMs + activation passes")
+    ap.add_argument("--env-spacing", type=float, default=None,
+                    help="override env.envSpacing (0: every env at the origin, the helicopters fly; default: the reference's grid, where every env away "
+                         "from the origin resets on every step -- positions and goals are global-frame, multi_ingenuity.py:381-453)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -34,9 +37,15 @@ def main():
 
     N = args.num_envs
     torch.manual_seed(0)
-    out = {"task": args.task, "num_envs": N, "replay_size": args.replay_size, "actor": "library" if args.library_actor else "mms_linear2_act"}
+    out = {"task": args.task, "num_envs": N, "replay_size": args.replay_size, "actor": "library" if args.library_actor else "mms_linear2_act",
+           "env_spacing": "reference default" if args.env_spacing is None else args.env_spacing}
+    from massive_marl_benchmark_amd.model import default_cfg
+    cfg = None
+    if args.env_spacing is not None:
+        cfg = default_cfg(args.task)
+        cfg["env"]["envSpacing"] = float(args.env_spacing)
     for variant in ("copies", "bound"):
-        eng = Engine(args.task, num_envs=N, device=0, seed=0, clip_obs=5.0)
+        eng = Engine(args.task, cfg=cfg, num_envs=N, device=0, seed=0, clip_obs=5.0)
         W, AD = eng.obs_dim, eng.num_actions
         ac = MLPActorCritic(spaces.Box(-np.inf * np.ones(W), np.inf * np.ones(W)), spaces.Box(-np.ones(AD), np.ones(AD)), 0.1, "cuda:0",
                             hidden_sizes=[256, 256, 256]).cuda()                       # cfg/ddpg/config.yaml: hidden_nodes 256 x 3
@@ -94,7 +103,8 @@ def main():
             e1.record(s); s.synchronize()
             graph_ms = e0.elapsed_time(e1) / (reps * 16)
         finite = bool(torch.isfinite(buf.next_observations[:32]).all())
-        out[variant] = {"eager_ms_per_step": eager_ms, "eager_env_steps_per_s": N / (eager_ms * 1e-3),
+        n_steps = 1 + 64 + args.steps + 16 + 16 + reps * 16
+        out[variant] = {"resets_per_env_step": int(eng.tensor("reset_count").sum()) / float(N * n_steps),"eager_ms_per_step": eager_ms, "eager_env_steps_per_s": N / (eager_ms * 1e-3),
                         "graph_ms_per_step": graph_ms, "graph_env_steps_per_s": N / (graph_ms * 1e-3), "finite": finite}
         eng.bind_obs_out(None); eng.bind_rollout_out(None, None)
         del graph

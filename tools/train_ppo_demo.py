@@ -15,7 +15,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--task", default="OneAnt", choices=["OneAnt", "TenAnt"])
     ap.add_argument("--num-envs", type=int, default=4096)
@@ -35,8 +35,12 @@ def main():
                     help="the step kernel also writes the observation's operand planes (Engine.bind_obs_planes) and act() reads them instead of splitting the rows")
     ap.add_argument("--friction-combine", default="average", choices=["average", "min"],
                     help="cfg env.frictionCombine: PhysX's average rule (default) or min = a box that is frictionless against everything")
-    args = ap.parse_args()
+    ap.add_argument("--split-min-tiles", type=int, default=None, help="ActorCritic.split_min_tiles (0: the split layers whatever the batch size)")
+    return ap.parse_args(argv)
 
+
+def train(args, log=print):
+    """The loop; returns {"reward_per_step": [one mean per iteration], "ac", "env", "obs", "states"} (tests/test_gpu_parity.py drives it)."""
     import torch
     from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
     from massive_marl_benchmark_amd.algorithms.rl.ppo.storage import RolloutStorage
@@ -61,6 +65,9 @@ def main():
                      seed=args.seed).to(dev)
     ac.split_layers = not args.exact_fp32_layers
     ac.split_format = args.split_format
+    if args.split_min_tiles is not None:
+        ac.split_min_tiles = args.split_min_tiles
+    history = []
     storage = RolloutStorage(N, T, (obs_dim,), (0,), (act_dim,), device=str(dev))
     opt = torch.optim.Adam(ac.parameters(), lr=args.lr)
     lr = args.lr
@@ -70,7 +77,7 @@ def main():
     ep_len = torch.zeros(N, device=dev)
     done_ret, done_len, done_cnt = 0.0, 0.0, 0
     t0 = time.time()
-    print("task %s, %d envs, obs %d, actions %d, hidden %s" % (args.task, N, obs_dim, act_dim, args.hidden), flush=True)
+    log("task %s, %d envs, obs %d, actions %d, hidden %s" % (args.task, N, obs_dim, act_dim, args.hidden))
     planes, planes_ok = None, False
     if args.obs_planes:
         planes = torch.empty(N * ((obs_dim + 31) // 32) * 128, dtype=torch.uint8, device=dev)
@@ -94,6 +101,7 @@ def main():
         with torch.no_grad():
             last_values = ac.critic(obs)
         mean_step_reward = float(storage.rewards.mean())
+        history.append(mean_step_reward)
         storage.compute_returns(last_values, GAMMA, LAM)
         flat = lambda x: x.view(-1, *x.shape[2:])
         B = N * T
@@ -127,12 +135,17 @@ def main():
             torch.cuda.synchronize()
             finite = bool(torch.isfinite(obs).all())
             root = env.task.engine.tensor("root_states")
-            print("it %4d  reward/step %8.3f  episodes %6d  mean return %9.2f  mean length %6.1f  lr %.1e  std %.2f  max|v| %.1f  finite %s  %.0f env-steps/s"
-                  % (it + 1, mean_step_reward, done_cnt, done_ret / max(done_cnt, 1), done_len / max(done_cnt, 1), lr,
-                     float(ac.log_std.detach().exp().mean()), float(root[:, 7:10].abs().max()), finite, (it + 1) * T * N / (time.time() - t0)), flush=True)
+            log("it %4d  reward/step %8.3f  episodes %6d  mean return %9.2f  mean length %6.1f  lr %.1e  std %.2f  max|v| %.1f  finite %s  %.0f env-steps/s"
+                % (it + 1, mean_step_reward, done_cnt, done_ret / max(done_cnt, 1), done_len / max(done_cnt, 1), lr,
+                   float(ac.log_std.detach().exp().mean()), float(root[:, 7:10].abs().max()), finite, (it + 1) * T * N / (time.time() - t0)))
             done_ret, done_len, done_cnt = 0.0, 0.0, 0
             if not finite:
-                sys.exit("non-finite observation")
+                raise RuntimeError("non-finite observation")
+    return {"reward_per_step": history, "ac": ac, "env": env, "obs": obs, "states": states}
+
+
+def main():
+    train(parse(), log=lambda m: print(m, flush=True))
 
 
 if __name__ == "__main__":
