@@ -214,9 +214,11 @@ int mms_gae_ppo(int device, const float* rewards, const uint8_t* dones, const fl
                 int32_t T, int64_t N, float gamma, float lam, void* hip_stream);
 /* advantages := (advantages - mean) / (std + 1e-8) with the unbiased std from stats. */
 int mms_adv_normalize(int device, float* advantages, const double* stats, int64_t count, void* hip_stream);
-/* mms_gae_ppo + mms_adv_normalize for ONE rank (nothing to all-reduce in between), the whole of storage.py:51-65: up to 65536
- * transitions in a single launch with a fixed summation order (bit-reproducible; stats need no zeroing), larger rollouts as the two
- * launches above.  stats[0..2] receives {sum(adv), sum(adv^2), count} of the un-normalised advantages. */
+/* mms_gae_ppo + mms_adv_normalize for ONE rank (nothing to all-reduce in between), the whole of storage.py:51-65: the scan leaves
+ * per-block partial sums instead of float64 atomics and the normalisation sums them in a fixed order -- bit-reproducible, and stats
+ * needs no zeroing (the atomics' 24-byte memset costs two fill kernels inside a captured rollout).  stats: f64 [MMS_GAE_STATS_DOUBLES]
+ * = {sum(adv), sum(adv^2), count} of the un-normalised advantages, then scratch for the partials. */
+#define MMS_GAE_STATS_DOUBLES (3 + 2 * 2048)
 int mms_gae_ppo_normalized(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values,
                            float* returns, float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam,
                            void* hip_stream);

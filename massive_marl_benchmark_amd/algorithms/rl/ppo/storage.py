@@ -35,7 +35,7 @@ class RolloutStorage:
         self.num_envs = N
         self.step = 0
         self.process_group = process_group
-        self._stats = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self._stats = torch.zeros(3 + 2 * 2048, dtype=torch.float64, device=self.device)      # MMS_GAE_STATS_DOUBLES (include/mms.h)
 
     def observation_slot(self, t):
         return self.observations[t]
@@ -71,13 +71,13 @@ class RolloutStorage:
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         last_values = last_values.contiguous().view(-1).float()
         if self.process_group is None:
-            # one rank: scan + normalisation in one launch (fixed summation order, nothing to zero; up to 64 K transitions)
+            # one rank: per-block partial sums instead of atomics (fixed summation order: bit-reproducible; nothing to zero)
             _lib.check(L.mms_gae_ppo_normalized(idx, p(self.rewards), p(self.dones), p(self.values), p(last_values), p(self.returns),
                                                 p(self.advantages), p(self._stats), T, N, float(gamma), float(lam), stream), None, "mms_gae_ppo_normalized", L)
             return
         _lib.check(L.mms_gae_ppo(idx, p(self.rewards), p(self.dones), p(self.values), p(last_values), p(self.returns),
                                  p(self.advantages), p(self._stats), T, N, float(gamma), float(lam), stream), None, "mms_gae_ppo", L)
-        torch.distributed.all_reduce(self._stats, group=self.process_group)       # sum, sum of squares, count
+        torch.distributed.all_reduce(self._stats[:3], group=self.process_group)   # sum, sum of squares, count
         _lib.check(L.mms_adv_normalize(idx, p(self.advantages), p(self._stats), T * N, stream), None, "mms_adv_normalize", L)
 
     def get_statistics(self):

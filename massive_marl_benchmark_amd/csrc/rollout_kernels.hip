@@ -54,17 +54,18 @@ __global__ void __launch_bounds__(256) gae_ppo_kernel(const float* __restrict__ 
     }
 }
 
-// Both steps in ONE launch for rollouts of at most 64 K transitions on one rank (TenAnt 4096 envs x 8 steps = 32 K): a single
-// 1024-thread block scans its columns, reduces the advantage statistics in a fixed order (per-thread, wave butterfly, wave order:
-// deterministic, no atomics, nothing to zero beforehand -- the two-launch form pays a 24-byte memset that the runtime turns into two
-// fill kernels, ~9.5 us, and a second launch) and normalises what it wrote.  stats receives {sum, sum of squares, count} as well.
-__global__ void __launch_bounds__(1024) gae_ppo_norm_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ dones,
-                                                            const float* __restrict__ values, const float* __restrict__ last_values,
-                                                            float* __restrict__ returns, float* __restrict__ advantages,
-                                                            double* __restrict__ stats, int T, int64_t N, float gamma, float lam) {
-    __shared__ double s_sum[16], s_sq[16], s_tot[3];
+// The one-rank form of the two steps (nothing to all-reduce in between), bit-reproducible and with nothing to zero beforehand: the scan
+// leaves per-block partial sums in a scratch area (no atomics; the atomics of gae_ppo_kernel need a 24-byte memset that the runtime
+// turns into two fill kernels, ~9.5 us inside a captured rollout), and EVERY block of the normalisation sums the partials in the same
+// fixed order before it normalises its share.  stats = f64 [3 + 2 * kGaeMaxBlocks]: {sum, sum of squares, count}, then the partials.
+constexpr int kGaeMaxBlocks = 2048;
+__global__ void __launch_bounds__(256) gae_ppo_partials_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ dones,
+                                                               const float* __restrict__ values, const float* __restrict__ last_values,
+                                                               float* __restrict__ returns, float* __restrict__ advantages,
+                                                               double* __restrict__ stats, int T, int64_t N, float gamma, float lam) {
+    __shared__ double s_sum[4], s_sq[4];
     double lsum = 0.0, lsq = 0.0;
-    for (int64_t i = threadIdx.x; i < N; i += 1024)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
         gae_ppo_column(rewards, dones, values, last_values, returns, advantages, T, N, i, gamma, lam, lsum, lsq);
     lsum = wave_sum(lsum);
     lsq = wave_sum(lsq);
@@ -72,16 +73,30 @@ __global__ void __launch_bounds__(1024) gae_ppo_norm_kernel(const float* __restr
     if ((threadIdx.x & 63) == 0) { s_sum[wave] = lsum; s_sq[wave] = lsq; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int w = 0; w < 16; w++) { a += s_sum[w]; b += s_sq[w]; }
-        s_tot[0] = a; s_tot[1] = b; s_tot[2] = (double)T * (double)N;
-        stats[0] = a; stats[1] = b; stats[2] = s_tot[2];
+        stats[3 + 2 * blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        stats[4 + 2 * blockIdx.x] = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]);
+    }
+}
+__global__ void __launch_bounds__(256) adv_normalize_partials_kernel(float* __restrict__ advantages, double* __restrict__ stats, int nparts,
+                                                                     double count_d, int64_t count) {
+    __shared__ double s_sum[4], s_sq[4], s_tot[3];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) { a += stats[3 + 2 * i]; b += stats[4 + 2 * i]; }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = a; s_sq[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_tot[0] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        s_tot[1] = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]);
+        s_tot[2] = count_d;
+        if (blockIdx.x == 0) { stats[0] = s_tot[0]; stats[1] = s_tot[1]; stats[2] = s_tot[2]; }
     }
     __syncthreads();
     float fm, inv;
     adv_norm_params(s_tot, fm, inv);
-    for (int64_t i = threadIdx.x; i < N; i += 1024)          // (each thread re-reads only what it stored itself)
-        for (int t = 0; t < T; t++) advantages[t * N + i] = (advantages[t * N + i] - fm) * inv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        advantages[i] = (advantages[i] - fm) * inv;
 }
 
 // advantages := (advantages - mean) / (std + 1e-8), std unbiased (torch.std default)
@@ -293,12 +308,12 @@ hipError_t launch_gae_ppo(const float* rewards, const uint8_t* dones, const floa
 }
 hipError_t launch_gae_ppo_normalized(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
                                      float* advantages, double* stats, int T, int64_t N, float gamma, float lam, hipStream_t s) {
-    if ((int64_t)T * N <= 65536) {
-        hipLaunchKernelGGL(gae_ppo_norm_kernel, dim3(1), dim3(1024), 0, s, rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam);
-        return hipGetLastError();
-    }
-    if (hipError_t e = launch_gae_ppo(rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam, s); e != hipSuccess) return e;
-    return launch_adv_normalize(advantages, stats, (int64_t)T * N, s);
+    const int blocks = grid_for(N);                                        // <= kGaeMaxBlocks partial pairs
+    hipLaunchKernelGGL(gae_ppo_partials_kernel, dim3(blocks), dim3(256), 0, s, rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    const int64_t count = (int64_t)T * N;
+    hipLaunchKernelGGL(adv_normalize_partials_kernel, dim3(grid_for(count)), dim3(256), 0, s, advantages, stats, blocks, (double)T * (double)N, count);
+    return hipGetLastError();
 }
 hipError_t launch_adv_normalize(float* advantages, const double* stats, int64_t count, hipStream_t s) {
     hipLaunchKernelGGL(adv_normalize_kernel, dim3(grid_for(count)), dim3(256), 0, s, advantages, stats, count);

@@ -39,6 +39,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// cache policy of the operand DMA (aux of global_load_lds: 0 default, 2 = nt); A/B knobs, the defaults are what measured fastest
+#ifndef MMS_S16_AUX_X
+#define MMS_S16_AUX_X 0
+#endif
+#ifndef MMS_S16_AUX_W
+#define MMS_S16_AUX_W 0
+#endif
 constexpr int kChunk16 = 128;                    // one row's two planes of 32 k
 constexpr float kLoScale = 2048.f;               // the lo plane holds the residual times 2^11
 constexpr int kTopExp = 14;                      // a row's bound sits at 2^14 (fp16 ends just below 2^16)
@@ -303,7 +310,8 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
         const uint8_t* ws = wb + (size_t)kc * kChunk16;
 #pragma unroll
         for (int i = 0; i < G::NDMA; i++)
-            __builtin_amdgcn_global_load_lds((gptr16_t)((i < G::NX ? xs : ws) + goff[i]), (lptr16_t)(lds + buf * G::BUF + (wave + 8 * i) * 1024), 16, 0, 0);
+            if (i < G::NX) __builtin_amdgcn_global_load_lds((gptr16_t)(xs + goff[i]), (lptr16_t)(lds + buf * G::BUF + (wave + 8 * i) * 1024), 16, 0, MMS_S16_AUX_X);
+            else __builtin_amdgcn_global_load_lds((gptr16_t)(ws + goff[i]), (lptr16_t)(lds + buf * G::BUF + (wave + 8 * i) * 1024), 16, 0, MMS_S16_AUX_W);
     };
 
     // this lane's fragment address inside a buffer: row r16 of a 16-row tile, plane 0, k-group g4; plane 1 is the same address ^ 64

@@ -136,6 +136,26 @@ def main():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     out["fused_graph"] = timed(graph.replay, args.iters)
+    # A/B: without the unconditional refresh of the derived copies at step 0 of every rollout (GroupedPolicyInference.refresh_every_rollout:
+    # what follows a trainer that updates through `.data`, hatrpo_trainer.py:122) -- round 3's figure was measured this way
+    inf.refresh_every_rollout = False
+    with torch.cuda.stream(side):
+        fused()
+        graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph2, stream=side):
+            fused()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    out["fused_graph_no_refresh"] = timed(graph2.replay, args.iters)
+    out["fused_eager_no_refresh"] = timed(fused, args.iters)
+    inf.refresh_every_rollout = True
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    inf.refresh(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(4):
+        inf.refresh()
+    e1.record(); torch.cuda.synchronize()
+    out["refresh_ms_eager"] = e0.elapsed_time(e1) / 4
     out["finite"] = bool(torch.isfinite(sh.returns).all()) and bool(torch.isfinite(sh.share_obs).all())
     # roofline of the collection step's dominant work, the policy layers: fp32-equivalent FLOPs per env step (T collect passes + one
     # critics-only bootstrap pass per rollout) over the step time, against the pipe they run on

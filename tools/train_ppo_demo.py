@@ -40,7 +40,8 @@ def parse(argv=None):
 
 
 def train(args, log=print):
-    """The loop; returns {"reward_per_step": [one mean per iteration], "ac", "env", "obs", "states"} (tests/test_gpu_parity.py drives it)."""
+    """The loop; returns {"reward_per_step": [one mean per iteration], "episodes": [(sum of returns, count) of the episodes that ended in
+    each iteration], "value_error": [per iteration, E(return - value)^2 / var(return) of the rollout as collected], "ac", "env", "obs", "states"} (tests/test_gpu_parity.py drives it)."""
     import torch
     from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
     from massive_marl_benchmark_amd.algorithms.rl.ppo.storage import RolloutStorage
@@ -67,7 +68,7 @@ def train(args, log=print):
     ac.split_format = args.split_format
     if args.split_min_tiles is not None:
         ac.split_min_tiles = args.split_min_tiles
-    history = []
+    history, episodes, vloss_hist = [], [], []
     storage = RolloutStorage(N, T, (obs_dim,), (0,), (act_dim,), device=str(dev))
     opt = torch.optim.Adam(ac.parameters(), lr=args.lr)
     lr = args.lr
@@ -76,6 +77,7 @@ def train(args, log=print):
     ep_ret = torch.zeros(N, device=dev)
     ep_len = torch.zeros(N, device=dev)
     done_ret, done_len, done_cnt = 0.0, 0.0, 0
+    run_ret, run_cnt = 0.0, 0
     t0 = time.time()
     log("task %s, %d envs, obs %d, actions %d, hidden %s" % (args.task, N, obs_dim, act_dim, args.hidden))
     planes, planes_ok = None, False
@@ -96,15 +98,21 @@ def train(args, log=print):
             n_fin = int(fin.sum())
             if n_fin:
                 done_ret += float(ep_ret[fin].sum()); done_len += float(ep_len[fin].sum()); done_cnt += n_fin
+                run_ret += float(ep_ret[fin].sum()); run_cnt += n_fin
                 ep_ret[fin] = 0
                 ep_len[fin] = 0
         with torch.no_grad():
             last_values = ac.critic(obs)
         mean_step_reward = float(storage.rewards.mean())
         history.append(mean_step_reward)
+        episodes.append((run_ret, run_cnt))
+        run_ret, run_cnt = 0.0, 0
         storage.compute_returns(last_values, GAMMA, LAM)
         flat = lambda x: x.view(-1, *x.shape[2:])
         B = N * T
+        with torch.no_grad():                                  # how well the critic the rollout ran with explains the returns it produced
+            ret_ = storage.returns.view(-1)
+            vloss_hist.append(float((ret_ - storage.values.view(-1)).pow(2).mean() / ret_.var().clamp_min(1e-8)))
         for _ in range(EPOCHS):
             perm = torch.arange(B, device=dev)                 # 'sequential' sampler (cfg/ppo/config.yaml sampler)
             for idx in perm.chunk(MINIB):
@@ -141,7 +149,7 @@ def train(args, log=print):
             done_ret, done_len, done_cnt = 0.0, 0.0, 0
             if not finite:
                 raise RuntimeError("non-finite observation")
-    return {"reward_per_step": history, "ac": ac, "env": env, "obs": obs, "states": states}
+    return {"reward_per_step": history, "episodes": episodes, "value_error": vloss_hist, "ac": ac, "env": env, "obs": obs, "states": states}
 
 
 def main():
