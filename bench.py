@@ -418,6 +418,7 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         refresh_us = 1e3 * ev0.elapsed_time(ev1) / 32
+    ac.bind_rollout(None, None)                 # (a bound storage at step 0 would make every probe call below refresh the derived buffers first)
     layer_err = policy_layer_errors(torch, ac, obs_clipped) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
     layer_roof = policy_layer_roofline(torch, ac, obs_clipped, args) if (args.policy_dtype == "fp32" and not args.library_gemms) else None
     eng.bind_obs_out(None)

@@ -411,6 +411,22 @@ int mms_linear_group_act_split16(int device, int32_t groups, int64_t M, int32_t 
                                  const float* const* ln_stat_in, float* const* ln_part_out, const float* const* head_w, float* const* head_part,
                                  const int32_t* head_dims, void* hip_stream);
 
+/* The weights' side of a layer BEHIND A FOLDED LayerNorm, refreshed on the device after every update (GroupedPolicyInference.refresh():
+ * no host synchronisation, every output at the caller's address; the reference re-reads its parameters in every forward,
+ * agents/algorithms/utils/mlp.py:19-27,44-60).  For g < groups and row n of w_g [N[g], K[g]] (f32, contiguous; N, K: HOST arrays, the
+ * shapes may differ from group to group):
+ *   W~[n, k] = w[n, k] gamma_g[k] (gamma or gamma[g] NULL: w itself) -> planes_g (H32) with inv_g[n] = 1 / its row scale (planes or
+ *   planes[g] NULL: no planes), wt[g] = W~ as f32 [N, K] (NULL: not stored), s[g][n] = sum_k W~[n, k], c[g][n] = sum_k w[n, k] beta_g[k] +
+ *   bias_g[n] (NULL: without that term), rb[g][n] = |W~ row|_2 sqrt(K) + |c[n]|: the row's bound of W~ xhat + c over normalised inputs.
+ * mms_fold_scales16_group: scale_g = 2^(14 - e) with 1.001 max_{i < n[g]} rb[g][i] <= 2^e -> scale1[g][0] (f32 [1], optional) and
+ *   ysc[g][0..M) = scale_g, yinv[g][0..M) = 1 / scale_g (f32 [M] each, optional): the y_scale / next x_inv rows of
+ *   mms_linear_group_act_split16 for a layer whose output bound does not depend on the data. */
+int mms_fold_planes16_group(int device, int32_t groups, const int64_t* N, const int32_t* K, const float* const* w, const float* const* gamma,
+                            const float* const* beta, const float* const* bias, void* const* planes, float* const* inv, float* const* s,
+                            float* const* c, float* const* rb, float* const* wt, void* hip_stream);
+int mms_fold_scales16_group(int device, int32_t groups, const float* const* rb, const int32_t* n, int64_t M, float* const* scale1,
+                            float* const* ysc, float* const* yinv, void* hip_stream);
+
 /* stat_g[r] = (mean, 1 / sqrt(var + eps)) of row r from mms_linear_group_act_split's ln_part_out (`slots` = N / 64 slots of 64). */
 int mms_row_stats_chan_group(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part, float* const* stat, float eps,
                              void* hip_stream);

@@ -143,113 +143,147 @@ class GroupedPolicyInference:
             raise NotImplementedError("GroupedPolicyInference: at most 16 actions, hidden size a multiple of 4 up to 1024")
         self.eps = float(self.actors[0].base.feature_norm.eps)
         self.device = self.actors[0].act.action_out.fc_mean.weight.device
-        self._M = None
+        self._M, self._D, self.p, self._versions = None, None, None, ()
         self.refresh()
 
     # -- parameters ---------------------------------------------------------------------------------------------------------------
+    def _derived(self):
+        """Every copy DERIVED from the parameters, allocated ONCE (stable addresses: the launches of a captured rollout keep pointing at
+        them) together with the prebuilt arguments of the launches that rebuild them -- refresh() is device work only:
+          folded weights W~ = W diag(gamma) (f32, for the exact-fp32 fold path), their operand planes and inverse row scales, s = W~ 1,
+          c = W beta + b, the rows' output bounds (mms_fold_planes16_group: the actors' and critics' first layers behind their feature
+          LayerNorms, the H x H layers behind the hidden LayerNorms, the output heads behind the last one); per network and layer the
+          power of two of the output rows (mms_fold_scales16_group); the three-plane format's planes of W~ (mms_split_planes_group);
+          the zero-padded first weights of the unfolded path and the action standard deviations (torch._foreach_* into fixed buffers)."""
+        if self._D is not None:
+            return self._D
+        dev, n, H, A, depth = self.device, self.n, self.hidden, self.act_dim, self.depth
+        L, idx, _ = _lib.for_device(dev)
+        z = lambda *sh, **k: torch.zeros(*sh, device=dev, **k)
+        d = lambda t: t.detach()
+        self.kp_a, self.kp_c = (self.obs_dim + 3) & ~3, (self.sobs_dim + 3) & ~3
+        both = self.a_blocks + self.c_blocks
+        split = self.split_layers and self.fold_layernorm and self.sobs_dim % 4 == 0 and H % 128 == 0
+        h16 = self.split_format == "f16x2"
+        pbytes = lambda N, K: N * ((K + 31) // 32) * (128 if h16 else 192)
+        u8 = lambda G, N, K: [torch.empty(pbytes(N, K), dtype=torch.uint8, device=dev) for _ in range(G)]
+        D = {"split": split, "w1_a": z(n, H, self.kp_a), "w1_c": z(n, H, self.kp_c), "std": z(n, A), "fold": {}, "calls": [], "scale_jobs": []}
+        up = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+        i64 = lambda v: (ctypes.c_int64 * len(v))(*v)
+        i32 = lambda v: (ctypes.c_int32 * len(v))(*v)
+
+        def fold_set(ws, gammas, betas, biases, N, K, want_wt, want_planes, want_rb):
+            """buffers + one job description of a set of G matrices [N, K] behind LayerNorms (gamma, beta)"""
+            G = len(ws)
+            Nmax = max(N) if isinstance(N, (list, tuple)) else N
+            st = {"G": G, "N": N, "K": K, "wt": z(G, Nmax, K) if want_wt else None, "s": z(G, Nmax), "c": z(G, Nmax), "rb": z(G, Nmax) if want_rb else None,
+                  "planes": u8(G, N, K) if want_planes else None, "inv": z(G, N) if (want_planes and h16) else None,
+                  "src": (ws, gammas, betas, biases)}
+            return st
+
+        def fold_call(sets):
+            """ONE mms_fold_planes16_group launch over several sets (at most MMS_MAX_GROUPS matrices)"""
+            Ns, Ks, w, gm, bt, bs, pl, iv, sv, cv, rb, wt = [], [], [], [], [], [], [], [], [], [], [], []
+            for st in sets:
+                ws, gammas, betas, biases = st["src"]
+                for g in range(st["G"]):
+                    Ns.append(st["N"] if not isinstance(st["N"], (list, tuple)) else st["N"][g])
+                    Ks.append(st["K"])
+                    w.append(d(ws[g])); gm.append(d(gammas[g])); bt.append(d(betas[g])); bs.append(d(biases[g]))
+                    h32 = st["planes"] is not None and h16
+                    pl.append(st["planes"][g] if h32 else None); iv.append(st["inv"][g] if h32 else None)
+                    sv.append(st["s"][g]); cv.append(st["c"][g]); rb.append(None if st["rb"] is None else st["rb"][g])
+                    wt.append(None if st["wt"] is None else st["wt"][g])
+            assert len(w) <= 32
+            keep = (w, gm, bt, bs)
+            return (L.mms_fold_planes16_group, (idx, len(w), i64(Ns), i32(Ks), up(w), up(gm), up(bt), up(bs), up(pl), up(iv), up(sv), up(cv), up(rb), up(wt)),
+                    "mms_fold_planes16_group", keep)
+
+        need_wt = True                                         # (the exact-fp32 fold path reads W~ itself; the three-plane format splits it)
+        fa = [a.base.feature_norm for a in self.actors]
+        fc = [c.base.feature_norm for c in self.critics]
+        firsts = []
+        D["a1"] = None
+        if split:
+            D["a1"] = fold_set([b[0][0].weight for b in self.a_blocks], [m.weight for m in fa], [m.bias for m in fa], [b[0][0].bias for b in self.a_blocks],
+                               H, self.obs_dim, not h16, True, h16)
+            firsts.append(D["a1"])
+        D["c1"] = None
+        if self.sobs_dim % 4 == 0:
+            D["c1"] = fold_set([b[0][0].weight for b in self.c_blocks], [m.weight for m in fc], [m.bias for m in fc], [b[0][0].bias for b in self.c_blocks],
+                               H, self.sobs_dim, need_wt, split, split and h16)
+            firsts.append(D["c1"])
+        if firsts:
+            D["calls"].append(fold_call(firsts))
+        for l in range(1, depth):
+            D["fold"][l] = fold_set([b[l][0].weight for b in both], [b[l - 1][1].weight for b in both], [b[l - 1][1].bias for b in both],
+                                    [b[l][0].bias for b in both], H, H, need_wt, split, split and h16 and l < depth - 1)
+            D["calls"].append(fold_call([D["fold"][l]]))
+        D["heads"] = None
+        if split:
+            last = depth - 1
+            hw = [a.act.action_out.fc_mean.weight for a in self.actors] + [c.v_out.weight for c in self.critics]
+            hb = [a.act.action_out.fc_mean.bias for a in self.actors] + [c.v_out.bias for c in self.critics]
+            hd = fold_set(hw, [b[last][1].weight for b in both], [b[last][1].bias for b in both], hb, [A] * n + [1] * n, H, False, False, False)
+            hd["wt"] = z(2 * n, A, H)                                                  # critics: row 0 = v_out, the rest stays zero
+            D["heads"] = hd
+            D["calls"].append(fold_call([hd]))
+            if not h16:                                        # three bf16 planes of the folded weights
+                for st in [D["a1"], D["c1"]] + [D["fold"][l] for l in D["fold"]]:
+                    wts = list(st["wt"].unbind(0))
+                    D["calls"].append((L.mms_split_planes_group, (idx, st["G"], st["N"], st["K"], 0, up(wts), up(st["planes"])), "mms_split_planes_group", wts))
+            else:
+                # output scales per layer over the 2n networks (actors first): layer 0 = the two first layers, l >= 1 = the H x H layers
+                D["scale1"] = {0: z(2 * n)}
+                D["scale_jobs"].append((0, list(D["a1"]["rb"].unbind(0)) + list(D["c1"]["rb"].unbind(0))))
+                for l in range(1, depth - 1):
+                    D["scale1"][l] = z(2 * n)
+                    D["scale_jobs"].append((l, list(D["fold"][l]["rb"].unbind(0))))
+        self._D = D
+        return D
+
     def refresh(self):
-        """Call after the parameters changed (an optimizer step): rebuilds the zero-padded first actor weights and the std vectors;
-        everything else is read from the modules' own storage."""
+        """Rebuild every copy derived from the parameters from the parameters as they are NOW: device work only (a handful of launches
+        on the caller's stream), into buffers whose addresses never change -- it runs at step 0 of every rollout in both collect forms
+        and may be captured in a hipGraph with the rollout."""
         if self._chunks is not None:
             for c in self._chunks:
                 c.refresh()
             return
-        dev, n = self.device, self.n
-        d = lambda t: t.detach()
+        D = self._derived()
+        L, idx, stream = _lib.for_device(self.device)
         self._versions = self._param_versions()
-        self.kp_a = (self.obs_dim + 3) & ~3
-        self.kp_c = (self.sobs_dim + 3) & ~3
-
-        def padded(blocks, k, kp):
-            ws = [d(b[0][0].weight) for b in blocks]
-            if kp == k:
-                return ws
-            w = torch.zeros(len(blocks), self.hidden, kp, device=dev)
-            w[:, :, :k] = torch.stack(ws)
-            return list(w.unbind(0))
-        self._w1_a = padded(self.a_blocks, self.obs_dim, self.kp_a)
-        self._w1_c = padded(self.c_blocks, self.sobs_dim, self.kp_c)
+        for fn, args, what, _ in D["calls"]:
+            _lib.check(fn(*args, stream), None, what, L)
+        d = lambda t: t.detach()
+        if self.kp_a != self.obs_dim:
+            torch._foreach_copy_([D["w1_a"][i, :, :self.obs_dim] for i in range(self.n)], [d(b[0][0].weight) for b in self.a_blocks])
+        if self.kp_c != self.sobs_dim:
+            torch._foreach_copy_([D["w1_c"][i, :, :self.sobs_dim] for i in range(self.n)], [d(b[0][0].weight) for b in self.c_blocks])
         heads = [a.act.action_out for a in self.actors]
-        self._std = [(torch.sigmoid(d(hd.log_std) / hd.std_x_coef) * hd.std_y_coef).float().contiguous() for hd in heads]   # distributions.py:116
-        # folded form of hidden layer l >= 1 behind LayerNorm l - 1: W (LN(h) gamma + beta) + b = rstd (W~ h - mean s) + c
-        self._fold = {}
-        both = self.a_blocks + self.c_blocks
-        for l in range(1, self.depth):
-            W = torch.stack([d(b[l][0].weight) for b in both])                         # [2n, H, H]
-            gam = torch.stack([d(b[l - 1][1].weight) for b in both])                   # [2n, H]
-            bet = torch.stack([d(b[l - 1][1].bias) for b in both])
-            bias = torch.stack([d(b[l][0].bias) for b in both])
-            Wt = (W * gam[:, None, :]).contiguous()
-            self._fold[l] = (Wt, Wt.sum(-1).contiguous(), (torch.einsum("gnk,gk->gn", W, bet) + bias).contiguous())
-        # the critics' first layer behind the feature LayerNorm of the centralised observation, folded the same way: the raw
-        # share_obs rows are read where they lie (every critic of an env reads the SAME rows: one statistics pass, no normalised copies)
-        self._fold_c1 = None
-        if self.sobs_dim % 4 == 0:
-            W = torch.stack([d(b[0][0].weight) for b in self.c_blocks])
-            gam = torch.stack([d(c.base.feature_norm.weight) for c in self.critics])
-            bet = torch.stack([d(c.base.feature_norm.bias) for c in self.critics])
-            bias = torch.stack([d(b[0][0].bias) for b in self.c_blocks])
-            Wt = (W * gam[:, None, :]).contiguous()
-            self._fold_c1 = (Wt, Wt.sum(-1).contiguous(), (torch.einsum("gnk,gk->gn", W, bet) + bias).contiguous())
-        self._refresh_split()
-        self._bind()
+        t = torch._foreach_div([d(hd.log_std).float() for hd in heads], [float(hd.std_x_coef) for hd in heads])
+        torch._foreach_sigmoid_(t)
+        torch._foreach_mul_(t, [float(hd.std_y_coef) for hd in heads])                     # distributions.py:116
+        torch._foreach_copy_(list(D["std"].unbind(0)), t)
+        if self.p is None:
+            self._bind()
+        self._fill_scales()
 
-    def _refresh_split(self):
-        """Derived copies of the split path: the actors' first layer folded with their feature LayerNorm, the output heads folded with
-        the last LayerNorm, and the P32 planes of every (folded) weight matrix."""
-        self._sp = None
-        H, n, d = self.hidden, self.n, (lambda t: t.detach())
-        if not (self.split_layers and self.fold_layernorm and self._fold_c1 is not None and H % 128 == 0):
+    def _fill_scales(self):
+        """The hidden activations' power-of-two scales of the two-plane path: one value per network and layer (scale1), and -- once a batch
+        size has buffers -- the per-row arrays the layer kernel reads."""
+        D = self._D
+        if not (D and D["split"] and self.split_format == "f16x2"):
             return
         L, idx, stream = _lib.for_device(self.device)
-        W = torch.stack([d(b[0][0].weight) for b in self.a_blocks])
-        gam = torch.stack([d(a.base.feature_norm.weight) for a in self.actors])
-        bet = torch.stack([d(a.base.feature_norm.bias) for a in self.actors])
-        bias = torch.stack([d(b[0][0].bias) for b in self.a_blocks])
-        Wt = (W * gam[:, None, :]).contiguous()
-        fold_a1 = (Wt, Wt.sum(-1).contiguous(), (torch.einsum("gnk,gk->gn", W, bet) + bias).contiguous())
-        last = self.depth - 1
-        both = self.a_blocks + self.c_blocks
-        A = self.act_dim
-        hw = torch.zeros(2 * n, A, H, device=self.device)                              # critics: row 0 = v_out, the rest zero
-        hb = torch.zeros(2 * n, A, device=self.device)
-        for i, a in enumerate(self.actors):
-            hw[i], hb[i] = d(a.act.action_out.fc_mean.weight), d(a.act.action_out.fc_mean.bias)
-        for i, c in enumerate(self.critics):
-            hw[n + i, :1], hb[n + i, :1] = d(c.v_out.weight), d(c.v_out.bias)
-        g_last = torch.stack([d(b[last][1].weight) for b in both])
-        b_last = torch.stack([d(b[last][1].bias) for b in both])
-        hwt = (hw * g_last[:, None, :]).contiguous()
-        heads = (hwt, hwt.sum(-1).contiguous(), (torch.einsum("gjk,gk->gj", hw, b_last) + hb).contiguous())
-
-        h16 = self.split_format == "f16x2"
-        up = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-
-        def planes(Wg):                                                                 # [G, N, K] -> G plane tensors (+ G inverse row scales)
-            G, N, K = Wg.shape
-            out = [torch.empty(N * ((K + 31) // 32) * (128 if h16 else 192), dtype=torch.uint8, device=self.device) for _ in range(G)]
-            inv = torch.empty(G, N, device=self.device) if h16 else None
-            scr = torch.empty(G, N, device=self.device) if h16 else None
-            for lo in range(0, G, 32):
-                src, dst = [Wg[g] for g in range(lo, min(lo + 32, G))], out[lo:lo + 32]
-                if h16:
-                    _lib.check(L.mms_split_planes16_group(idx, len(src), N, K, 0, _ptrs(src), up(dst), up(list(scr[lo:lo + 32].unbind(0))),
-                                                          up(list(inv[lo:lo + 32].unbind(0))), 0, 0, None, None, None, None, 0.0, stream), None, "mms_split_planes16_group", L)
-                else:
-                    _lib.check(L.mms_split_planes_group(idx, len(src), N, K, 0, _ptrs(src), up(dst), stream), None, "mms_split_planes_group", L)
-            return (out, inv) if h16 else out
-
-        def out_scale(fold):                                                            # [G] power of two: the layer's output bound at 2^14
-            Wt, _, cv = fold
-            bound = ((Wt.pow(2).sum(-1).sqrt() * float(Wt.shape[-1]) ** 0.5 + cv.abs()).max(-1).values * 1.001).clamp_min(1e-30)
-            return torch.exp2(14.0 - torch.frexp(bound)[1].float())
-        self._sp = {"a1": fold_a1, "heads": heads, "w_a1": planes(fold_a1[0]), "w_c1": planes(self._fold_c1[0]),
-                    "w": {l: planes(self._fold[l][0]) for l in self._fold}}
-        if h16:
-            # output scales per layer over the 2n networks (actors first): layer 0 = the two first layers, l >= 1 = the H x H layers
-            self._sp["ysc"] = {0: torch.cat([out_scale(fold_a1), out_scale(self._fold_c1)])}
-            for l in self._fold:
-                self._sp["ysc"][l] = out_scale(self._fold[l])
+        n = self.n
+        have_rows = self._M is not None and getattr(self, "ysc", None) is not None
+        up = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+        for l, rbs in D["scale_jobs"]:
+            ysc = list(self.ysc[l].unbind(0)) if have_rows else [None] * (2 * n)
+            yinv = list(self.yinv[l].unbind(0)) if have_rows else [None] * (2 * n)
+            _lib.check(L.mms_fold_scales16_group(idx, 2 * n, up(rbs), (ctypes.c_int32 * (2 * n))(*([self.hidden] * (2 * n))), self._M if have_rows else 0,
+                                                 up(list(D["scale1"][l].unbind(0))), up(ysc), up(yinv), stream), None, "mms_fold_scales16_group", L)
 
     def _param_versions(self):
         """(data_ptr, version) of every source parameter: what the derived copies of refresh() were built from"""
@@ -260,10 +294,13 @@ class GroupedPolicyInference:
             for c in self._chunks:
                 c._ensure_fresh()
         elif self._versions != self._param_versions():
+            if tuple(v[0] for v in self._versions) != tuple(v[0] for v in self._param_versions()):
+                self._D, self.p, self._M = None, None, None          # the parameters moved: every cached address is void
             self.refresh()
 
     def _bind(self):
         d = lambda t: t.detach()
+        D = self._D
         A, C = self.a_blocks, self.c_blocks
         fa = [a.base.feature_norm for a in self.actors]
         fc = [c.base.feature_norm for c in self.critics]
@@ -273,6 +310,10 @@ class GroupedPolicyInference:
             ts = [None if t is None else t for t in ts]
             self._keep.append(ts)
             return _ptrs(ts)
+        ub = lambda t: list(t.unbind(0))
+        self._w1_a = ub(D["w1_a"]) if self.kp_a != self.obs_dim else [d(b[0][0].weight) for b in A]
+        self._w1_c = ub(D["w1_c"]) if self.kp_c != self.sobs_dim else [d(b[0][0].weight) for b in C]
+        self._std = ub(D["std"])
         self.p = {
             "fn_a_g": arr([d(m.weight) for m in fa]), "fn_a_b": arr([d(m.bias) for m in fa]),
             "fn_c_g": arr([d(m.weight) for m in fc]), "fn_c_b": arr([d(m.bias) for m in fc]),
@@ -286,32 +327,35 @@ class GroupedPolicyInference:
             if l > 0:
                 self.p["w%d" % l] = arr([d(b[l][0].weight) for b in both])
                 self.p["b%d" % l] = arr([d(b[l][0].bias) for b in both])
+        self._fold = {l: (st["wt"], st["s"], st["c"]) for l, st in D["fold"].items()}
         for l, (Wt, sv, cv) in self._fold.items():
-            self.p["fw%d" % l], self.p["fs%d" % l], self.p["fc%d" % l] = arr(list(Wt.unbind(0))), arr(list(sv.unbind(0))), arr(list(cv.unbind(0)))
-        if self._fold_c1 is not None:
-            Wt, sv, cv = self._fold_c1
-            self.p["fw1_c"], self.p["fs1_c"], self.p["fc1_c"] = arr(list(Wt.unbind(0))), arr(list(sv.unbind(0))), arr(list(cv.unbind(0)))
+            self.p["fw%d" % l], self.p["fs%d" % l], self.p["fc%d" % l] = arr(ub(Wt)), arr(ub(sv)), arr(ub(cv))
+        self._fold_c1 = None
+        if D["c1"] is not None:
+            st = D["c1"]
+            self._fold_c1 = (st["wt"], st["s"], st["c"])
+            self.p["fw1_c"], self.p["fs1_c"], self.p["fc1_c"] = arr(ub(st["wt"])), arr(ub(st["s"])), arr(ub(st["c"]))
         heads = [a.act.action_out.fc_mean for a in self.actors]
         vouts = [c.v_out for c in self.critics]
         self.p["hw"] = arr([d(m.weight) for m in heads] + [d(m.weight) for m in vouts])
         self.p["hb"] = arr([d(m.bias) for m in heads] + [d(m.bias) for m in vouts])
         self.p["std"] = arr(self._std + [None] * self.n)
         self.p["std_none"] = arr([None] * (2 * self.n))
-        if self._sp is not None:
-            sp = self._sp
-            up = lambda ts: (self._keep.append(ts), (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]))[1]
+        self._sp = None
+        if D["split"]:
             h16 = self.split_format == "f16x2"
-            pl_of = (lambda v: v[0]) if h16 else (lambda v: v)
-            self.p["sw_a1"], self.p["sw_c1"] = up(pl_of(sp["w_a1"])), up(pl_of(sp["w_c1"]))
-            self.p["fs1_a"], self.p["fc1_a"] = arr(list(sp["a1"][1].unbind(0))), arr(list(sp["a1"][2].unbind(0)))
-            for l, pl in sp["w"].items():
-                self.p["sw%d" % l] = up(pl_of(pl))
+            up = lambda ts: (self._keep.append(ts), (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]))[1]
+            self._sp = {"a1": D["a1"], "heads": D["heads"], "scale1": D.get("scale1")}
+            self.p["sw_a1"], self.p["sw_c1"] = up(D["a1"]["planes"]), up(D["c1"]["planes"])
+            self.p["fs1_a"], self.p["fc1_a"] = arr(ub(D["a1"]["s"])), arr(ub(D["a1"]["c"]))
+            for l, st in D["fold"].items():
+                self.p["sw%d" % l] = up(st["planes"])
             if h16:
-                self.p["swi_a1"], self.p["swi_c1"] = arr(list(sp["w_a1"][1].unbind(0))), arr(list(sp["w_c1"][1].unbind(0)))
-                for l, pl in sp["w"].items():
-                    self.p["swi%d" % l] = arr(list(pl[1].unbind(0)))
-            self._M = None                                        # (the per-row output scales of _buffers are built from this refresh's bounds)
-            self.p["hwt"], self.p["hs"], self.p["hc"] = arr(list(sp["heads"][0].unbind(0))), arr(list(sp["heads"][1].unbind(0))), arr(list(sp["heads"][2].unbind(0)))
+                self.p["swi_a1"], self.p["swi_c1"] = arr(ub(D["a1"]["inv"])), arr(ub(D["c1"]["inv"]))
+                for l, st in D["fold"].items():
+                    self.p["swi%d" % l] = arr(ub(st["inv"]))
+            hd = D["heads"]
+            self.p["hwt"], self.p["hs"], self.p["hc"] = arr(ub(hd["wt"])), arr(ub(hd["s"])), arr(ub(hd["c"]))
         self._A = (ctypes.c_int32 * (2 * self.n))(*([self.act_dim] * self.n + [1] * self.n))
         self._A1 = (ctypes.c_int32 * self.n)(*([1] * self.n))
         self._Aa = (ctypes.c_int32 * self.n)(*([self.act_dim] * self.n))
@@ -361,8 +405,8 @@ class GroupedPolicyInference:
                 # row scales of the raw inputs (written by the split) and of the hidden activations (constants of the refresh, one per
                 # network and layer, laid out per row because that is what the kernel reads)
                 self.xs_a, self.xi_a, self.xs_c, self.xi_c = z(n, M), z(n, M), z(n, M), z(n, M)
-                self.ysc = {l: v[:, None].expand(2 * n, M).contiguous() for l, v in self._sp["ysc"].items()}
-                self.yinv = {l: (1.0 / v) for l, v in self.ysc.items()}
+                self.ysc = {l: z(2 * n, M) for l in self._sp["scale1"]}
+                self.yinv = {l: z(2 * n, M) for l in self._sp["scale1"]}
                 self.q.update({"xs_a": _ptrs(ub(self.xs_a)), "xi_a": _ptrs(ub(self.xi_a)), "xs_c": _ptrs(ub(self.xs_c)), "xi_c": _ptrs(ub(self.xi_c)),
                                "xi_c0": _ptrs([self.xi_c[0]] * n)})
                 for l in self.ysc:
@@ -370,6 +414,7 @@ class GroupedPolicyInference:
                 self.q["ysc0_a"], self.q["yinv0_a"] = _ptrs(ub(self.ysc[0][:n])), _ptrs(ub(self.yinv[0][:n]))
         _critic_halves(self.q, n)
         self._M = M
+        self._fill_scales()
 
     # -- the split path ---------------------------------------------------------------------------------------------------------
     def _split_applies(self, M, sobs_pitch):

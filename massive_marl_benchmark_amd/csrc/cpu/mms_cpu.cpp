@@ -727,6 +727,80 @@ MMS_API int mms_chain_refresh16(int device, int32_t nchains, int32_t L, const fl
     return 0;
 }
 
+// The folded-LayerNorm layers' weight side (csrc/fold16_kernels.hip; include/mms.h)
+MMS_API int mms_fold_planes16_group(int device, int32_t groups, const int64_t* N, const int32_t* K, const float* const* w, const float* const* gamma,
+                                    const float* const* beta, const float* const* bias, void* const* planes, float* const* inv, float* const* s_out,
+                                    float* const* c_out, float* const* rb, float* const* wt, void*) {
+    if (cpu_only(device)) return 1;
+    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_fold_planes16_group: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
+    if (!N || !K || !w) { g_error = "mms_fold_planes16_group: bad arguments (null array)"; return 1; }
+    for (int g = 0; g < groups; g++) {
+        if (N[g] < 0 || K[g] <= 0) { g_error = "mms_fold_planes16_group: bad shape in a group (N >= 0, K > 0)"; return 1; }
+        if (!w[g] || (planes && planes[g] && (!inv || !inv[g]))) {
+            g_error = "mms_fold_planes16_group: null or misaligned pointer in a group (planes 16-byte aligned and with inv)";
+            return 1;
+        }
+    }
+    for (int g = 0; g < groups; g++) {
+        const int Kg = K[g], KC = (Kg + 31) / 32;
+        const float* gm = gamma ? gamma[g] : nullptr;
+        const float* bt = beta ? beta[g] : nullptr;
+        uint16_t* out = planes ? (uint16_t*)planes[g] : nullptr;
+#pragma omp parallel for schedule(static)
+        for (int64_t r = 0; r < N[g]; r++) {
+            const float* wr = w[g] + r * Kg;
+            float big = 0.f, s = 0.f, c = 0.f, l2 = 0.f;
+            for (int k = 0; k < Kg; k++) {
+                const float v = gm ? wr[k] * gm[k] : wr[k];
+                big = fmaxf(big, fabsf(v));
+                s += v;
+                l2 += v * v;
+                if (bt) c += wr[k] * bt[k];
+            }
+            if (bias && bias[g]) c += bias[g][r];
+            float sc, iv;
+            pow2_scale(big, sc, iv);
+            for (int kc = 0; kc < KC && out; kc++) {
+                uint16_t* ch = out + (r * KC + kc) * 64;
+                for (int j = 0; j < 32; j++) {
+                    const int k = kc * 32 + j;
+                    split2(k < Kg ? (gm ? wr[k] * gm[k] : wr[k]) * sc : 0.f, ch + j, ch + 32 + j);
+                }
+            }
+            if (wt && wt[g])
+                for (int k = 0; k < Kg; k++) wt[g][r * Kg + k] = gm ? wr[k] * gm[k] : wr[k];
+            if (inv && inv[g]) inv[g][r] = iv;
+            if (s_out && s_out[g]) s_out[g][r] = s;
+            if (c_out && c_out[g]) c_out[g][r] = c;
+            if (rb && rb[g]) rb[g][r] = sqrtf(l2) * sqrtf((float)Kg) + fabsf(c);
+        }
+    }
+    return 0;
+}
+
+MMS_API int mms_fold_scales16_group(int device, int32_t groups, const float* const* rb, const int32_t* n, int64_t M, float* const* scale1,
+                                    float* const* ysc, float* const* yinv, void*) {
+    if (cpu_only(device)) return 1;
+    if (groups < 1 || groups > MMS_MAX_GROUPS) { g_error = "mms_fold_scales16_group: groups must be 1.." + std::to_string(MMS_MAX_GROUPS); return 1; }
+    if (!rb || !n || M < 0) { g_error = "mms_fold_scales16_group: bad arguments"; return 1; }
+    for (int g = 0; g < groups; g++)
+        if (!rb[g] || n[g] < 0) { g_error = "mms_fold_scales16_group: null pointer or negative count in a group"; return 1; }
+    for (int g = 0; g < groups; g++) {
+        float m = 0.f;
+        for (int i = 0; i < n[g]; i++) m = fmaxf(m, rb[g][i]);
+        float bound = m * 1.001f;
+        if (!(bound > 1e-30f)) bound = 1e-30f;
+        float sc, iv;
+        pow2_scale(bound, sc, iv);
+        if (scale1 && scale1[g]) scale1[g][0] = sc;
+        for (int64_t r = 0; r < M; r++) {
+            if (ysc && ysc[g]) ysc[g][r] = sc;
+            if (yinv && yinv[g]) yinv[g][r] = iv;
+        }
+    }
+    return 0;
+}
+
 MMS_API int mms_linear_group_act_split16(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x, const void* const* w,
                                          const float* const* b, void* const* y, const float* const* x_inv, const float* const* w_inv,
                                          const float* const* y_scale, int32_t act, int32_t out_mode, const float* const* ln_s,

@@ -656,6 +656,47 @@ __attribute__((visibility("default"))) int mms_chain_refresh16(int device, int32
     return 0;
 }
 
+// ---- the folded-LayerNorm layers' weight side, refreshed on the device (fold16_kernels.hip) ------------------------------------
+__attribute__((visibility("default"))) int mms_fold_planes16_group(int device, int32_t groups, const int64_t* N, const int32_t* K, const float* const* w,
+                                                                   const float* const* gamma, const float* const* beta, const float* const* bias,
+                                                                   void* const* planes, float* const* inv, float* const* s_out, float* const* c_out,
+                                                                   float* const* rb, float* const* wt, void* s) {
+    MMS_DEV(device)
+    if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_fold_planes16_group: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
+    if (!N || !K || !w) { g_create_error = "mms_fold_planes16_group: bad arguments (null array)"; return 1; }
+    mms::FoldPlanesArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (N[g] < 0 || K[g] <= 0) { g_create_error = "mms_fold_planes16_group: bad shape in a group (N >= 0, K > 0)"; return 1; }
+        if (!w[g] || (planes && planes[g] && (!inv || !inv[g])) || (planes && (reinterpret_cast<uintptr_t>(planes[g]) & 15) != 0)) {
+            g_create_error = "mms_fold_planes16_group: null or misaligned pointer in a group (planes 16-byte aligned and with inv)";
+            return 1;
+        }
+        a.w[g] = w[g];
+        a.gamma[g] = gamma ? gamma[g] : nullptr; a.beta[g] = beta ? beta[g] : nullptr; a.bias[g] = bias ? bias[g] : nullptr;
+        a.planes[g] = planes ? planes[g] : nullptr; a.inv[g] = inv ? inv[g] : nullptr;
+        a.s[g] = s_out ? s_out[g] : nullptr; a.c[g] = c_out ? c_out[g] : nullptr; a.rb[g] = rb ? rb[g] : nullptr; a.wt[g] = wt ? wt[g] : nullptr;
+        a.rows_g[g] = N[g]; a.K_g[g] = K[g];
+    }
+    MMS_FREE(mms::launch_fold_planes16(a, groups, (hipStream_t)s));
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_fold_scales16_group(int device, int32_t groups, const float* const* rb, const int32_t* n, int64_t M,
+                                                                   float* const* scale1, float* const* ysc, float* const* yinv, void* s) {
+    MMS_DEV(device)
+    if (groups < 1 || groups > mms::kMaxGroups) { g_create_error = "mms_fold_scales16_group: groups must be 1.." + std::to_string(mms::kMaxGroups); return 1; }
+    if (!rb || !n || M < 0) { g_create_error = "mms_fold_scales16_group: bad arguments"; return 1; }
+    mms::FoldScalesArgs a = {};
+    for (int g = 0; g < groups; g++) {
+        if (!rb[g] || n[g] < 0) { g_create_error = "mms_fold_scales16_group: null pointer or negative count in a group"; return 1; }
+        a.rb[g] = rb[g]; a.n[g] = n[g];
+        a.scale1[g] = scale1 ? scale1[g] : nullptr; a.ysc[g] = ysc ? ysc[g] : nullptr; a.yinv[g] = yinv ? yinv[g] : nullptr;
+    }
+    a.M = M;
+    MMS_FREE(mms::launch_fold_scales16(a, groups, (hipStream_t)s));
+    return 0;
+}
+
 __attribute__((visibility("default"))) int mms_linear_group_act_split16(int device, int32_t groups, int64_t M, int32_t N, int32_t K, const void* const* x,
                                                                         const void* const* w, const float* const* b, void* const* y,
                                                                         const float* const* x_inv, const float* const* w_inv, const float* const* y_scale,
@@ -729,6 +770,10 @@ __attribute__((visibility("default"))) int mms_marl_heads_finish(int device, int
     for (int g = 0; g < groups; g++) {
         if (!part[g] || !head_part[g] || !hs[g] || !hc[g] || !out[g] || A[g] < 1 || A[g] > 16) {
             g_create_error = "mms_marl_heads_finish: null pointer or output width outside 1..16 in a group";
+            return 1;
+        }
+        if ((reinterpret_cast<uintptr_t>(head_part[g]) & 15) != 0 || (reinterpret_cast<uintptr_t>(part[g]) & 7) != 0) {
+            g_create_error = "mms_marl_heads_finish: head_part must be 16-byte aligned and part 8-byte aligned (read as float4 / float2)";
             return 1;
         }
         a.part[g] = part[g]; a.head_part[g] = head_part[g]; a.hs[g] = hs[g]; a.hc[g] = hc[g]; a.out[g] = out[g];

@@ -189,6 +189,37 @@ struct ChainRefreshArgs {
     float* chain_inv;
 };
 
+// The weights' side of a layer behind a folded LayerNorm (fold16_kernels.hip): per network g and row n of w_g [rows_g, K_g]
+//   W~[n, k] = w[n, k] gamma[k] (gamma NULL: w itself), planes_g / inv_g = its H32 planes and inverse row scales (planes NULL: none),
+//   wt_g = W~ as f32 (NULL: not stored), s_g[n] = sum_k W~[n, k], c_g[n] = sum_k w[n, k] beta[k] + bias[n] (beta / bias NULL: without),
+//   rb_g[n] = |W~ row|_2 sqrt(K) + |c[n]|: the row's bound of W~ xhat + c over normalised inputs (|xhat|_2 <= sqrt(K)).
+struct FoldPlanesArgs {
+    const float* w[kMaxGroups];
+    const float* gamma[kMaxGroups];
+    const float* beta[kMaxGroups];
+    const float* bias[kMaxGroups];
+    void* planes[kMaxGroups];
+    float* inv[kMaxGroups];
+    float* s[kMaxGroups];
+    float* c[kMaxGroups];
+    float* rb[kMaxGroups];
+    float* wt[kMaxGroups];
+    int64_t rows_g[kMaxGroups];
+    int K_g[kMaxGroups];
+};
+
+// Per network g: scale = 2^(14 - e), 1.001 max_{i < n[g]} rb_g[i] <= 2^e -> scale1[g][0] (optional) and ysc[g][0..M) / yinv[g][0..M) = 1 / scale
+struct FoldScalesArgs {
+    const float* rb[kMaxGroups];
+    float* scale1[kMaxGroups];
+    float* ysc[kMaxGroups];
+    float* yinv[kMaxGroups];
+    int n[kMaxGroups];
+    int64_t M;
+};
+
+hipError_t launch_fold_planes16(const FoldPlanesArgs& a, int groups, hipStream_t s);
+hipError_t launch_fold_scales16(const FoldScalesArgs& a, int groups, hipStream_t s);
 hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, hipStream_t s);
 hipError_t launch_chain_refresh16(const ChainRefreshArgs& a, hipStream_t s);
 hipError_t launch_linear_split16(const Split16LinearArgs& a, int groups, hipStream_t s);

@@ -57,8 +57,7 @@ __global__ void __launch_bounds__(256) gae_ppo_kernel(const float* __restrict__ 
 // The one-rank form of the two steps (nothing to all-reduce in between), bit-reproducible and with nothing to zero beforehand: the scan
 // leaves per-block partial sums in a scratch area (no atomics; the atomics of gae_ppo_kernel need a 24-byte memset that the runtime
 // turns into two fill kernels, ~9.5 us inside a captured rollout), and EVERY block of the normalisation sums the partials in the same
-// fixed order before it normalises its share.  stats = f64 [3 + 2 * kGaeMaxBlocks]: {sum, sum of squares, count}, then the partials.
-constexpr int kGaeMaxBlocks = 2048;
+// fixed order before it normalises its share.  stats = f64 [3 + 2 * 2048] (grid_for caps the blocks at 2048): {sum, sum of squares, count}, then the partials.
 __global__ void __launch_bounds__(256) gae_ppo_partials_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ dones,
                                                                const float* __restrict__ values, const float* __restrict__ last_values,
                                                                float* __restrict__ returns, float* __restrict__ advantages,
@@ -308,7 +307,7 @@ hipError_t launch_gae_ppo(const float* rewards, const uint8_t* dones, const floa
 }
 hipError_t launch_gae_ppo_normalized(const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
                                      float* advantages, double* stats, int T, int64_t N, float gamma, float lam, hipStream_t s) {
-    const int blocks = grid_for(N);                                        // <= kGaeMaxBlocks partial pairs
+    const int blocks = grid_for(N);                                        // <= 2048 partial pairs
     hipLaunchKernelGGL(gae_ppo_partials_kernel, dim3(blocks), dim3(256), 0, s, rewards, dones, values, last_values, returns, advantages, stats, T, N, gamma, lam);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     const int64_t count = (int64_t)T * N;

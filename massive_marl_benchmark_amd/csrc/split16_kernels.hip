@@ -429,11 +429,15 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
         const int vnext = v + (int)gridDim.x;
         const bool has_next = vnext < total;
         const int nb0 = blast == 2 ? 0 : blast + 1, nb1 = nb0 == 2 ? 0 : nb0 + 1;
+        // (the next tile's first wait counts the vmcnt entries issued from here on: exactly these DMAs, then the kStores output stores --
+        //  the scheduling barriers keep the compiler from moving a store in front of the prefetch or a DMA behind the stores)
+        __builtin_amdgcn_sched_barrier(0);
         if (has_next) {                                                 // the next tile's first two slices into the two free buffers
             setup_tile(vnext);
             dma_slice(0, nb0);
             if (KC > 1) dma_slice(1, nb1);
         }
+        __builtin_amdgcn_sched_barrier(0);
         uint8_t* scr_base = lds + (G::SCRATCH_IN_BUF ? blast * G::BUF : 3 * G::BUF);
         const int act = a.act;
         // hi hi + 2^-11 cross, the operands' scales undone (powers of two: exact), bias, activation -- in place of the accumulators.

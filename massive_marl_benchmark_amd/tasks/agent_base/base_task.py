@@ -93,6 +93,11 @@ class BaseTask:
         if self.randomize and bool(self.reset_buf.any()):
             self.apply_randomizations(self.randomization_params)          # reset_idx does this (ten_ant.py:812-813)
         self.engine.step()
+        # the binding ends with the step: a later direct Engine.step() / post_step / reset_all, or a writer of engine.tensor("actions")
+        # (ActorCritic.bind_rollout(storage, engine.tensor("actions"))), finds the engine reading its own buffer again.  `self.actions`
+        # stays an ALIAS of the caller's tensor where the reference holds a clone (ten_ant.py:887): an in-place edit of that tensor
+        # after step() shows in task.actions
+        self.engine.bind_actions(None)
         self.frame_count += 1
         self.randomize_buf += 1
         if self.dr_randomizations.get('observations', None):

@@ -121,6 +121,13 @@ def check_abi_error_paths(L, device):
     fails(L.mms_weight_planes16_group(device, 1, n8, k8, one, one, (vp * 1)(None), one, None, None), contains="null")
     fails(L.mms_weight_planes16_group(device, 1, n8, (ctypes.c_int32 * 1)(0), one, one, one, one, None, None), contains="shape")
     fails(L.mms_weight_planes16_group(device, 1, None, k8, one, one, one, one, None, None), contains="null array")
+    fails(L.mms_fold_planes16_group(device, 0, n8, k8, one, None, None, None, None, None, None, None, None, None, None), contains="groups")
+    fails(L.mms_fold_planes16_group(device, 1, n8, k8, (vp * 1)(None), None, None, None, None, None, None, None, None, None, None), contains="null")
+    fails(L.mms_fold_planes16_group(device, 1, n8, k8, one, None, None, None, one, None, None, None, None, None, None), contains="with inv")
+    fails(L.mms_fold_planes16_group(device, 1, n8, (ctypes.c_int32 * 1)(0), one, None, None, None, None, None, None, None, None, None, None), contains="shape")
+    fails(L.mms_fold_scales16_group(device, 33, one, k8, 8, None, None, None, None), contains="groups")
+    fails(L.mms_fold_scales16_group(device, 1, one, (ctypes.c_int32 * 1)(-1), 8, None, None, None, None), contains="negative")
+    fails(L.mms_fold_scales16_group(device, 1, None, k8, 8, None, None, None, None), contains="bad arguments")
     c8 = (ctypes.c_int32 * 1)(8)
     fails(L.mms_chain_refresh16(device, 0, 1, one, None, c8, zp, 0.0, 0, None, None, None), contains="nchains")
     fails(L.mms_chain_refresh16(device, 8, 8, one, None, c8, zp, 0.0, 0, None, None, None), contains="nchains")

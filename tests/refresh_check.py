@@ -71,6 +71,53 @@ def check_refresh_entry_points(device):
     return {sh: t.cpu() for sh, t in zip(shapes, l1)}
 
 
+def check_fold_entry_points(device):
+    """mms_fold_planes16_group / mms_fold_scales16_group against the torch statement of the LayerNorm fold (W~ = W diag(gamma), s = W~ 1,
+    c = W beta + b, row bound |W~ row|_2 sqrt(K) + |c|) and against mms_split_planes16_group on W~ (planes, inverse scales: bit for bit)."""
+    dev = torch.device(device)
+    L, idx, stream = _lib.for_device(dev)
+    torch.manual_seed(3)
+    shapes = ((128, 46), (128, 388), (256, 256), (8, 128), (1, 128))
+    G = len(shapes)
+    w = [torch.randn(N, K).to(dev) for N, K in shapes]
+    gam = [(1.0 + 0.3 * torch.randn(K)).to(dev) for _, K in shapes]
+    bet = [(0.2 * torch.randn(K)).to(dev) for _, K in shapes]
+    bias = [torch.randn(N).to(dev) for N, _ in shapes]
+    planes = [torch.zeros(N * ((K + 31) // 32) * 128, dtype=torch.uint8, device=dev) for N, K in shapes]
+    inv, sv, cv, rb = ([torch.zeros(N, device=dev) for N, _ in shapes] for _ in range(4))
+    wt = [torch.zeros(N, K, device=dev) for N, K in shapes]
+    Ns, Ks = (ctypes.c_int64 * G)(*[N for N, _ in shapes]), (ctypes.c_int32 * G)(*[K for _, K in shapes])
+    assert L.mms_fold_planes16_group(idx, G, Ns, Ks, _arr(w), _arr(gam), _arr(bet), _arr(bias), _arr(planes), _arr(inv), _arr(sv), _arr(cv), _arr(rb), _arr(wt),
+                                     stream) == 0, _lib.last_error(None, L)
+    for g, (N, K) in enumerate(shapes):
+        Wt = w[g] * gam[g][None, :]
+        assert torch.equal(wt[g], Wt), (N, K)
+        ref_s, ref_c = Wt.double().sum(1), w[g].double() @ bet[g].double() + bias[g].double()
+        assert float((sv[g].double() - ref_s).abs().max()) < 1e-5 * (1.0 + float(Wt.abs().sum(1).max()))
+        assert float((cv[g].double() - ref_c).abs().max()) < 1e-5 * (1.0 + float(ref_c.abs().max()))
+        ref_rb = Wt.double().pow(2).sum(1).sqrt() * K ** 0.5 + ref_c.abs()
+        assert float(((rb[g].double() - ref_rb).abs() / ref_rb).max()) < 1e-5
+        p2, s2, i2 = torch.zeros_like(planes[g]), torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+        assert L.mms_split_planes16_group(idx, 1, N, K, 0, _arr([Wt.contiguous()]), _arr([p2]), _arr([s2]), _arr([i2]), 0, 0, None, None, None, None, 0.0, stream) == 0
+        assert torch.equal(planes[g], p2) and torch.equal(inv[g], i2), (N, K)
+    # without gamma / beta / bias: the plain matrix; optional outputs may be absent
+    s0 = [torch.zeros(N, device=dev) for N, _ in shapes]
+    assert L.mms_fold_planes16_group(idx, G, Ns, Ks, _arr(w), None, None, None, None, None, _arr(s0), None, None, None, stream) == 0, _lib.last_error(None, L)
+    for g in range(G):
+        assert float((s0[g].double() - w[g].double().sum(1)).abs().max()) < 1e-4
+    # the networks' output scales: 2^(14 - e) with 1.001 max rb <= 2^e, once and per row of the batch
+    M = 300
+    scale1 = [torch.zeros(1, device=dev) for _ in range(G)]
+    ysc, yinv = [torch.zeros(M, device=dev) for _ in range(G)], [torch.zeros(M, device=dev) for _ in range(G)]
+    assert L.mms_fold_scales16_group(idx, G, _arr(rb), (ctypes.c_int32 * G)(*[N for N, _ in shapes]), M, _arr(scale1), _arr(ysc), _arr(yinv), stream) == 0
+    for g in range(G):
+        bound = float(rb[g].max()) * 1.001
+        want = 2.0 ** (14 - (torch.frexp(torch.tensor(bound, dtype=torch.float32))[1].item()))
+        assert float(scale1[g]) == want and bool((ysc[g] == want).all()) and bool((yinv[g] == 1.0 / want).all()), (g, float(scale1[g]), want)
+        assert bound * want <= 2.0 ** 14
+    return {sh: t.cpu() for sh, t in zip(shapes, rb)}
+
+
 def check_module_refresh(device, hid=(128, 128), n=128, obs_dim=36):
     """Which parameter updates the fused layers follow, and when."""
     dev = torch.device(device)

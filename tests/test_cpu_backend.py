@@ -449,6 +449,7 @@ def test_obs_planes_from_the_step_on_cpu_build():
     check_obs_planes("cpu", task="OneAnt")
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/agents"), reason="the reference tree is not present on this machine (it does not travel to the GPU box)")
 def test_reference_learners_drop_in_unchanged(tmp_path):
     """The reference's real learners, imported in place and unmodified, over this build's VecTaskPython / MultiVecTaskPython on the
     CPU build: PPO.run (agents/algorithms/rl/ppo/ppo.py:99-175), Runner.run (agents/algorithms/marl/runner.py:114-151) as mappo, happo
@@ -468,8 +469,37 @@ def test_reference_learners_drop_in_unchanged(tmp_path):
 
 
 def test_refresh_entry_points_and_module_refresh_on_cpu_build():
-    """The device-side refresh of the f16x2 layers' weight planes / bound chain (mms_weight_planes16_group, mms_layer_bounds16,
-    mms_chain_scales16) and ActorCritic.refresh() on the CPU build: tests/refresh_check.py (the HIP build runs the same list)."""
+    """The device-side refresh of the f16x2 layers' weight planes / bound chain (mms_weight_planes16_group, mms_chain_refresh16),
+    of the folded-LayerNorm layers' weight side (mms_fold_planes16_group, mms_fold_scales16_group) and ActorCritic.refresh() on the CPU build: tests/refresh_check.py (the HIP build runs the same list)."""
     import refresh_check
     refresh_check.check_refresh_entry_points("cpu")
+    refresh_check.check_fold_entry_points("cpu")
     assert refresh_check.check_module_refresh("cpu") > 1e-3
+
+
+def test_task_step_leaves_no_action_binding():
+    """BaseTask.step binds the caller's action tensor for the launch only (mms_bind_actions; the reference clones it, ten_ant.py:887): a
+    direct Engine.step() behind it reads the engine's own "actions" buffer again -- the trajectory of task.step(a); write b into
+    engine.tensor("actions"); engine.step() equals that of an engine fed a, b through its buffer."""
+    from massive_marl_benchmark_amd.tasks.one_ant import OneAnt
+    cfg = default_cfg("OneAnt")
+    cfg["env"]["numEnvs"] = 8
+    cfg["seed"] = 5
+    g = torch.Generator().manual_seed(2)
+    a, b = (torch.rand(8, 8, generator=g) * 2 - 1 for _ in range(2))
+    task = OneAnt(cfg, None, "physx", "cpu", 0, True)
+    other = OneAnt(cfg, None, "physx", "cpu", 0, True)
+    for t in (task, other):
+        t.engine.reset_all()
+    keep = a.clone()
+    task.step(a)                                                      # binds `a`, steps, unbinds
+    a.fill_(123.0)                                                    # (the caller's tensor is the caller's again)
+    task.engine.tensor("actions").copy_(b)
+    task.engine.step()
+    for acts in (keep, b):
+        other.engine.tensor("actions").copy_(acts)
+        other.engine.step()
+    for name in ("root_states", "dof_state", "obs", "rew"):
+        assert torch.equal(task.engine.tensor(name), other.engine.tensor(name)), name
+    task.engine.close()
+    other.engine.close()
