@@ -199,7 +199,11 @@ class GroupedPolicyInference:
             return (L.mms_fold_planes16_group, (idx, len(w), i64(Ns), i32(Ks), up(w), up(gm), up(bt), up(bs), up(pl), up(iv), up(sv), up(cv), up(rb), up(wt)),
                     "mms_fold_planes16_group", keep)
 
-        need_wt = True                                         # (the exact-fp32 fold path reads W~ itself; the three-plane format splits it)
+        # W~ itself (f32) is read by the exact-fp32 fold path and split by the three-plane format; with the two-plane split path active it
+        # is not stored (a quarter of the refresh's traffic: 780 MB for the 100-ant swarm's critics) and batch sizes the split path does not
+        # take (not a multiple of 128) run the unfolded layers instead
+        need_wt = not (split and h16)
+        self._has_wt = need_wt
         fa = [a.base.feature_norm for a in self.actors]
         fc = [c.base.feature_norm for c in self.critics]
         firsts = []
@@ -213,8 +217,8 @@ class GroupedPolicyInference:
             D["c1"] = fold_set([b[0][0].weight for b in self.c_blocks], [m.weight for m in fc], [m.bias for m in fc], [b[0][0].bias for b in self.c_blocks],
                                H, self.sobs_dim, need_wt, split, split and h16)
             firsts.append(D["c1"])
-        if firsts:
-            D["calls"].append(fold_call(firsts))
+        for st in firsts:                                      # (one launch each: the 46-wide actor rows take the kernel's unaligned path)
+            D["calls"].append(fold_call([st]))
         for l in range(1, depth):
             D["fold"][l] = fold_set([b[l][0].weight for b in both], [b[l - 1][1].weight for b in both], [b[l - 1][1].bias for b in both],
                                     [b[l][0].bias for b in both], H, H, need_wt, split, split and h16 and l < depth - 1)
@@ -329,12 +333,16 @@ class GroupedPolicyInference:
                 self.p["b%d" % l] = arr([d(b[l][0].bias) for b in both])
         self._fold = {l: (st["wt"], st["s"], st["c"]) for l, st in D["fold"].items()}
         for l, (Wt, sv, cv) in self._fold.items():
-            self.p["fw%d" % l], self.p["fs%d" % l], self.p["fc%d" % l] = arr(ub(Wt)), arr(ub(sv)), arr(ub(cv))
+            self.p["fs%d" % l], self.p["fc%d" % l] = arr(ub(sv)), arr(ub(cv))
+            if Wt is not None:
+                self.p["fw%d" % l] = arr(ub(Wt))
         self._fold_c1 = None
         if D["c1"] is not None:
             st = D["c1"]
             self._fold_c1 = (st["wt"], st["s"], st["c"])
-            self.p["fw1_c"], self.p["fs1_c"], self.p["fc1_c"] = arr(ub(st["wt"])), arr(ub(st["s"])), arr(ub(st["c"]))
+            self.p["fs1_c"], self.p["fc1_c"] = arr(ub(st["s"])), arr(ub(st["c"]))
+            if st["wt"] is not None:
+                self.p["fw1_c"] = arr(ub(st["wt"]))
         heads = [a.act.action_out.fc_mean for a in self.actors]
         vouts = [c.v_out for c in self.critics]
         self.p["hw"] = arr([d(m.weight) for m in heads] + [d(m.weight) for m in vouts])
@@ -535,7 +543,7 @@ class GroupedPolicyInference:
             return values, actions, (None if deterministic else logp)
         chk(L.mms_layernorm_group(idx, n, M, self.obs_dim, self.kp_a, obs_pitch, obs_p, p["fn_a_g"], p["fn_a_b"], q["x_a"], self.eps, stream), "mms_layernorm_group")
         H = self.hidden
-        fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0 and self.kp_a >= 8
+        fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0 and self.kp_a >= 8 and self._has_wt
         fold_c1 = fold and self._fold_c1 is not None and sobs_pitch == self.sobs_dim and self.sobs_dim >= 8
         if not fold_c1:
             chk(L.mms_layernorm_group(idx, n, M, self.sobs_dim, self.kp_c, sobs_pitch, sobs_p, p["fn_c_g"], p["fn_c_b"], q["x_c"], self.eps, stream), "mms_layernorm_group")
@@ -656,7 +664,7 @@ class GroupedPolicyInference:
             vp, v_pitch = _row_ptrs(values)
             self._forward_split(L, idx, stream, M, None, 0, sobs_p, False, None, vp, None, (ctypes.c_int32 * n)(*([v_pitch] * n)), None)
             return values
-        fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0
+        fold = self.fold_layernorm and self.depth > 1 and M % 128 == 0 and H % 128 == 0 and self._has_wt
         fold_c1 = fold and self._fold_c1 is not None and sobs_pitch == self.sobs_dim and self.sobs_dim >= 8
         slots = H // 64
         if fold_c1:

@@ -31,6 +31,7 @@ __device__ __forceinline__ void fold_pow2_scale(float bound, float& scale, float
 
 // One wave per row (64 lanes walk the row's 8-element pieces, two passes as split16_planes_kernel), four rows per block,
 // blockIdx.y = network.  Matrices of different shapes in one launch (rows_g / K_g per network).
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256) fold_planes16_kernel(FoldPlanesArgs a) {
     const int g = blockIdx.y;
     const int K = a.K_g[g];
@@ -45,8 +46,13 @@ __global__ void __launch_bounds__(256) fold_planes16_kernel(FoldPlanesArgs a) {
     const float* __restrict__ gam = a.gamma[g];
     const float* __restrict__ bet = a.beta[g];
     auto load8 = [&](const float* src, int p, float* v, float fill) {
+        if (ALIGNED && p * 8 + 8 <= K) {                                 // (every row and vector 16-byte aligned: K a multiple of 4)
+            const float4 q0 = *reinterpret_cast<const float4*>(src + p * 8), q1 = *reinterpret_cast<const float4*>(src + p * 8 + 4);
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = (p * 8 + j < K) ? src[p * 8 + j] : fill;
+            for (int j = 0; j < 8; j++) v[j] = (p * 8 + j < K) ? src[p * 8 + j] : fill;
+        }
     };
     float big = 0.f, s = 0.f, c = 0.f, l2 = 0.f;
     for (int p = lane; p < pieces; p += 64) {
@@ -86,7 +92,18 @@ __global__ void __launch_bounds__(256) fold_planes16_kernel(FoldPlanesArgs a) {
             const float t = wt * scale;
             hi[j] = (_Float16)t;
             lo[j] = (_Float16)((t - (float)hi[j]) * 2048.f);
-            if (wt_out && live && p * 8 + j < K) wt_out[row * (int64_t)K + p * 8 + j] = wt;
+            if (!ALIGNED && wt_out && live && p * 8 + j < K) wt_out[row * (int64_t)K + p * 8 + j] = wt;
+            v[j] = wt;
+        }
+        if (ALIGNED && wt_out && live) {
+            float* dst = wt_out + row * (int64_t)K + p * 8;
+            if (p * 8 + 8 <= K) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (p * 8 + j < K) dst[j] = v[j];
+            }
         }
         if (out && live) {
             uint8_t* dst = out + (row * KC + (p >> 2)) * (int64_t)128 + (p & 3) * 16;
@@ -110,7 +127,14 @@ hipError_t launch_fold_planes16(const FoldPlanesArgs& a, int groups, hipStream_t
         blocks = need > blocks ? need : blocks;
     }
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(fold_planes16_kernel, dim3(blocks, groups), dim3(256), 0, s, a);
+    bool aligned = true;
+    for (int g = 0; g < groups; g++) {
+        uintptr_t bits = reinterpret_cast<uintptr_t>(a.w[g]) | reinterpret_cast<uintptr_t>(a.gamma[g]) | reinterpret_cast<uintptr_t>(a.beta[g]) |
+                         reinterpret_cast<uintptr_t>(a.wt[g]);
+        aligned = aligned && (a.K_g[g] % 4) == 0 && (bits & 15) == 0;
+    }
+    if (aligned) hipLaunchKernelGGL(fold_planes16_kernel<true>, dim3(blocks, groups), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(fold_planes16_kernel<false>, dim3(blocks, groups), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
