@@ -85,7 +85,9 @@ class BaseTask:
                 and a.numel() == self._actions.numel() and a.data_ptr() % 8 == 0):
             self.engine.bind_actions(a)
             self.actions = a.view(self._actions.shape)
+            self.actions_read_in_place = True                         # (this step's launch reads the caller's tensor; tests look at it)
         else:
+            self.actions_read_in_place = False
             self.engine.bind_actions(None)
             if a.data_ptr() != self._actions.data_ptr():
                 self._actions.copy_(a.reshape(self._actions.shape))

@@ -580,7 +580,7 @@ def test_vec_wrappers(torch_cuda):
         if t == 7:
             a = a.t().contiguous().t()                            # not contiguous: copy
         o2, r2, d2, _ = env2.step(a)
-        assert (task2.engine._bound_actions is None) == (t in (5, 7))
+        assert task2.actions_read_in_place == (t not in (5, 7)) and task2.engine._bound_actions is None      # (the binding ends with the step)
         ref.tensor("actions").copy_(a.float())
         ref.step()
         torch.cuda.synchronize()
