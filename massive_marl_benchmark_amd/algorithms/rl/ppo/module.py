@@ -426,6 +426,7 @@ class ActorCritic(nn.Module):
         if self.split_format == "f16x2":
             return self._split_hidden16(nets, inputs, tag, planes)
         assert self.split_format == "bf16x3", self.split_format
+        self._ensure_fresh()                                # (the weights' P32 planes are re-split by refresh() too: stable buffers)
         x0 = inputs[0]
         dev, M, K = x0.device, x0.shape[0], x0.shape[1]
         L, idx, stream = _lib.for_device(dev)

@@ -195,12 +195,12 @@ hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, h
 // them; then the chain's scales for rows whose input bound is a CONSTANT (observation rows clamped to clip_obs, whose planes the step
 // kernel writes) -- the recurrence of split16_planes_kernel with b_0 = bound0, the same value for every row.
 __global__ void __launch_bounds__(256) chain_refresh16_kernel(ChainRefreshArgs a) {
-    __shared__ float s_part[2][4];
     __shared__ float s_chain[2 * kMaxGroups];
     const int E = a.nchains * a.L;
-    for (int e = 0; e < E; e++) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = wave; e < E; e += 4) {                                  // one wave per entry: the four entries of a PPO policy at once
         float m = 0.f, b = 0.f;
-        for (int i = threadIdx.x; i < a.n[e]; i += 256) {
+        for (int i = lane; i < a.n[e]; i += 64) {
             m = fmaxf(m, a.l1[e][i]);
             if (a.bias[e]) b = fmaxf(b, fabsf(a.bias[e][i]));
         }
@@ -208,14 +208,9 @@ __global__ void __launch_bounds__(256) chain_refresh16_kernel(ChainRefreshArgs a
             m = fmaxf(m, __shfl_xor(m, k, 64));
             b = fmaxf(b, __shfl_xor(b, k, 64));
         }
-        if ((threadIdx.x & 63) == 0) { s_part[0][threadIdx.x >> 6] = m; s_part[1][threadIdx.x >> 6] = b; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            s_chain[2 * e] = fmaxf(fmaxf(s_part[0][0], s_part[0][1]), fmaxf(s_part[0][2], s_part[0][3]));
-            s_chain[2 * e + 1] = fmaxf(fmaxf(s_part[1][0], s_part[1][1]), fmaxf(s_part[1][2], s_part[1][3]));
-        }
-        __syncthreads();
+        if (lane == 0) { s_chain[2 * e] = m; s_chain[2 * e + 1] = b; }
     }
+    __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < 2 * E) a.chain[threadIdx.x] = s_chain[threadIdx.x];
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= a.rows) return;

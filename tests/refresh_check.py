@@ -118,14 +118,18 @@ def check_fold_entry_points(device):
     return {sh: t.cpu() for sh, t in zip(shapes, rb)}
 
 
-def check_module_refresh(device, hid=(128, 128), n=128, obs_dim=36):
-    """Which parameter updates the fused layers follow, and when."""
+def check_module_refresh(device, hid=(128, 128), n=128, obs_dim=36, fmt="f16x2"):
+    """Which parameter updates the fused layers follow, and when (both plane formats)."""
     dev = torch.device(device)
     torch.manual_seed(5)
     cfg = {"pi_hid_sizes": list(hid), "vf_hid_sizes": list(hid), "activation": "elu"}
     ac = ActorCritic((obs_dim,), (0,), (8,), 0.8, cfg, seed=3).to(dev)
     ac.split_min_tiles = 0
+    ac.split_format = fmt
     obs, states = torch.randn(n, obs_dim, device=dev).clamp(-5, 5), torch.zeros(n, 0, device=dev)
+    h16 = fmt == "f16x2"
+    addresses = lambda: ([r["planes"].data_ptr() for rs in ac._h16["recs"] for r in rs] + [ac._h16["bounds"].data_ptr()]) if h16 else \
+        sorted(v[1].data_ptr() for v in ac._wplanes.values())
 
     def close(m=None):
         m = m or ac
@@ -138,8 +142,8 @@ def check_module_refresh(device, hid=(128, 128), n=128, obs_dim=36):
                 e = max(e, rel(mu, m.actor(obs)), rel(v, m.critic(obs)))
         return e
 
-    assert ac.split_format == "f16x2" and close() < 1e-5 and ac._split_bufs, "the split path did not run"
-    planes_addr = [r["planes"].data_ptr() for rs in ac._h16["recs"] for r in rs] + [ac._h16["bounds"].data_ptr()]
+    assert close() < 1e-5 and ac._split_bufs, "the split path did not run"
+    planes_addr = addresses()
     # 1. an optimizer step (in place: version counters move) is followed by the next act, unbound
     opt = torch.optim.SGD(ac.parameters(), lr=0.5)
     for q in ac.parameters():
@@ -164,10 +168,10 @@ def check_module_refresh(device, hid=(128, 128), n=128, obs_dim=36):
     assert close() < 1e-5
     ac.bind_rollout(None, None)
     # derived buffers never moved
-    assert planes_addr == [r["planes"].data_ptr() for rs in ac._h16["recs"] for r in rs] + [ac._h16["bounds"].data_ptr()]
+    assert planes_addr == addresses()
     # 4. a copy starts from its own parameters (no shared derived state), and follows its own updates
     twin = copy.deepcopy(ac)
-    assert twin._h16 is None and twin._calls is None
+    assert twin._h16 is None and twin._calls is None and twin._wplanes is None and twin.split_format == fmt
     with torch.no_grad():
         for q in twin.parameters():
             q.add_(0.2 * torch.randn_like(q))

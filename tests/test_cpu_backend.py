@@ -475,6 +475,7 @@ def test_refresh_entry_points_and_module_refresh_on_cpu_build():
     refresh_check.check_refresh_entry_points("cpu")
     refresh_check.check_fold_entry_points("cpu")
     assert refresh_check.check_module_refresh("cpu") > 1e-3
+    assert refresh_check.check_module_refresh("cpu", fmt="bf16x3") > 1e-3
 
 
 def test_task_step_leaves_no_action_binding():

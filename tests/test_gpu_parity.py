@@ -1599,6 +1599,7 @@ def test_refresh_entry_points_and_module_refresh(torch_cuda):
     for key in fold_gpu:                                              # the row bounds of the LayerNorm folds: the two builds sum in different orders
         assert float(((fold_gpu[key] - fold_cpu[key]).abs() / fold_cpu[key]).max()) < 1e-5, key
     stale = refresh_check.check_module_refresh("cuda", hid=(256, 128, 128), n=256, obs_dim=388)
+    assert refresh_check.check_module_refresh("cuda", hid=(256, 128, 128), n=256, obs_dim=388, fmt="bf16x3") > 1e-3
     parity.record("gpu/module_refresh", stale_error_without_refresh_after_data_write=stale)
 
 
