@@ -91,7 +91,7 @@ class ActorCritic(nn.Module):
     # for both networks) and both last layers inside the sampling kernel (mms_ppo_heads_act): five launches per `act`.  Used when
     # the networks qualify (fp32, ELU, actor and critic of the same hidden shapes, last hidden width a multiple of 64); otherwise
     # the library path below.  Rollout step at 4096 envs: 350 us, against 361 us for the library GEMMs + separate ELU passes with the
-    # critic on a second stream (profiles/r01_v12_*).  With fuse_layers off, fuse_head alone puts only the actor's last layer into
+    # critic on a second stream (profiles/r01_v12_bench.json, r01_v12_bench_library_gemms.json).  With fuse_layers off, fuse_head alone puts only the actor's last layer into
     # the sampling kernel (no gain next to the critic's GEMMs: 371.8 us against 365.5 us, profiles/r01_v8_rollout_ab.txt).
     fuse_layers = True
     # The hidden layers on the bf16 matrix pipe with fp32 operands carried as three bf16 planes (csrc/split_kernels.hip,
