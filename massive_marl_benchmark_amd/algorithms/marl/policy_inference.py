@@ -90,6 +90,7 @@ class GroupedPolicyInference:
         if len(actors) != len(critics) or not actors:
             raise ValueError("one actor and one critic per agent")
         self._chunks = None
+        self._plans = None
         if len(actors) > 16:
             # MMS_MAX_GROUPS = 32 networks per launch = 16 agents: more agents (the 100-ant swarm) run as chunks of sixteen, each its
             # own set of grouped launches.  The noise key of agent k stays seed + k however the agents are chunked.
@@ -143,7 +144,7 @@ class GroupedPolicyInference:
             raise NotImplementedError("GroupedPolicyInference: at most 16 actions, hidden size a multiple of 4 up to 1024")
         self.eps = float(self.actors[0].base.feature_norm.eps)
         self.device = self.actors[0].act.action_out.fc_mean.weight.device
-        self._M, self._D, self.p, self._versions = None, None, None, ()
+        self._M, self._D, self.p, self._versions, self._plans = None, None, None, (), None
         self.refresh()
 
     # -- parameters ---------------------------------------------------------------------------------------------------------------
@@ -299,7 +300,7 @@ class GroupedPolicyInference:
                 c._ensure_fresh()
         elif self._versions != self._param_versions():
             if tuple(v[0] for v in self._versions) != tuple(v[0] for v in self._param_versions()):
-                self._D, self.p, self._M = None, None, None          # the parameters moved: every cached address is void
+                self._D, self.p, self._M, self._plans = None, None, None, None      # the parameters moved: every cached address is void
             self.refresh()
 
     def _bind(self):
@@ -602,13 +603,59 @@ class GroupedPolicyInference:
         written straight into `shared.actions[step]`, `shared.action_log_probs[step]`, `shared.value_preds[step]`.  Returns the
         [N, agents, act_dim] action slot (what `shared.env_step` takes)."""
         s, n = shared.step, self.n
-        if s == 0 and self.refresh_every_rollout:
-            self.refresh()                                  # the trainers updated in between, possibly through .data (no version counter moves)
-        obs, sobs = shared.obs[s], shared.share_obs[s]
-        out = ([shared.value_preds[s][:, k:k + 1] for k in range(n)], [shared.actions[s][:, k] for k in range(n)],
-               [shared.action_log_probs[s][:, k] for k in range(n)])
-        self.get_actions([sobs] * n, [obs[:, k] for k in range(n)], deterministic=deterministic, out=out)
+        if self.refresh_every_rollout:
+            if s == 0:
+                self.refresh()                              # the trainers updated in between, possibly through .data (no version counter moves)
+        else:
+            self._ensure_fresh()                            # (inside a rollout the parameters stand still: no check per step otherwise)
+        # the marshalled operands of slot s (ten row views per buffer, their pointer arrays) are built once per (buffers, slot): what is
+        # left per call is the launches -- the eager collect step then stays ahead of the GPU like the captured one
+        key = (shared.obs.data_ptr(), shared.share_obs.data_ptr(), shared.actions.data_ptr(), shared.value_preds.data_ptr(), tuple(shared.obs.shape), s,
+               bool(deterministic))
+
+        def make():
+            obs, sobs = shared.obs[s], shared.share_obs[s]
+            out = ([shared.value_preds[s][:, k:k + 1] for k in range(n)], [shared.actions[s][:, k] for k in range(n)],
+                   [shared.action_log_probs[s][:, k] for k in range(n)])
+            return [sobs] * n, [obs[:, k] for k in range(n)], out
+        self._get_actions_planned(key, make, deterministic)
         return shared.actions[s]
+
+    def _get_actions_planned(self, key, make, deterministic):
+        """get_actions(share_obs, obs, deterministic, out) with (share_obs, obs, out) = make(), called only when `key` is new: the split
+        path's operand pointer arrays are cached under it (the caller vouches that the key names the tensors)."""
+        if self._plans is None:
+            self._plans = {}
+        plan = self._plans.get(key)
+        if plan is None:
+            share_obs, obs, out = make()
+            if self._chunks is not None:
+                plan = ("chunks", [(c, (lambda so=share_obs[lo:hi], ob=obs[lo:hi], ou=tuple(x[lo:hi] for x in out): (so, ob, ou)))
+                                   for c, (lo, hi) in zip(self._chunks, self._ranges)])
+            else:
+                M = obs[0].shape[0]
+                self._buffers(M)
+                f32 = lambda t: t.detach() if t.dtype == torch.float32 else t.detach().float()
+                obs_f, sobs_f = [f32(t) for t in obs], [f32(t) for t in share_obs]
+                obs_p, obs_pitch = _row_ptrs(obs_f)
+                sobs_p, sobs_pitch = _row_ptrs(sobs_f)
+                direct = all(a is b for a, b in zip(obs_f + sobs_f, list(obs) + list(share_obs)))      # (no converted temporaries in the pointer arrays)
+                if self._split_applies(M, sobs_pitch) and direct:
+                    plan = ("split", M, obs_p, obs_pitch, sobs_p) + tuple(self._out_ptrs(out)[3:]) + ((obs_f, sobs_f, out),)
+                else:
+                    plan = ("generic", share_obs, obs, out)
+            self._plans[key] = plan
+        if plan[0] == "chunks":
+            for c, mk in plan[1]:
+                c._get_actions_planned(key, mk, deterministic)
+        elif plan[0] == "generic":
+            self.get_actions(plan[1], plan[2], deterministic=deterministic, out=plan[3])
+        else:
+            _, M, obs_p, obs_pitch, sobs_p, out_p, logp_p, pitch, _keep = plan
+            self._buffers(M)
+            L, idx, stream = _lib.for_device(self.device)
+            self._forward_split(L, idx, stream, M, obs_p, obs_pitch, sobs_p, True, self.p["std_none"] if deterministic else self.p["std"], out_p, logp_p, pitch,
+                                self.q["cnt"])
 
     # collect_into refreshes at step 0 of every rollout (see the module docstring); False leaves only the version-counter check -- for
     # callers that never write parameters through .data and want the ~ms of derived-copy rebuilding only when an optimizer stepped
