@@ -91,6 +91,7 @@ class GroupedPolicyInference:
             raise ValueError("one actor and one critic per agent")
         self._chunks = None
         self._plans = None
+        self._plist = None
         if len(actors) > 16:
             # MMS_MAX_GROUPS = 32 networks per launch = 16 agents: more agents (the 100-ant swarm) run as chunks of sixteen, each its
             # own set of grouped launches.  The noise key of agent k stays seed + k however the agents are chunked.
@@ -292,7 +293,9 @@ class GroupedPolicyInference:
 
     def _param_versions(self):
         """(data_ptr, version) of every source parameter: what the derived copies of refresh() were built from"""
-        return tuple((q.data_ptr(), q._version) for m in self.actors + self.critics for q in m.parameters())
+        if self._plist is None:                                   # (walking twenty modules' parameter trees costs more than reading the counters)
+            self._plist = [q for m in self.actors + self.critics for q in m.parameters()]
+        return tuple((q.data_ptr(), q._version) for q in self._plist)
 
     def _ensure_fresh(self):
         if self._chunks is not None:

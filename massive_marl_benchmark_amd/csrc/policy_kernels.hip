@@ -595,10 +595,26 @@ __global__ void __launch_bounds__(256) row_stats_kernel(RowStatsArgs a) {
 // The same from slot partials in the two-pass form the split layers leave: (sum, M2 about the slot's own mean) of 64 activations per
 // slot, combined with Chan's formula -- no E[x^2] - mean^2 cancellation however large the row's mean is against its spread.
 __device__ __forceinline__ void chan_combine(const float2* part, int64_t M, int64_t row, int slots, float& mean, float& m2) {
+    // (eight slots at a time with all loads issued before the first use: a hidden size of 512 is one round trip, not sixteen)
     float sum = 0.f;
+    m2 = 0.f;
+    if (slots <= 16) {
+        float2 p[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) p[k] = (k < slots) ? part[(size_t)k * M + row] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 16; k++) sum += p[k].x;                     // (slots past the last add zero: the order of the real ones is unchanged)
+        mean = sum / (64.f * (float)slots);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < slots) {
+                const float d = p[k].x * (1.f / 64.f) - mean;
+                m2 += p[k].y + 64.f * d * d;
+            }
+        return;
+    }
     for (int k = 0; k < slots; k++) sum += part[(size_t)k * M + row].x;
     mean = sum / (64.f * (float)slots);
-    m2 = 0.f;
     for (int k = 0; k < slots; k++) {
         const float2 p = part[(size_t)k * M + row];
         const float d = p.x * (1.f / 64.f) - mean;
@@ -637,6 +653,7 @@ __global__ void __launch_bounds__(256) marl_heads_finish_kernel(HeadsFinishArgs 
     for (int j = 0; j < 16; j++) dots[j] = 0.f;
     const float4* hp = reinterpret_cast<const float4*>(a.head_part[g]);
     const int HQ = (A + 3) >> 2;                                         // float4 pieces per row and slot (the partials' stride is A rounded up to 4)
+#pragma unroll 8
     for (int k = 0; k < a.slots; k++) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
