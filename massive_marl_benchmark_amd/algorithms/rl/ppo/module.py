@@ -244,42 +244,41 @@ class ActorCritic(nn.Module):
         version counter (agents/algorithms/marl/hatrpo_trainer.py:122 updates that way; PPO's optimizer.step() does not); on every other
         call of act / value when a parameter's version counter or address has changed.  Call it yourself after writing parameters through
         `.data` without a bound storage, and before replaying a captured graph that does not contain it."""
-        if True:
-            dev = self.log_std.device
-            vers, addrs = self._param_tags()
-            if self._addr_tag is not None and self._addr_tag != (addrs, str(dev)):
-                # the parameters moved (.to(device), a new storage): every cached address is void
-                self._h16, self._wplanes, self._split_bufs, self._calls, self._sample_calls = None, None, None, None, None
-            self._addr_tag, self._ver_tag = (addrs, str(dev)), vers
-            st = self._h16
-            if st is not None:
-                stream = _lib.for_device(st["dev"])[2]
-                for fn, args, what in st["calls"]:
-                    _lib.check(fn(*args, stream), None, what, st["L"])
-                # ... then the bound chain: one launch per set of constant-bound scales (it also stores the chain entries of its
-                # networks), and one without rows for networks no such set covers
-                covered = set()
-                for (members, rows, scale), (_, cs, ci, alias) in st["given"].items():
-                    ca = self._chain_args(st, members)
-                    if ca is None or alias:
-                        continue
-                    _lib.check(st["L"].mms_chain_refresh16(st["idx"], *ca, 16384.0 / scale, rows, ctypes.c_void_p(cs.data_ptr()), ctypes.c_void_p(ci.data_ptr()), stream),
-                               None, "mms_chain_refresh16", st["L"])
-                    covered.update(members)
-                depths = {Lh for _, Lh in st["slices"]}
-                rest = [tuple(range(len(st["recs"])))] if len(depths) == 1 else [(g,) for g in range(len(st["recs"]))]
-                for grp in rest:
-                    if not set(grp) <= covered:
-                        ca = self._chain_args(st, grp)
-                        if ca is not None:
-                            _lib.check(st["L"].mms_chain_refresh16(st["idx"], *ca, 0.0, 0, None, None, stream), None, "mms_chain_refresh16", st["L"])
-            if self._wplanes:                                # the three-plane format's weights (no scales, no chain)
-                for key in list(self._wplanes):
-                    tag, planes, lin = self._wplanes[key]
-                    if self.split_format == "bf16x3":
-                        self._weight_planes(lin, *_lib.for_device(lin.weight.device), force=True)
-                    else:
-                        self._wplanes[key] = (None, planes, lin)    # not in use now: re-split at their next use
+        dev = self.log_std.device
+        vers, addrs = self._param_tags()
+        if self._addr_tag is not None and self._addr_tag != (addrs, str(dev)):
+            # the parameters moved (.to(device), a new storage): every cached address is void
+            self._h16, self._wplanes, self._split_bufs, self._calls, self._sample_calls = None, None, None, None, None
+        self._addr_tag, self._ver_tag = (addrs, str(dev)), vers
+        st = self._h16
+        if st is not None:
+            stream = _lib.for_device(st["dev"])[2]
+            for fn, args, what in st["calls"]:
+                _lib.check(fn(*args, stream), None, what, st["L"])
+            # ... then the bound chain: one launch per set of constant-bound scales (it also stores the chain entries of its
+            # networks), and one without rows for networks no such set covers
+            covered = set()
+            for (members, rows, scale), (_, cs, ci, alias) in st["given"].items():
+                ca = self._chain_args(st, members)
+                if ca is None or alias:
+                    continue
+                _lib.check(st["L"].mms_chain_refresh16(st["idx"], *ca, 16384.0 / scale, rows, ctypes.c_void_p(cs.data_ptr()), ctypes.c_void_p(ci.data_ptr()), stream),
+                           None, "mms_chain_refresh16", st["L"])
+                covered.update(members)
+            depths = {Lh for _, Lh in st["slices"]}
+            rest = [tuple(range(len(st["recs"])))] if len(depths) == 1 else [(g,) for g in range(len(st["recs"]))]
+            for grp in rest:
+                if not set(grp) <= covered:
+                    ca = self._chain_args(st, grp)
+                    if ca is not None:
+                        _lib.check(st["L"].mms_chain_refresh16(st["idx"], *ca, 0.0, 0, None, None, stream), None, "mms_chain_refresh16", st["L"])
+        if self._wplanes:                                # the three-plane format's weights (no scales, no chain)
+            for key in list(self._wplanes):
+                tag, planes, lin = self._wplanes[key]
+                if self.split_format == "bf16x3":
+                    self._weight_planes(lin, *_lib.for_device(lin.weight.device), force=True)
+                else:
+                    self._wplanes[key] = (None, planes, lin)    # not in use now: re-split at their next use
 
     def _ensure_fresh(self):
         """refresh() when a parameter's version counter or address has moved since the derived buffers were built (see refresh for what
