@@ -261,6 +261,27 @@ int mms_ppo_heads_act(int device, const float* hidden, const float* weight, cons
                       int64_t* counters, int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
                       float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N, int32_t A, void* hip_stream);
 
+/* mms_ppo_heads_act FUSED INTO THE STEP: with a head bound, the next mms_step evaluates the policy's output heads and the sampling tail
+ * for its own 16 envs per workgroup in the step kernel's prologue -- the arithmetic of mms_ppo_heads_act, instruction for instruction
+ * (csrc/head_block.h is the body of both) -- writes the action / log-prob / value / mu / sigma slots and takes the sampled actions from
+ * LDS instead of reading an action tensor: one launch and one memory round trip less per rollout step (pre_physics_step,
+ * ten_ant.py:886-891, then consumes what ActorCritic.act, module.py:73-87, would have returned).  The binding holds for ONE step: the
+ * step that consumes it clears it (the slot pointers move with every rollout step).  Available where the step kernel runs its 16-envs-
+ * per-workgroup TenAnt layout (num_agents 10, num_envs a multiple of 16 and >= 16 per CU, no physical DR) with H a multiple of 512 and
+ * A = 80; anywhere else the call fails and the caller launches mms_ppo_heads_act.  Fields as the arguments of mms_ppo_heads_act;
+ * actions_out may name the engine's "actions" buffer (kept for task.actions) or be NULL. */
+typedef struct mms_policy_head {
+    const float* hidden; const float* weight; const float* bias;        /* actor: last hidden activations [N, H], last layer [A, H], [A] */
+    const float* vhidden; const float* vweight; const float* vbias;     /* critic: [N, VH], [VH], [1] */
+    const float* log_std;                                                /* [A] */
+    int64_t* counters;                                                   /* [N] draw counters */
+    float* actions_out; float* act_slot; float* logp_slot; float* value_slot; float* mu_slot; float* sigma_slot;
+    uint64_t seed;
+    int64_t row_offset;
+    int32_t H, VH, A, reference_scale;
+} mms_policy_head;
+int mms_bind_policy_head(mms_handle h, const mms_policy_head* head);   /* NULL: unbind */
+
 /* One hidden layer of the PPO policy for BOTH networks in one launch (module.py:27-52: nn.Linear + activation, actor and
  * critic of the same shape): y_g = act(x_g @ w_g^T + b_g), g = 0, 1, on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact
  * fp32 products and sums) with bias and activation in the epilogue.  x [M,K], w [N,K] and b [N] in torch's Linear layout,

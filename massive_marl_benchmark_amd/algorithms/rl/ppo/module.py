@@ -69,9 +69,10 @@ class ActorCritic(nn.Module):
         self._calls = None      # prebuilt launch lists of the f16x2 hidden layers, per (buffers, input addresses)
         self._sample_calls = None
         self._qualify = None
+        self._step_engine = None
 
     _DERIVED = ("_counters", "_side", "_trunk", "_act_bufs", "_value_bufs", "_one_bufs", "_wplanes", "_split_bufs", "_nets", "_h16", "_addr_tag",
-                "_ver_tag", "_calls", "_sample_calls", "_qualify", "_bound")
+                "_ver_tag", "_calls", "_sample_calls", "_qualify", "_bound", "_step_engine")
 
     def __deepcopy__(self, memo):
         """A copy starts without derived state: the caches hold device addresses of THIS module's parameters and buffers."""
@@ -114,11 +115,17 @@ class ActorCritic(nn.Module):
         raise NotImplementedError
 
     # -- fused sampling ----------------------------------------------------------------------
-    def bind_rollout(self, storage=None, actions_out=None):
+    def bind_rollout(self, storage=None, actions_out=None, step_engine=None):
         """Optional zero-copy destinations: `storage` (a RolloutStorage: `act` then writes actions / log-prob / value /
         mu / sigma into slot `storage.step` and returns views of those slots, which `add_transitions` recognises and does
-        not copy again) and `actions_out` (e.g. the engine's "actions" buffer)."""
+        not copy again) and `actions_out` (e.g. the engine's "actions" buffer).
+        step_engine (with a storage; optional): an Engine whose NEXT step() follows every `act` -- the output heads and the sampling tail
+        then run in that step kernel's prologue (Engine.bind_policy_head / mms_bind_policy_head: the same instruction sequence as
+        mms_ppo_heads_act, one launch and one memory round trip less per rollout step) and `act` returns the slot views BEFORE they are
+        filled: valid for whoever reads them in stream order behind the step (add_transitions, the learner), not for host code between
+        `act` and `step`.  Used where the engine has the layout for it (Engine.takes_policy_head()); elsewhere the heads kernel runs."""
         self._bound = (storage, actions_out)
+        self._step_engine = step_engine if (storage is not None and step_engine is not None and step_engine.takes_policy_head()) else None
 
     def _fp32_layers_qualify(self):
         """mms_linear2_act applies: fp32 ELU networks, actor and critic with the same hidden shapes, input widths multiples of 4."""
@@ -534,13 +541,16 @@ class ActorCritic(nn.Module):
             la, lc = self.actor[-1], self.critic[-1]
             ckey = (storage.actions.data_ptr(), storage.values.data_ptr(), storage.step, hidden.data_ptr(), None if vhidden is None else vhidden.data_ptr(),
                     None if actions_out is None else actions_out.data_ptr(), N, la.weight.data_ptr(), la.bias.data_ptr(), lc.weight.data_ptr(),
-                    lc.bias.data_ptr(), self.log_std.data_ptr(), self._counters.data_ptr())
+                    lc.bias.data_ptr(), self.log_std.data_ptr(), self._counters.data_ptr(), None if self._step_engine is None else id(self._step_engine))
             if self._sample_calls is None:
                 self._sample_calls = {}
             hit = self._sample_calls.get(ckey)
             if hit is not None:
-                args, ret = hit
-                _lib.check(L.mms_ppo_heads_act(*args, stream), None, "mms_ppo_heads_act", L)
+                args, ret, head = hit
+                if head is not None and self._step_engine is not None:
+                    self._step_engine.bind_policy_head(head)         # the engine's next step() evaluates the heads and samples
+                else:
+                    _lib.check(L.mms_ppo_heads_act(*args, stream), None, "mms_ppo_heads_act", L)
                 return ret
         if storage is not None:
             s = storage.step
@@ -566,9 +576,21 @@ class ActorCritic(nn.Module):
                     None if vh is None else p(vlast.weight.detach()), None if vh is None else p(vlast.bias.detach()),
                     0 if vh is None else vlast.in_features, p(log_std), self.seed, p(self._counters), self.row_offset, 1,
                     p(actions_out), p(act), p(logp), p(val), p(mu), p(sigma), N, A)
-            _lib.check(L.mms_ppo_heads_act(*args, stream), None, "mms_ppo_heads_act", L)
+            head = None
+            eng = self._step_engine
+            if (ckey is not None and eng is not None and vh is not None and value is None and self.log_std.dtype == torch.float32 and eng.device == dev
+                    and last.in_features % 512 == 0 and A == eng.num_actions and N == eng.num_envs and self.row_offset == eng.config.env_offset):
+                from ....model import MmsPolicyHead
+                a_ = lambda t: None if t is None else t.data_ptr()
+                head = MmsPolicyHead(a_(hidden), a_(last.weight), a_(last.bias), a_(vh), a_(vlast.weight), a_(vlast.bias), a_(log_std), a_(self._counters),
+                                     a_(actions_out), a_(act), a_(logp), a_(val), a_(mu), a_(sigma), self.seed, self.row_offset, last.in_features,
+                                     vlast.in_features, A, 1)
+            if head is not None:
+                eng.bind_policy_head(head)
+            else:
+                _lib.check(L.mms_ppo_heads_act(*args, stream), None, "mms_ppo_heads_act", L)
             if ckey is not None and self.log_std.dtype == torch.float32:
-                self._sample_calls[ckey] = (args, (act, logp.view(-1), val, mu, sigma))
+                self._sample_calls[ckey] = (args, (act, logp.view(-1), val, mu, sigma), head)
         return act, logp.view(-1), val, mu, sigma
 
     def act(self, observations, states, obs_planes=None):

@@ -39,6 +39,8 @@ struct mms_engine {
     void* obs_planes = nullptr;
     float obs_planes_scale = 1.f;
     const float* actions_in = nullptr;
+    int head_on = 0;                        // mms_bind_policy_head: consumed by the next mms_step
+    mms_policy_head head{};
     int write_raw_obs = 1, write_clipped_obs = 1, dr_enabled = 0;
     float* rew_out = nullptr;
     uint8_t* done_out = nullptr;
@@ -185,9 +187,26 @@ MMS_API int mms_get_tensor(mms_handle h, const char* name, mms_tensor* out) {
     return 0;
 }
 
+MMS_API int mms_ppo_heads_act(int device, const float* hidden, const float* weight, const float* bias, int32_t H, const float* value,
+                              const float* vhidden, const float* vweight, const float* vbias, int32_t VH, const float* log_std, uint64_t seed,
+                              int64_t* counters, int64_t row_offset, int32_t reference_scale, float* actions_out, float* act_slot,
+                              float* logp_slot, float* value_slot, float* mu_slot, float* sigma_slot, int64_t N, int32_t A, void*);
+
 static int do_step(mms_handle h, int physics) {
     if (!h) return fail(nullptr, "mms_step: null handle");
-    mms::HostBufs b{h->actions_in ? const_cast<float*>(h->actions_in) : buf<float>(h, "actions"), h->write_raw_obs ? buf<float>(h, "obs") : nullptr,
+    const float* head_actions = nullptr;
+    if (physics && h->head_on) {
+        // the fused policy head (mms_bind_policy_head): on the host the heads operator runs in front of the step, into the action tensor
+        // the step then reads -- the same values as the two calls made separately
+        const mms_policy_head& p = h->head;
+        float* dst = p.actions_out ? p.actions_out : buf<float>(h, "actions");
+        h->head_on = 0;
+        if (mms_ppo_heads_act(-1, p.hidden, p.weight, p.bias, p.H, nullptr, p.vhidden, p.vweight, p.vbias, p.VH, p.log_std, p.seed, p.counters, p.row_offset,
+                              p.reference_scale, dst, p.act_slot, p.logp_slot, p.value_slot, p.mu_slot, p.sigma_slot, h->cfg.num_envs, p.A, nullptr))
+            return fail(h, "mms_step: the bound policy head failed: " + g_error);
+        head_actions = dst;
+    }
+    mms::HostBufs b{head_actions ? const_cast<float*>(head_actions) : (h->actions_in ? const_cast<float*>(h->actions_in) : buf<float>(h, "actions")), h->write_raw_obs ? buf<float>(h, "obs") : nullptr,
                     h->write_clipped_obs ? buf<float>(h, "obs_clipped") : nullptr, buf<float>(h, "rew"), buf<int64_t>(h, "reset"),
                     buf<int64_t>(h, "progress"), buf<float>(h, "root_states"), buf<float>(h, "initial_root_states"),
                     buf<float>(h, "dof_state"), buf<float>(h, "env_origin"), buf<float>(h, "prev"), buf<float>(h, "reset_noise"),
@@ -244,6 +263,20 @@ MMS_API int mms_bind_obs_planes16(mms_handle h, void* planes, float scale) {
 MMS_API int mms_bind_actions(mms_handle h, const float* src) {
     if (!h) return fail(nullptr, "mms_bind_actions: null handle");
     h->actions_in = src;
+    return 0;
+}
+MMS_API int mms_bind_policy_head(mms_handle h, const mms_policy_head* head) {
+    if (!h) return fail(nullptr, "mms_bind_policy_head: null handle");
+    if (!head) { h->head_on = 0; return 0; }
+    if (h->dr_enabled || h->cfg.task != MMS_TASK_TEN_ANT || h->cfg.num_agents != 10 || h->cfg.num_envs % 16 != 0)
+        return fail(h, "mms_bind_policy_head: not available for this engine (needs the 16-envs-per-workgroup TenAnt layout: 10 ants, num_envs a multiple "
+                       "of 16 and >= 16 per CU, no physical DR) -- launch mms_ppo_heads_act instead");
+    if (!head->hidden || !head->weight || !head->bias || !head->vhidden || !head->vweight || !head->vbias || !head->log_std || !head->counters)
+        return fail(h, "mms_bind_policy_head: null pointer (hidden, weight, bias, vhidden, vweight, vbias, log_std, counters are required)");
+    if (head->A != 8 * h->cfg.num_agents || head->H <= 0 || head->H % 512 != 0 || head->VH <= 0 || head->VH % 4 != 0)
+        return fail(h, "mms_bind_policy_head: A must be 8 x num_agents, H a multiple of 512, VH a multiple of 4");
+    h->head = *head;
+    h->head_on = 1;
     return 0;
 }
 MMS_API int mms_set_dr(mms_handle h, int32_t enable) {

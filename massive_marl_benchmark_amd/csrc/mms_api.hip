@@ -16,6 +16,7 @@
 
 namespace mms {
 hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream);
+bool step_layout_takes_head(int task, int num_envs, int num_agents, int packing);
 hipError_t launch_gae_ppo(const float*, const uint8_t*, const float*, const float*, float*, float*, double*, int, int64_t, float, float, hipStream_t);
 hipError_t launch_adv_normalize(float*, const double*, int64_t, hipStream_t);
 hipError_t launch_gae_ppo_normalized(const float*, const uint8_t*, const float*, const float*, float*, float*, double*, int, int64_t, float, float, hipStream_t);
@@ -45,6 +46,8 @@ struct mms_engine {
     void* obs_planes = nullptr;
     float obs_planes_scale = 1.f;
     const float* actions_in = nullptr;      // mms_bind_actions
+    bool head_on = false;                   // mms_bind_policy_head: consumed (and cleared) by the next mms_step
+    mms_policy_head head{};
     void* scratch = nullptr;                // staging of mms_set_state(env_ids)
     size_t scratch_bytes = 0;
     int write_raw_obs = 1, write_clipped_obs = 1;
@@ -290,6 +293,8 @@ static mms::StepArgs step_args(mms_handle h, int physics) {
     a.obs_dim = h->obs_dim;
     a.prev_dim = h->prev_dim;
     a.packing = h->packing;
+    a.head_on = (physics && h->head_on) ? 1 : 0;
+    if (a.head_on) a.head = h->head;
     return a;
 }
 
@@ -298,6 +303,7 @@ static int do_step(mms_handle h, void* stream, int physics) {
     DeviceGuard guard(h->cfg.device);
     MMS_HIP(h, guard.err);
     mms::StepArgs a = step_args(h, physics);
+    if (physics) h->head_on = false;                                  // the binding is for one step (the slot pointers move every step)
     MMS_HIP(h, mms::launch_step(a, h->cfg.task, (hipStream_t)stream));
     return 0;
 }
@@ -382,6 +388,26 @@ __attribute__((visibility("default"))) int mms_bind_actions(mms_handle h, const 
     if (!h) return fail(nullptr, "mms_bind_actions: null handle");
     if (src && (reinterpret_cast<uintptr_t>(src) & 7) != 0) return fail(h, "mms_bind_actions: the action tensor must be 8-byte aligned");
     h->actions_in = src;
+    return 0;
+}
+
+__attribute__((visibility("default"))) int mms_bind_policy_head(mms_handle h, const mms_policy_head* head) {
+    if (!h) return fail(nullptr, "mms_bind_policy_head: null handle");
+    if (!head) { h->head_on = false; return 0; }
+    DeviceGuard guard(h->cfg.device);
+    MMS_HIP(h, guard.err);
+    if (h->dr_enabled || !mms::step_layout_takes_head(h->cfg.task, h->cfg.num_envs, h->cfg.num_agents, h->packing))
+        return fail(h, "mms_bind_policy_head: not available for this engine (needs the 16-envs-per-workgroup TenAnt layout: 10 ants, num_envs a multiple "
+                       "of 16 and >= 16 per CU, no physical DR) -- launch mms_ppo_heads_act instead");
+    if (!head->hidden || !head->weight || !head->bias || !head->vhidden || !head->vweight || !head->vbias || !head->log_std || !head->counters)
+        return fail(h, "mms_bind_policy_head: null pointer (hidden, weight, bias, vhidden, vweight, vbias, log_std, counters are required)");
+    if (head->A != 8 * h->cfg.num_agents || head->H <= 0 || head->H % 512 != 0 || head->VH <= 0 || head->VH % 4 != 0)
+        return fail(h, "mms_bind_policy_head: A must be 8 x num_agents, H a multiple of 512, VH a multiple of 4");
+    uintptr_t bits = reinterpret_cast<uintptr_t>(head->hidden) | reinterpret_cast<uintptr_t>(head->weight) | reinterpret_cast<uintptr_t>(head->vhidden) |
+                     reinterpret_cast<uintptr_t>(head->vweight);
+    if ((bits & 15) != 0) return fail(h, "mms_bind_policy_head: hidden, weight, vhidden, vweight must be 16-byte aligned");
+    h->head = *head;
+    h->head_on = true;
     return 0;
 }
 

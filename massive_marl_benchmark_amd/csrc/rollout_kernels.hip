@@ -17,6 +17,7 @@
 
 #include <stdlib.h>
 
+#include "head_block.h"
 #include "mms_lane.h"
 #include "rollout_lane.h"
 
@@ -138,37 +139,6 @@ __global__ void __launch_bounds__(256) marl_views_kernel(const float* __restrict
         obs_all[i] = obs[marl_view_source(i, agents, per, shared)];
 }
 
-// Sampling of one row by one wave: lane j draws the noise of action j (and j + 64), the row's log-probability is a wave
-// reduction.  The per-row draw counter lives in device memory so that a replayed hipGraph sees fresh noise; the store of
-// c + 1 depends on the load of c, which orders the two.  `mean_row` may point to global memory or LDS.
-struct PpoActOut {
-    float* actions_out; float* act_slot; float* logp_slot; float* value_slot; float* mu_slot; float* sigma_slot;
-};
-__device__ __forceinline__ void ppo_sample_row(const float* mean_row, const float* __restrict__ value, const float* __restrict__ log_std,
-                                               uint64_t seed, int64_t* __restrict__ counters, int64_t row_offset, int ref_scale,
-                                               const PpoActOut& o, int64_t row, int A, int lane, bool have_value = false, float value_now = 0.f) {
-    const int64_t c = counters[row];
-    float lp = 0.f;
-    for (int j = lane; j < A; j += 64) {
-        const float ls = log_std[j];
-        const float m = mean_row[j];
-        float term;
-        const float act = ppo_sample_one(m, ls, seed, (uint64_t)(row_offset + row), (uint64_t)c, (uint32_t)j, ref_scale, term);
-        lp += term;
-        if (o.actions_out) o.actions_out[row * A + j] = act;
-        if (o.act_slot) o.act_slot[row * A + j] = act;
-        if (o.mu_slot) o.mu_slot[row * A + j] = m;
-        if (o.sigma_slot) o.sigma_slot[row * A + j] = ls;
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) lp += __shfl_xor(lp, m, 64);
-    if (lane == 0) {
-        if (o.logp_slot) o.logp_slot[row] = lp;
-        if (o.value_slot && (have_value || value)) o.value_slot[row] = have_value ? value_now : value[row];
-        counters[row] = c + 1;
-    }
-}
-
 __global__ void __launch_bounds__(256) ppo_act_kernel(const float* __restrict__ mean, const float* __restrict__ value,
                                                       const float* __restrict__ log_std, uint64_t seed, int64_t* __restrict__ counters,
                                                       int64_t row_offset, int ref_scale, PpoActOut o, int64_t N, int A) {
@@ -177,17 +147,7 @@ __global__ void __launch_bounds__(256) ppo_act_kernel(const float* __restrict__ 
     ppo_sample_row(mean + row * A, value, log_std, seed, counters, row_offset, ref_scale, o, row, A, threadIdx.x & 63);
 }
 
-// The same with the actor's last Linear layer folded in: mean = hidden @ W^T + b on the matrix cores, then the sampling.
-// A block owns 16 rows; its WAVES (8 when H is a multiple of 512, else 4 / 2 / 1) waves split K = H evenly and each accumulates the 16 x A tile of its share with
-// v_mfma_f32_16x16x4_f32 (exact fp32 products and sums).  Operand lane map: lane l supplies A[l & 15][k = l >> 4] and
-// B[k = l >> 4][l & 15]; a lane loads 4 consecutive k of its row as one float4 and feeds four MFMAs from it, which only
-// permutes the order in which k is summed.  The partial sums meet in LDS, in wave order.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-// NCT = number of 16-column tiles (compile time: the accumulators must be plain registers), A <= 16 NCT.
-// Rows past N and columns past A are computed from clamped (valid) addresses and never read back.
-// RT = 16-row tiles per block (the block's waves still split K): with RT = 2 the head's weight fragments feed two row tiles, i.e. the
-// launch reads the 164 KB of head weights once per 32 rows instead of once per 16 (L2 -> CU traffic 42 -> 21 MB at 4096 rows) in half
-// as many blocks.
+// The same with the actor's last Linear layer folded in (head_block.h: the body is shared with the step kernel's fused prologue)
 template <int NCT, int WAVES, int RT>
 __global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* __restrict__ hidden, const float* __restrict__ weight,
                                                            const float* __restrict__ bias, int H, const float* __restrict__ value,
@@ -196,100 +156,8 @@ __global__ void __launch_bounds__(64 * WAVES) ppo_head_act_kernel(const float* _
                                                            const float* __restrict__ log_std, uint64_t seed, int64_t* __restrict__ counters,
                                                            int64_t row_offset, int ref_scale, PpoActOut o, int64_t N, int A) {
     extern __shared__ __attribute__((aligned(16))) float s_part[];      // [WAVES][16 RT rows][AP], then [16 RT][AP] means
-    constexpr int AP = NCT * 16, ROWS = 16 * RT;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, g = lane >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
-    const float* hrow[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) {
-        const int64_t row_a = r0 + 16 * rt + i < N ? r0 + 16 * rt + i : N - 1;
-        hrow[rt] = hidden + row_a * (int64_t)H + 4 * g;
-    }
-    const float* wrow[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ct++) {
-        const int j = ct * 16 + i;
-        wrow[ct] = weight + (int64_t)(j < A ? j : A - 1) * H + 4 * g;
-    }
-    f32x4 acc[RT][NCT];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // The critic's last layer (module.py:49: nn.Linear(hidden, 1)) for the rows this wave samples below: one dot product per row,
-    // evaluated here so that its loads travel with the actor head's operands instead of costing a round trip after the barriers.
-    constexpr int RPW = ROWS / WAVES;                                        // rows sampled per wave (WAVES in 1, 2, 4, 8)
-    float v_rows[RPW];
-#pragma unroll
-    for (int q = 0; q < RPW; q++) {
-        v_rows[q] = 0.f;
-        const int64_t row = r0 + wave * RPW + q;
-        if (vhidden && row < N) {
-            const float* hv = vhidden + row * (int64_t)VH;
-            float part = 0.f;
-            for (int k = lane * 4; k < VH; k += 256) {
-                const float4 h4 = *reinterpret_cast<const float4*>(hv + k), w4 = *reinterpret_cast<const float4*>(vweight + k);
-                part += h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
-            v_rows[q] = part + vbias[0];
-        }
-    }
-    const int kq = H / WAVES;
-    const int kbeg = wave * kq;
-    // 64 k per trip (the launcher picks WAVES so that H / WAVES is a multiple of 64): the 4 x (RT + NCT) float4 loads of a
-    // trip are issued together, then its 16 RT NCT MFMAs
-    for (int kc = kbeg; kc < kbeg + kq; kc += 64) {
-        float4 a[RT][4], b[4][NCT];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) a[rt][u] = *reinterpret_cast<const float4*>(hrow[rt] + kc + 16 * u);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ct++) b[u][ct] = *reinterpret_cast<const float4*>(wrow[ct] + kc + 16 * u);
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-#pragma unroll
-                for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][u].x, b[u][ct].x, acc[rt][ct], 0, 0, 0);
-#pragma unroll
-                for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][u].y, b[u][ct].y, acc[rt][ct], 0, 0, 0);
-#pragma unroll
-                for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][u].z, b[u][ct].z, acc[rt][ct], 0, 0, 0);
-#pragma unroll
-                for (int ct = 0; ct < NCT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][u].w, b[u][ct].w, acc[rt][ct], 0, 0, 0);
-            }
-    }
-    // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
-    float* mine = s_part + (size_t)wave * ROWS * AP;
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) mine[(16 * rt + 4 * g + r) * AP + ct * 16 + i] = acc[rt][ct][r];
-        }
-    __syncthreads();
-    float* s_mean = s_part + (size_t)WAVES * ROWS * AP;
-    for (int e = threadIdx.x; e < ROWS * AP; e += 64 * WAVES) {
-        const int j = e % AP;
-        float sum = s_part[e];
-#pragma unroll
-        for (int w = 1; w < WAVES; w++) sum += s_part[w * ROWS * AP + e];    // wave order
-        s_mean[e] = sum + bias[j < A ? j : 0];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < RPW; q++) {
-        const int r = wave * RPW + q;
-        const int64_t row = r0 + r;
-        if (row >= N) continue;
-        ppo_sample_row(s_mean + r * AP, value, log_std, seed, counters, row_offset, ref_scale, o, row, A, lane, vhidden != nullptr, v_rows[q]);
-    }
+    ppo_head_block<NCT, WAVES, RT>(s_part, (int)threadIdx.x, true, (int64_t)blockIdx.x * 16 * RT, hidden, weight, bias, H, value, vhidden, vweight, vbias, VH,
+                                   log_std, seed, counters, row_offset, ref_scale, o, N, A);
 }
 
 hipError_t launch_adv_normalize(float* advantages, const double* stats, int64_t count, hipStream_t s);

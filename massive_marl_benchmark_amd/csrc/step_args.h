@@ -31,6 +31,8 @@ struct StepArgs {
     int32_t do_physics;
     int32_t num_envs, num_agents, obs_dim, prev_dim;
     int32_t packing;                  // 1: several envs per workgroup where the lane counts allow (default), 0: one env per workgroup
+    int32_t head_on;                  // 1: the policy's output heads + sampling run in the prologue (mms_bind_policy_head), `head` is valid
+    mms_policy_head head;
 };
 
 }  // namespace mms

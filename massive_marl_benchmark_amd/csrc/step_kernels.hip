@@ -15,6 +15,7 @@
 // actions 320 B, caches 168 B in; the same state plus the 1552 B observation row(s) out.
 #include <hip/hip_runtime.h>
 
+#include "head_block.h"
 #include "mms_lane.h"
 #include "step_args.h"
 
@@ -105,7 +106,7 @@ __host__ __device__ inline size_t ant_env_lds_floats(int obs_dim, int A) {
 // AT > 0 fixes the number of ants at compile time (LDS offsets become immediates, the per-ant loops unroll); 0 = runtime.
 // DR: per-env physical domain randomisation (mass / damping scales, limit offsets) read from a.dr; a separate instantiation so
 // that the nominal kernel carries none of it.
-template <int TASK, int BLOCK, int EPB, int AT, bool DR>
+template <int TASK, int BLOCK, int EPB, int AT, bool DR, bool HEAD = false>
 // The 512-thread layout (the runtime-sized one: the 100-ant swarm) is held to 168 VGPRs as well.  Its eight waves are two per SIMD
 // and a second block never fits beside them, so the register count looks free -- it is not: at 182-194 VGPRs (what the compiler takes
 // when allowed 256) the same instruction stream, counter for counter (SQ_INSTS_*, SQ_WAVE_CYCLES, I-cache misses), took 214-232 us
@@ -123,6 +124,34 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     static_assert(sizeof(mms_config) % 4 == 0, "copied word by word");
     const mms_config* C = reinterpret_cast<const mms_config*>(lds);
     const mms_model* M = &C->model;
+    // ---- the policy's output heads + sampling, fused (mms_bind_policy_head; HEAD instantiation of the 16-envs-per-block layout only) ----
+    // The block's 16 envs are the 16 rows of one heads-kernel block: waves 0-7 run head_block.h's body (the same instruction sequence as
+    // mms_ppo_heads_act: K = 512 split over eight waves, v_mfma_f32_16x16x4_f32, partial sums in wave order, sampling by row), waves 8-11
+    // only join its barriers.  It runs FIRST, in LDS that nothing has written yet (behind the config block and the leg constants: partials
+    // [8][16][80], means [16][80], the block's sampled actions [16][80]); every ant lane takes its two actions into registers before the
+    // prologue below reuses that space.
+    float2 ac_head = make_float2(0.f, 0.f);
+    if constexpr (HEAD) {
+        static_assert(BLOCK == 768 && EPB == 16 && AT == 10 && TASK == MMS_TASK_TEN_ANT, "the fused head assumes 16 rows x 80 actions per block");
+        float* s_head = lds + kCfgFloats + (4 * sizeof(LegConst) + 15) / 16 * 4;
+        float* s_head_actions = s_head + 9 * 16 * 80;
+        PpoActOut o{a.head.actions_out, a.head.act_slot, a.head.logp_slot, a.head.value_slot, a.head.mu_slot, a.head.sigma_slot};
+        o.lds_actions = s_head_actions;
+        o.lds_row0 = (int64_t)blockIdx.x * 16;
+        ppo_head_block<5, 8, 1, 4>(s_head, (int)threadIdx.x, threadIdx.x < 512, (int64_t)blockIdx.x * 16, a.head.hidden, a.head.weight, a.head.bias, a.head.H, nullptr,
+                                a.head.vhidden, a.head.vweight, a.head.vbias, a.head.VH, a.head.log_std, a.head.seed, a.head.counters, a.head.row_offset,
+                                a.head.reference_scale, o, a.num_envs, 8 * AT);
+        __syncthreads();                                             // the sampled actions are in LDS
+        if (threadIdx.x < 16 * 4 * AT) ac_head = reinterpret_cast<const float2*>(s_head_actions)[threadIdx.x];   // lane (env e, ant lane t) = thread 40 e + t: actions 80 e + 2 t
+        asm volatile("" : "+v"(ac_head.x), "+v"(ac_head.y));        // (taken now: the prologue below reuses the space behind the next barrier)
+        __syncthreads();
+    }
+    constexpr int kObsAT = TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : (TASK == MMS_TASK_MULTI_ANT_CIRCLE ? 38 * AT : 60);
+    constexpr int kPrevAT = TASK == MMS_TASK_TEN_ANT ? 4 * AT + 2 : (TASK == MMS_TASK_MULTI_ANT_CIRCLE ? 2 * AT : 6);
+    const int obs_dim = AT > 0 ? kObsAT : a.obs_dim;
+    const int prev_dim = AT > 0 ? kPrevAT : a.prev_dim;
+    const int obs_pad = (obs_dim + 3) & ~3;
+
     const int A = AT > 0 ? AT : a.num_agents;
     const int LA = 4 * A;                                     // ant lanes per env
     const int ant_region = EPB * LA;
@@ -141,11 +170,6 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     const bool live = env_raw < a.num_envs;                  // a partial last block still runs every barrier
     const int env = live ? env_raw : a.num_envs - 1;
     const int ant = tid >> 2, leg = tid & 3;
-    constexpr int kObsAT = TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : (TASK == MMS_TASK_MULTI_ANT_CIRCLE ? 38 * AT : 60);
-    constexpr int kPrevAT = TASK == MMS_TASK_TEN_ANT ? 4 * AT + 2 : (TASK == MMS_TASK_MULTI_ANT_CIRCLE ? 2 * AT : 6);
-    const int obs_dim = AT > 0 ? kObsAT : a.obs_dim;
-    const int prev_dim = AT > 0 ? kPrevAT : a.prev_dim;
-    const int obs_pad = (obs_dim + 3) & ~3;
 
     // per-leg constants and the box pose live in LDS and are read at the point of use: keeping them in registers
     // costs ~55 VGPRs per lane for values that are wave-uniform or 4-periodic
@@ -213,7 +237,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     if (is_ant) {
         float4 d = reinterpret_cast<const float4*>(a.dof_state + (size_t)env * A * 16)[tid];   // (q1, qd1, q2, qd2): coalesced 16 B / lane
         S.q[0] = d.x; S.qd[0] = d.y; S.q[1] = d.z; S.qd[1] = d.w;
-        ac = reinterpret_cast<const float2*>(a.actions + (size_t)env * A * 8)[tid];             // this lane's two actions
+        if constexpr (HEAD) ac = ac_head;                                                        // ... sampled by the head prologue above
+        else ac = reinterpret_cast<const float2*>(a.actions + (size_t)env * A * 8)[tid];        // this lane's two actions
         if (DR) *s_dr = load_leg_dr(a.dr + ((size_t)env * A + ant) * MMS_DR_FLOATS, leg);       // read back by this lane only
     }
     for (int i = threadIdx.x; i < (int)(sizeof(mms_config) / 4); i += BLOCK) lds[i] = reinterpret_cast<const float*>(Cg)[i];
@@ -692,9 +717,37 @@ static hipError_t launch_ant(const StepArgs& a, hipStream_t stream) {
             allowed[a.dr ? 1 : 0][dev] = true;
         }
     }
+    if (a.head_on) {
+        // the fused policy head exists for the 16-envs-per-block TenAnt layout without physical DR only (mms_bind_policy_head checks)
+        if constexpr (TASK == MMS_TASK_TEN_ANT && BLOCK == 768 && EPB == 16 && AT == 10) {
+            if (a.dr || a.num_envs % 16 != 0) return hipErrorInvalidValue;
+            static bool head_allowed[64] = {};
+            int dev = 0;
+            if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+            const void* k = reinterpret_cast<const void*>(ant_step_kernel<TASK, BLOCK, EPB, AT, false, true>);
+            if (dev >= 0 && dev < 64 && !head_allowed[dev]) {
+                if (hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
+                head_allowed[dev] = true;
+            }
+            hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, false, true>), dim3(grid), dim3(BLOCK), lds, stream, a);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (a.dr) hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, true>), dim3(grid), dim3(BLOCK), lds, stream, a);
     else hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, false>), dim3(grid), dim3(BLOCK), lds, stream, a);
     return hipGetLastError();
+}
+
+// would mms_step launch the layout the fused policy head exists for? (mms_bind_policy_head)
+bool step_layout_takes_head(int task, int num_envs, int num_agents, int packing) {
+    if (task != MMS_TASK_TEN_ANT || num_agents != 10 || packing == 0 || num_envs % 16 != 0) return false;
+    const char* force16 = getenv("MMS_STEP_BLOCK16");
+    if (force16) return force16[0] != '0';
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return num_envs >= 16 * cus;
 }
 
 hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {

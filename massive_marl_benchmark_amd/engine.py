@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .model import MmsTensor, make_config, task_dims
+from .model import MmsPolicyHead, MmsTensor, make_config, task_dims
 
 _TORCH_DTYPES = {0: (torch.float32, "<f4"), 1: (torch.int64, "<i8"), 2: (torch.int32, "<i4"), 3: (torch.uint8, "|u1")}
 
@@ -125,6 +125,19 @@ class Engine:
             ptr = ctypes.c_void_p(t.data_ptr())
         self._bound_actions = tensor_or_none  # keep it alive
         self._check(self._L.mms_bind_actions(self._h, ptr), "mms_bind_actions")
+
+    def takes_policy_head(self):
+        """Does the next step accept a bound policy head (mms_bind_policy_head: the 16-envs-per-workgroup TenAnt layout)?  Asked once by the
+        policy module; the answer of a probe binding with placeholder-free validation is what the library itself says."""
+        if getattr(self, "_takes_head", None) is None:
+            probe = MmsPolicyHead()                              # all pointers NULL: passes the layout check, fails the pointer check
+            rc = self._L.mms_bind_policy_head(self._h, ctypes.byref(probe))
+            self._takes_head = rc != 0 and "null pointer" in _lib.last_error(self._h, self._L)
+        return self._takes_head
+
+    def bind_policy_head(self, head):
+        """`head`: an MmsPolicyHead (prebuilt by the policy module, one per rollout slot) or None.  The binding is consumed by the next step()."""
+        self._check(self._L.mms_bind_policy_head(self._h, None if head is None else ctypes.byref(head)), "mms_bind_policy_head")
 
     def set_obs_outputs(self, raw=True, clipped=True):
         """Which engine-owned observation rows the step writes ("obs", "obs_clipped"); a rollout that binds a slot with

@@ -71,6 +71,17 @@ class MmsTensor(ctypes.Structure):
                 ("dtype", ctypes.c_int32), ("device", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class MmsPolicyHead(ctypes.Structure):
+    """struct mms_policy_head (include/mms.h): the operands of mms_ppo_heads_act, bound to the next mms_step (mms_bind_policy_head)."""
+    _fields_ = [("hidden", ctypes.c_void_p), ("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("vhidden", ctypes.c_void_p), ("vweight", ctypes.c_void_p), ("vbias", ctypes.c_void_p),
+                ("log_std", ctypes.c_void_p), ("counters", ctypes.c_void_p),
+                ("actions_out", ctypes.c_void_p), ("act_slot", ctypes.c_void_p), ("logp_slot", ctypes.c_void_p), ("value_slot", ctypes.c_void_p),
+                ("mu_slot", ctypes.c_void_p), ("sigma_slot", ctypes.c_void_p),
+                ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_int64),
+                ("H", ctypes.c_int32), ("VH", ctypes.c_int32), ("A", ctypes.c_int32), ("reference_scale", ctypes.c_int32)]
+
+
 # ----------------------------------------------------------------------------------------------
 # ant description (restated from nv_ant.xml; see module docstring)
 # ----------------------------------------------------------------------------------------------

@@ -57,6 +57,7 @@ def check_abi_error_paths(L, device):
     for fn, args in ((L.mms_step, (None,)), (L.mms_post_step, (None,)), (L.mms_reset_all, (None,)), (L.mms_bind_obs_out, (None,)),
                      (L.mms_bind_actions, (None,)), (L.mms_set_dr, (1,)), (L.mms_set_obs_outputs, (1, 1)), (L.mms_bind_rollout_out, (None, None))):
         fails(fn(None, *args), contains="null handle")
+    fails(L.mms_bind_policy_head(None, None), contains="null handle")
     fails(L.mms_set_state(None, b"obs", None, 1, None, 0, None))
     assert L.mms_destroy(None) == 0                                  # documented no-op
 
@@ -93,6 +94,9 @@ def check_abi_error_paths(L, device):
     h = vp()
     assert L.mms_create(ctypes.byref(c), ctypes.byref(h)) == 0
     fails(L.mms_set_dr(h, 1), h, "helicopter")
+    from massive_marl_benchmark_amd.model import MmsPolicyHead
+    fails(L.mms_bind_policy_head(h, ctypes.byref(MmsPolicyHead())), h, "not available")         # not the TenAnt layout
+    assert L.mms_bind_policy_head(h, None) == 0                                                  # unbinding is always fine
     assert L.mms_destroy(h) == 0
 
     # ---- the policy / rollout operators (no handle: the message is mms_last_error(NULL)) ----

@@ -1,0 +1,55 @@
+"""The policy's output heads + sampling tail fused into the step kernel's prologue (mms_bind_policy_head; ActorCritic.bind_rollout(...,
+step_engine=engine)) against the two separate calls (mms_ppo_heads_act, then mms_step) -- one check for both builds.  Both forms run
+csrc/head_block.h on the same operands (the CPU build: its heads operator in front of the step), so everything they leave -- the rollout
+slots, the draw counters, the engine's state and observations -- is compared BIT FOR BIT."""
+import torch
+
+from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
+from massive_marl_benchmark_amd.algorithms.rl.ppo.storage import RolloutStorage
+from massive_marl_benchmark_amd.engine import Engine
+
+
+def check_head_fusion(device, num_envs, hidden=(256, 512), steps=6):
+    dev = torch.device("cuda", 0) if device == "cuda" else torch.device("cpu")
+    runs = []
+    for fused in (False, True):
+        eng = Engine("TenAnt", num_envs=num_envs, device=0 if device == "cuda" else "cpu", seed=11, clip_obs=5.0)
+        assert eng.takes_policy_head(), "the engine does not take a bound policy head at this size"
+        torch.manual_seed(4)
+        ac = ActorCritic((eng.obs_dim,), (0,), (eng.num_actions,), 0.8, {"pi_hid_sizes": list(hidden), "vf_hid_sizes": list(hidden), "activation": "elu"},
+                         seed=21).to(dev)
+        ac.split_min_tiles = 0
+        T = steps
+        storage = RolloutStorage(num_envs, T, (eng.obs_dim,), (0,), (eng.num_actions,), device=str(dev))
+        ac.bind_rollout(storage, eng.tensor("actions"), step_engine=eng if fused else None)
+        assert (ac._step_engine is not None) == fused
+        states = torch.zeros(num_envs, 0, device=dev)
+        eng.reset_all()
+        eng.tensor("actions").zero_()
+        eng.step()
+        for t in range(T):
+            obs_t = storage.observations[t]
+            obs_t.copy_(eng.tensor("obs_clipped"))
+            if dev.type == "cuda":
+                act, logp, value, mu, sigma = ac.act(obs_t, states)
+            else:                                                    # (on the CPU build `act` keeps to the torch modules: drive the fused tail directly)
+                with torch.no_grad():
+                    ha, hc = ac.actor[:-1](obs_t), ac.critic[:-1](obs_t)
+                act, logp, value, mu, sigma = ac._sample(None, None, hidden=ha.contiguous(), vhidden=hc.contiguous())
+            eng.bind_rollout_out(storage.rewards[t].view(-1), storage.dones[t].view(-1))
+            eng.step()
+            storage.add_transitions(obs_t, states, act, storage.rewards[t], storage.dones[t], value, logp, mu, sigma)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        out = {k: getattr(storage, k).clone() for k in ("actions", "actions_log_prob", "values", "mu", "sigma", "rewards", "dones", "observations")}
+        out["counters"] = ac._counters.clone()
+        for k in ("root_states", "dof_state", "obs", "rew", "actions"):
+            out["eng/" + k] = eng.tensor(k).clone()
+        runs.append(out)
+        eng.bind_rollout_out(None, None)
+        eng.close()
+    a, b = runs
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["actions"].abs().max()) > 0.1 and int(a["counters"].min()) == steps
+    return True

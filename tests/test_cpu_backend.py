@@ -504,3 +504,18 @@ def test_task_step_leaves_no_action_binding():
         assert torch.equal(task.engine.tensor(name), other.engine.tensor(name)), name
     task.engine.close()
     other.engine.close()
+
+
+def test_policy_head_fused_into_the_step_on_cpu_build():
+    """mms_bind_policy_head on the CPU build (tests/head_fusion_check.py; the HIP build runs the same check at 4096 envs, where the step
+    kernel has the layout for it): the fused form leaves bit for bit what mms_ppo_heads_act + mms_step leave; and the calls the binding
+    refuses."""
+    import head_fusion_check
+    assert head_fusion_check.check_head_fusion("cpu", 32)
+    from massive_marl_benchmark_amd.engine import Engine
+    one = Engine("OneAnt", num_envs=16, device="cpu")
+    assert not one.takes_policy_head()
+    one.close()
+    odd = Engine("TenAnt", num_envs=24, device="cpu")
+    assert not odd.takes_policy_head()
+    odd.close()

@@ -1748,6 +1748,14 @@ def test_ppo_training_loop_on_the_hip_path(torch_cuda):
         out["env"].task.engine.close()
 
 
+def test_policy_head_fused_into_the_step(torch_cuda):
+    """mms_bind_policy_head on the HIP build at BASELINE size (4096 TenAnt envs: the 16-envs-per-workgroup layout the fused prologue exists
+    for), policy [1024, 1024, 512] as in the bench: six rollout steps with the heads + sampling in the step kernel's prologue leave, bit for
+    bit, what mms_ppo_heads_act + mms_step leave (tests/head_fusion_check.py: rollout slots, draw counters, engine state)."""
+    import head_fusion_check
+    assert head_fusion_check.check_head_fusion("cuda", 4096, hidden=(1024, 1024, 512))
+
+
 def test_abi_error_paths_and_indexed_set_state(torch_cuda):
     """The status-code contract of include/mms.h on the HIP build (the list of tests/abi_errors.py, as on the CPU build), and
     mms_set_state with more than 16 env ids: one scatter launch (the reference's indexed setters take thousands of ids,
