@@ -124,28 +124,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     static_assert(sizeof(mms_config) % 4 == 0, "copied word by word");
     const mms_config* C = reinterpret_cast<const mms_config*>(lds);
     const mms_model* M = &C->model;
-    // ---- the policy's output heads + sampling, fused (mms_bind_policy_head; HEAD instantiation of the 16-envs-per-block layout only) ----
-    // The block's 16 envs are the 16 rows of one heads-kernel block: waves 0-7 run head_block.h's body (the same instruction sequence as
-    // mms_ppo_heads_act: K = 512 split over eight waves, v_mfma_f32_16x16x4_f32, partial sums in wave order, sampling by row), waves 8-11
-    // only join its barriers.  It runs FIRST, in LDS that nothing has written yet (behind the config block and the leg constants: partials
-    // [8][16][80], means [16][80], the block's sampled actions [16][80]); every ant lane takes its two actions into registers before the
-    // prologue below reuses that space.
-    float2 ac_head = make_float2(0.f, 0.f);
-    if constexpr (HEAD) {
-        static_assert(BLOCK == 768 && EPB == 16 && AT == 10 && TASK == MMS_TASK_TEN_ANT, "the fused head assumes 16 rows x 80 actions per block");
-        float* s_head = lds + kCfgFloats + (4 * sizeof(LegConst) + 15) / 16 * 4;
-        float* s_head_actions = s_head + 9 * 16 * 80;
-        PpoActOut o{a.head.actions_out, a.head.act_slot, a.head.logp_slot, a.head.value_slot, a.head.mu_slot, a.head.sigma_slot};
-        o.lds_actions = s_head_actions;
-        o.lds_row0 = (int64_t)blockIdx.x * 16;
-        ppo_head_block<5, 8, 1, 4>(s_head, (int)threadIdx.x, threadIdx.x < 512, (int64_t)blockIdx.x * 16, a.head.hidden, a.head.weight, a.head.bias, a.head.H, nullptr,
-                                a.head.vhidden, a.head.vweight, a.head.vbias, a.head.VH, a.head.log_std, a.head.seed, a.head.counters, a.head.row_offset,
-                                a.head.reference_scale, o, a.num_envs, 8 * AT);
-        __syncthreads();                                             // the sampled actions are in LDS
-        if (threadIdx.x < 16 * 4 * AT) ac_head = reinterpret_cast<const float2*>(s_head_actions)[threadIdx.x];   // lane (env e, ant lane t) = thread 40 e + t: actions 80 e + 2 t
-        asm volatile("" : "+v"(ac_head.x), "+v"(ac_head.y));        // (taken now: the prologue below reuses the space behind the next barrier)
-        __syncthreads();
-    }
+    float2 ac_head = make_float2(0.f, 0.f);          // (HEAD instantiation: this lane's two sampled actions)
     constexpr int kObsAT = TASK == MMS_TASK_TEN_ANT ? 38 * AT + 8 : (TASK == MMS_TASK_MULTI_ANT_CIRCLE ? 38 * AT : 60);
     constexpr int kPrevAT = TASK == MMS_TASK_TEN_ANT ? 4 * AT + 2 : (TASK == MMS_TASK_MULTI_ANT_CIRCLE ? 2 * AT : 6);
     const int obs_dim = AT > 0 ? kObsAT : a.obs_dim;
@@ -188,6 +167,41 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     const int root_floats = kStage ? EPB * (A + 1) * 13 : 0;
     // behind it: six 16-B words per lane where a leg lane parks its joint axes between the two passes of a substep
     float* lds_lanes = s_root + ((root_floats + 3) & ~3);
+    // ---- the policy's output heads + sampling, fused (mms_bind_policy_head; HEAD instantiation of the 16-envs-per-block layout only) ----
+    // The block's 16 envs are the 16 rows of one heads-kernel block: waves 0-7 run head_block.h's body (the same instruction sequence as
+    // mms_ppo_heads_act: K = 512 split over eight waves, v_mfma_f32_16x16x4_f32, partial sums in wave order, sampling by row) in the
+    // kinematics parking space (partials [8][16][80], means [16][80], the block's sampled actions [16][80]: free until the inward pass).
+    // Waves 8-11 have no part in it but its barriers: they stage the block's inputs meanwhile -- the root slice, the config block, the
+    // leg constants, the caches -- which the other instantiations do with all twelve waves further down; the HBM round trip of the
+    // staging then lies under the head's.  Every ant lane takes its two actions into registers before the space is reused.
+    if constexpr (HEAD) {
+        static_assert(BLOCK == 768 && EPB == 16 && AT == 10 && TASK == MMS_TASK_TEN_ANT && kStage, "the fused head assumes 16 rows x 80 actions per block");
+        float* s_head = lds_lanes;
+        float* s_head_actions = s_head + 9 * 16 * 80;
+        static_assert((9 + 1) * 16 * 80 <= 6 * 4 * BLOCK, "the head's LDS must fit the parking space");
+        if (threadIdx.x >= 512) {
+            const int t = (int)threadIdx.x - 512;
+            const float4* src = reinterpret_cast<const float4*>(a.root_states + (size_t)blockIdx.x * root_floats);   // (num_envs % 16 == 0: no partial block)
+            for (int i = t; i < root_floats / 4; i += 256) reinterpret_cast<float4*>(s_root)[i] = src[i];
+            for (int i = t; i < (int)(sizeof(mms_config) / 4); i += 256) lds[i] = reinterpret_cast<const float*>(Cg)[i];
+            if (t < 4) s_leg[t] = load_leg_const(&Cg->model, t);
+            constexpr int kStageOff = ((kRedOff + (RP_STRIDE + 6) * AT + 3) & ~3) + ((kObsAT + 3) & ~3);          // s_stage - env_lds
+            for (int i = t; i < EPB * prev_dim; i += 256) {
+                const int e = i / prev_dim, k = i - e * prev_dim;
+                (lds_envs + (size_t)e * env_stride + kStageOff)[k] = a.prev[((size_t)blockIdx.x * EPB + e) * prev_dim + k];
+            }
+        }
+        PpoActOut o{a.head.actions_out, a.head.act_slot, a.head.logp_slot, a.head.value_slot, a.head.mu_slot, a.head.sigma_slot};
+        o.lds_actions = s_head_actions;
+        o.lds_row0 = (int64_t)blockIdx.x * 16;
+        ppo_head_block<5, 8, 1, 4>(s_head, (int)threadIdx.x, threadIdx.x < 512, (int64_t)blockIdx.x * 16, a.head.hidden, a.head.weight, a.head.bias, a.head.H, nullptr,
+                                   a.head.vhidden, a.head.vweight, a.head.vbias, a.head.VH, a.head.log_std, a.head.seed, a.head.counters, a.head.row_offset,
+                                   a.head.reference_scale, o, a.num_envs, 8 * AT);
+        __syncthreads();                                             // the sampled actions are in LDS
+        if (threadIdx.x < 16 * 4 * AT) ac_head = reinterpret_cast<const float2*>(s_head_actions)[threadIdx.x];   // lane (env e, ant lane t) = thread 40 e + t: actions 80 e + 2 t
+        // (no barrier behind the reads: nothing writes the parking space before the first substep's inward pass, which sits behind the
+        //  prologue's own barriers)
+    }
     const KinPark park{lds_lanes + 4 * threadIdx.x, 4 * BLOCK};
     LegDR* s_dr = reinterpret_cast<LegDR*>(lds_lanes + 6 * 4 * BLOCK) + threadIdx.x;     // (DR kernels only) this lane's slice
     float* env_lds = lds_envs + (size_t)e_loc * env_stride;
@@ -215,7 +229,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     // single residency round are in their prologue at the same time, so a second round trip would not be hidden by anything.
     AntLane S = {};
     float2 ac = make_float2(0.f, 0.f);
-    if (kStage) {
+    if (kStage && !HEAD) {                                 // (HEAD: staged by waves 8-11 beside the head prologue, above)
         const size_t g0 = (size_t)blockIdx.x * root_floats, gtot = (size_t)a.num_envs * actors * 13;
         if (g0 + root_floats <= gtot) {
             const float4* src = reinterpret_cast<const float4*>(a.root_states + g0);
@@ -241,10 +255,11 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
         else ac = reinterpret_cast<const float2*>(a.actions + (size_t)env * A * 8)[tid];        // this lane's two actions
         if (DR) *s_dr = load_leg_dr(a.dr + ((size_t)env * A + ant) * MMS_DR_FLOATS, leg);       // read back by this lane only
     }
-    for (int i = threadIdx.x; i < (int)(sizeof(mms_config) / 4); i += BLOCK) lds[i] = reinterpret_cast<const float*>(Cg)[i];
-    if (threadIdx.x < 4) s_leg[threadIdx.x] = load_leg_const(&Cg->model, threadIdx.x);
+    // (HEAD: staged by waves 8-11 above)
+    for (int i = threadIdx.x; i < (HEAD ? 0 : (int)(sizeof(mms_config) / 4)); i += BLOCK) lds[i] = reinterpret_cast<const float*>(Cg)[i];
+    if (!HEAD && threadIdx.x < 4) s_leg[threadIdx.x] = load_leg_const(&Cg->model, threadIdx.x);
 
-    for (int i = threadIdx.x; i < EPB * prev_dim; i += BLOCK) {       // the caches of the block's envs are contiguous in HBM
+    for (int i = threadIdx.x; i < (HEAD ? 0 : EPB * prev_dim); i += BLOCK) {       // the caches of the block's envs are contiguous in HBM
         const int e = i / prev_dim, k = i - e * prev_dim;
         const int en = min((int)(blockIdx.x * EPB + e), a.num_envs - 1);
         (lds_envs + (size_t)e * env_stride + (s_stage - env_lds))[k] = a.prev[(size_t)en * prev_dim + k];
@@ -603,6 +618,28 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
     }
 }
 
+#ifdef MMS_STEP_HEAD_TU
+// ---- the translation unit of the <..., HEAD = true> instantiation (step_head_kernels.hip) --------------------------------------------
+// A TU of its own: the register allocation of the 768-thread kernels sits AT the 168-VGPR limit of three waves per SIMD, and whether a
+// dword ends up in scratch turned out to depend on what ELSE the module holds (the plain instantiation picked up a spill from an edit
+// confined to the discarded `if constexpr (HEAD)` branch, and lost it again when the HEAD instantiation was not emitted).  Compiled
+// apart, an edit to the head prologue cannot move the allocation of the kernels every other caller launches.
+hipError_t launch_ten_ant_with_head(const StepArgs& a, size_t lds, int grid, hipStream_t stream) {
+    if (a.dr || a.num_envs % 16 != 0 || !a.head_on) return hipErrorInvalidValue;
+    static bool head_allowed[64] = {};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const void* k = reinterpret_cast<const void*>(ant_step_kernel<MMS_TASK_TEN_ANT, 768, 16, 10, false, true>);
+    if (dev >= 0 && dev < 64 && !head_allowed[dev]) {
+        if (hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
+        head_allowed[dev] = true;
+    }
+    hipLaunchKernelGGL((ant_step_kernel<MMS_TASK_TEN_ANT, 768, 16, 10, false, true>), dim3(grid), dim3(768), lds, stream, a);
+    return hipGetLastError();
+}
+#else
+hipError_t launch_ten_ant_with_head(const StepArgs& a, size_t lds, int grid, hipStream_t stream);       // step_head_kernels.hip
+
 // ---------------------------------------------------------------------------------------------
 // MultiIngenuity: one lane per helicopter, 4 lanes per env, 16 envs per wave64.
 // ---------------------------------------------------------------------------------------------
@@ -720,17 +757,7 @@ static hipError_t launch_ant(const StepArgs& a, hipStream_t stream) {
     if (a.head_on) {
         // the fused policy head exists for the 16-envs-per-block TenAnt layout without physical DR only (mms_bind_policy_head checks)
         if constexpr (TASK == MMS_TASK_TEN_ANT && BLOCK == 768 && EPB == 16 && AT == 10) {
-            if (a.dr || a.num_envs % 16 != 0) return hipErrorInvalidValue;
-            static bool head_allowed[64] = {};
-            int dev = 0;
-            if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-            const void* k = reinterpret_cast<const void*>(ant_step_kernel<TASK, BLOCK, EPB, AT, false, true>);
-            if (dev >= 0 && dev < 64 && !head_allowed[dev]) {
-                if (hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e != hipSuccess) return e;
-                head_allowed[dev] = true;
-            }
-            hipLaunchKernelGGL((ant_step_kernel<TASK, BLOCK, EPB, AT, false, true>), dim3(grid), dim3(BLOCK), lds, stream, a);
-            return hipGetLastError();
+            return launch_ten_ant_with_head(a, lds, grid, stream);
         } else {
             return hipErrorInvalidValue;
         }
@@ -783,5 +810,6 @@ hipError_t launch_step(const StepArgs& a, int task, hipStream_t stream) {
     if (lpe <= 512) return launch_ant<MMS_TASK_TEN_ANT, 512, 1, 0>(a, stream);
     return hipErrorInvalidValue;
 }
+#endif  // MMS_STEP_HEAD_TU
 
 }  // namespace mms

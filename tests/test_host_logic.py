@@ -347,10 +347,11 @@ def test_kernel_resources_of_the_built_library():
     step = {k: v for k, v in kernels.items() if "ant_step_kernelILi0E" in k}
     assert len(step) >= 8, sorted(kernels)
     for k, (vgpr, scratch) in step.items():
-        # (the instantiation with the policy head in its prologue, <..., false, true>, keeps ONE dword across the physics loop in scratch:
-        #  stored once and reloaded once per lane, 0.8 MB each way per launch against the 13-us launch it replaces; the others: none)
+        # (the instantiation with the policy head in its prologue, <..., false, true> -- a translation unit of its own, step_head_kernels.hip,
+        #  so that it cannot move the others' allocation -- keeps up to THREE address dwords across the physics loop in scratch: each stored
+        #  once and reloaded once or twice per lane, against the 13-us launch it replaces; the others: none)
         head = k.endswith("Lb0ELb1EEEvNS_8StepArgsE")
-        assert vgpr <= 168 and scratch <= (8 if head else 0), (k, vgpr, scratch)
+        assert vgpr <= 168 and scratch <= (16 if head else 0), (k, vgpr, scratch)
     for k, (vgpr, scratch) in kernels.items():
         if "linear_act" in k or "linear_split" in k or "split16_planes" in k or "split_planes" in k or "marl_heads" in k or "layernorm_rows" in k or "ppo_head_act" in k:
             assert scratch == 0, (k, vgpr, scratch)
