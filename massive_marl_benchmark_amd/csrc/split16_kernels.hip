@@ -31,6 +31,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "policy_args.h"
 
 namespace mms {
@@ -45,6 +47,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef MMS_S16_AUX_W
 #define MMS_S16_AUX_W 0
+#endif
+// the k-loop's form: 1 = rolling fragments (the ds_reads of slice k + 1 issued between the MFMAs of slice k), 0 = round 3's (every step
+// reads its fragments behind its barrier and waits for them); an A/B knob, bit-identical results
+// timing experiments (results INVALID; never in a shipped build): MMS_S16_EXP bit 0 = no operand DMA inside the k-loop, bit 1 = no MFMA
+// (the fragments are kept alive), bit 2 = no fragment reads inside the k-loop
+#ifndef MMS_S16_STAMP
+#define MMS_S16_STAMP 0
+#endif
+#ifndef MMS_S16_EXP
+#define MMS_S16_EXP 0
+#endif
+#if MMS_S16_EXP & 2
+#define MMS_S16_MFMA(a, b, c, x, y, z) ([&] { asm volatile("" ::"v"(a), "v"(b)); return c; }())
+#else
+#define MMS_S16_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#endif
+#ifndef MMS_S16_ROLL
+#define MMS_S16_ROLL 1
 #endif
 constexpr int kChunk16 = 128;                    // one row's two planes of 32 k
 constexpr float kLoScale = 2048.f;               // the lo plane holds the residual times 2^11
@@ -266,9 +286,13 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // ELU: the activation is ELU (compile time: straight-line epilogue); false = a.act at run time (ReLU, tanh, identity: not on a hot path).
 template <int MT, int OUT, int LN, bool ELU>
 __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; it has no __amdgpu_buffer_rsrc_t)
     using G = Geom16<MT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#if MMS_S16_STAMP   // clock probe (timing experiments only: overwrites the first 16 bytes of the first output): shader clocks and 100-MHz ticks of block 0
+    const uint64_t stamp_c0 = __builtin_readcyclecounter(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int wm = wave >> 1, wn = wave & 1;
     const int KC = a.KC, N = a.N;
     const int tiles_n = N / G::TN, tiles_m = a.M / G::TM, total = a.tiles;
@@ -286,8 +310,7 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
         goff[i] = (uint32_t)((i < G::NX ? row : row - G::TM) * (int)pitch + (c8 >> 2) * 64 + (c8 & 3) * 16);
     }
     int gi, m0, n0, tn;
-    const uint8_t* xb;
-    const uint8_t* wb;
+    __amdgpu_buffer_rsrc_t xr, wr;                                      // the current tile's X rows / W rows (raw buffers: [TM or TN rows][pitch] bytes)
     auto setup_tile = [&](int v) {
         int L = v;
         if ((total & 7) == 0 && (gridDim.x & 7) == 0) L = (v & 7) * (total >> 3) + (v >> 3);       // XCD-aware: as linear_split_kernel
@@ -297,16 +320,23 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
         gi = rest / tiles_m;
         m0 = tm * G::TM;
         n0 = tn * G::TN;
-        xb = reinterpret_cast<const uint8_t*>(a.x[gi]) + (size_t)m0 * pitch;
-        wb = reinterpret_cast<const uint8_t*>(a.w[gi]) + (size_t)n0 * pitch;
+        const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x[gi]) + (size_t)m0 * pitch;
+        const uint8_t* wb = reinterpret_cast<const uint8_t*>(a.w[gi]) + (size_t)n0 * pitch;
+        xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(xb), (short)0, (int)(G::TM * pitch), 0x00020000);
+        wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wb), (short)0, (int)(G::TN * pitch), 0x00020000);
+    };
+    // The operand DMA as BUFFER loads (`buffer_load_dwordx4 ... offen lds`): the tile's first X / W row in a resource descriptor (four
+    // SGPRs, rebuilt per tile by scalar code), the piece's lane offset as the 32-bit VGPR offset, the slice's offset in an SGPR -- no
+    // vector arithmetic per piece and no 64-bit lane addresses.  (As global loads the compiler kept base + lane offset as six 64-bit
+    // VGPR pairs per operand and added the slice's offset with a v_lshl_add_u64 per piece: 12-24 registers the rolling loop does not have.)
+    auto dma_piece = [&](int i, int kc, int buf) {                       // (i: compile time after unrolling)
+        const int so = kc * kChunk16;
+        if (i < G::NX) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr16_t)(lds + buf * G::BUF + (wave + 8 * i) * 1024), 16, goff[i], so, 0, MMS_S16_AUX_X);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lptr16_t)(lds + buf * G::BUF + (wave + 8 * i) * 1024), 16, goff[i], so, 0, MMS_S16_AUX_W);
     };
     auto dma_slice = [&](int kc, int buf) {
-        const uint8_t* xs = xb + (size_t)kc * kChunk16;
-        const uint8_t* ws = wb + (size_t)kc * kChunk16;
 #pragma unroll
-        for (int i = 0; i < G::NDMA; i++)
-            if (i < G::NX) __builtin_amdgcn_global_load_lds((gptr16_t)(xs + goff[i]), (lptr16_t)(lds + buf * G::BUF + (wave + 8 * i) * 1024), 16, 0, MMS_S16_AUX_X);
-            else __builtin_amdgcn_global_load_lds((gptr16_t)(ws + goff[i]), (lptr16_t)(lds + buf * G::BUF + (wave + 8 * i) * 1024), 16, 0, MMS_S16_AUX_W);
+        for (int i = 0; i < G::NDMA; i++) dma_piece(i, kc, buf);
     };
 
     // this lane's fragment address inside a buffer: row r16 of a 16-row tile, plane 0, k-group g4; plane 1 is the same address ^ 64
@@ -349,6 +379,94 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
         }
     };
 
+    // ---- the rolling form of a k-step (MMS_S16_ROLL) ----------------------------------------------------------------------------
+    // Round 3's step above opens with its fragment reads and waits for them: 10 ds_read_b128 behind the barrier, lgkmcnt(0), only then the
+    // first MFMA -- and the two waves of a SIMD do that in lockstep, so the matrix pipe idles for an LDS round trip (all eight waves'
+    // reads at once) in every step: per step 1536 cycles of MFMA, ~600 of LDS and ~400 of waits added up to the 2570 measured
+    // (profiles/r03_split16_layer_pmc.txt) instead of overlapping.  Here the fragments of slice k sit in registers when step k begins
+    // and the reads of slice k + 1 are issued BETWEEN its MFMAs, each into the registers the MFMAs in front of it have just used for
+    // the last time: the X fragments of row tile mt behind that tile's twelve MFMAs, the W fragments -- which every row tile needs --
+    // pair by pair inside the last row tile, whose MFMAs run column pair by column pair for that.  No register is added (the X
+    // fragments of all MT row tiles are live instead of one tile's: + 8 (MT - 1)), every accumulator sees its products in the same
+    // order as before (bit-identical results), and by the time a fragment is used its read is a step old.
+    // What the barrier at the top of step k then certifies: slice k + 1 has landed for every wave (each waited for its own pieces), and
+    // every wave has finished READING slice k (its lgkmcnt(0) in front of the barrier: the last of those reads were issued three MFMAs
+    // earlier) -- so slice k's buffer takes the DMA of slice k + 3, and the last slice's buffer is free for the epilogue's scratch
+    // without a barrier of its own.  DMA depth in time is unchanged (issued two barriers ahead of the barrier that needs it).
+    f16x8 wfr[4][2], xfr[MT][2];
+    auto read_w = [&](const uint8_t* base, int nt) {
+        wfr[nt][0] = *reinterpret_cast<const f16x8*>(base + (wfrag + nt * 16 * kChunk16));
+        wfr[nt][1] = *reinterpret_cast<const f16x8*>(base + ((wfrag + nt * 16 * kChunk16) ^ 64));
+    };
+    auto read_x = [&](const uint8_t* base, int mt) {
+        xfr[mt][0] = *reinterpret_cast<const f16x8*>(base + (xfrag + mt * 16 * kChunk16));
+        xfr[mt][1] = *reinterpret_cast<const f16x8*>(base + ((xfrag + mt * 16 * kChunk16) ^ 64));
+    };
+    // Where a wave issues the DMA of slice k + 3 inside step k: behind row tile `qa` (waves 0-3) / `qb` (waves 4-7) -- -1 = in front of the
+    // step's first MFMA, MT - 1 = inside the last row tile, behind its first column pair.  The two waves of a SIMD are waves w and w + 4:
+    // with qa != qb their DMA issue phases (6 instructions that hold the wave's in-order stream for 60-185 cycles each,
+    // MI355X_MICROARCH.md) do not coincide, and one of them feeds the matrix pipe while the other issues.
+#ifndef MMS_S16_DMA_SPREAD
+#define MMS_S16_DMA_SPREAD 0
+#endif
+#ifndef MMS_S16_DMA_QA
+#define MMS_S16_DMA_QA (MT == 4 ? 0 : -1)
+#endif
+#ifndef MMS_S16_DMA_QB
+#define MMS_S16_DMA_QB MMS_S16_DMA_QA
+#endif
+    const int qd = wave >= 4 ? ((MMS_S16_DMA_QB) < MT ? (MMS_S16_DMA_QB) : MT - 1) : ((MMS_S16_DMA_QA) < MT ? (MMS_S16_DMA_QA) : MT - 1);
+    auto roll_step = [&](auto more_c, const uint8_t* next, bool dma, int kc_dma, int buf_dma) {
+        constexpr bool more = decltype(more_c)::value && !(MMS_S16_EXP & 4);
+        if (MMS_S16_EXP & 1) dma = false;
+        if (!(MMS_S16_DMA_SPREAD) && dma && qd < 0) dma_slice(kc_dma, buf_dma);
+        // MMS_S16_DMA_SPREAD: the pieces one at a time between the groups of four MFMAs of the first MT - 1 row tiles (piece i behind group
+        // i NG / NDMA, waves 4-7 one group later) instead of all NDMA together
+        constexpr int NG = 3 * (MT - 1);
+        auto spread = [&](int g) {                                       // g: compile time
+            if (!(MMS_S16_DMA_SPREAD) || !dma) return;
+#pragma unroll
+            for (int i = 0; i < G::NDMA; i++) {
+                const int ga = i * NG / G::NDMA, gb = ga + 1 < NG ? ga + 1 : NG - 1;
+                if ((wave >= 4 ? gb : ga) == g) dma_piece(i, kc_dma, buf_dma);
+            }
+        };
+#pragma unroll
+        for (int mt = 0; mt < MT - 1; mt++) {
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) lo[mt][nt] = MMS_S16_MFMA(wfr[nt][1], xfr[mt][0], lo[mt][nt], 0, 0, 0);
+            if (MMS_S16_DMA_SPREAD) { __builtin_amdgcn_sched_barrier(0); spread(3 * mt); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) lo[mt][nt] = MMS_S16_MFMA(wfr[nt][0], xfr[mt][1], lo[mt][nt], 0, 0, 0);
+            if (MMS_S16_DMA_SPREAD) { __builtin_amdgcn_sched_barrier(0); spread(3 * mt + 1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) acc[mt][nt] = MMS_S16_MFMA(wfr[nt][0], xfr[mt][0], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            spread(3 * mt + 2);
+            if (!(MMS_S16_DMA_SPREAD) && dma && qd == mt) dma_slice(kc_dma, buf_dma);
+            if constexpr (more) read_x(next, mt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        constexpr int ml = MT - 1;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) lo[ml][2 * p + q] = MMS_S16_MFMA(wfr[2 * p + q][1], xfr[ml][0], lo[ml][2 * p + q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; q++) lo[ml][2 * p + q] = MMS_S16_MFMA(wfr[2 * p + q][0], xfr[ml][1], lo[ml][2 * p + q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; q++) acc[ml][2 * p + q] = MMS_S16_MFMA(wfr[2 * p + q][0], xfr[ml][0], acc[ml][2 * p + q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(MMS_S16_DMA_SPREAD) && p == 0 && dma && qd == ml) dma_slice(kc_dma, buf_dma);
+            if constexpr (more) { read_w(next, 2 * p); read_w(next, 2 * p + 1); }
+            if constexpr (more) if (p == 1) read_x(next, ml);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // (the LayerNorm-fold variants keep round 3's loop: their epilogue holds 24 more operand registers across the tile boundary, with the
+    //  rolling loop's 64 fragment registers they spill, and the grouped MAPPO pass measured no gain from it: 505 against 496-506 us)
+    constexpr bool kRoll = MMS_S16_ROLL != 0 && LN == 0;
+
     // 16-byte output stores a lane issues per tile BEHIND the next tile's prefetch (the count the next tile's first wait may leave
     // outstanding besides its own second slice); out_mode 2 stores under a predicate: none counted, the wait then covers them too
     constexpr int kStores = OUT == 2 ? 0 : MT * 4;
@@ -356,30 +474,73 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
     int v = blockIdx.x;
     setup_tile(v);
     int cur = 0;                                      // the buffer slice 0 of the current tile lives in
-    bool stores_in_flight = false;
+    bool stores_in_flight = false;                    // (= not the block's first tile)
     dma_slice(0, 0);
     if (KC > 1) dma_slice(1, 1);
+    if (kRoll && KC > 2) dma_slice(2, 2);             // (later tiles: behind their first barrier -- the third buffer is the epilogue's scratch until then)
     while (true) {
 #pragma unroll
         for (int i = 0; i < MT; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int kt = 0; kt < KC; kt++) {
-            const bool ahead = kt + 1 < KC;                             // slice kt + 1 is in flight behind slice kt
-            // (slice 1 of a following tile is older than the previous tile's stores as well, so step 1 could leave them outstanding too:
-            //  measured in round 4, no difference -- 0.498-0.506 against 0.495-0.501 ms per grouped MARL pass)
-            if (kt == 0 && stores_in_flight) {
-                if (ahead) wait_vm<G::NDMA + kStores>(); else wait_vm<kStores>();
+        int blast;
+        if constexpr (kRoll) {
+            // The wave's vector-memory queue at this point, oldest first: slice 0, slice 1, then slice 2 (first tile) or the previous
+            // tile's kStores output stores (later tiles).  Slice 0 has to have landed.
+            if (!stores_in_flight) {
+                if (KC > 2) wait_vm<2 * G::NDMA>(); else if (KC > 1) wait_vm<G::NDMA>(); else wait_vm<0>();
             } else {
-                if (ahead) wait_vm<G::NDMA>(); else wait_vm<0>();
+                if (KC > 1) wait_vm<G::NDMA + kStores>(); else wait_vm<kStores>();
             }
+            __builtin_amdgcn_s_barrier();                                // slice 0 is there for everyone; everyone has left the previous epilogue
+            {
+                const int b2 = cur == 0 ? 2 : cur - 1;                   // (cur + 2) % 3
+                if (stores_in_flight && KC > 2) dma_slice(2, b2);
+                const uint8_t* base = lds + cur * G::BUF;
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) read_w(base, nt);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) read_x(base, mt);
+            }
+            for (int kt = 0; kt + 1 < KC; kt++) {
+                const int nxt = cur == 2 ? 0 : cur + 1;                  // the buffer of slice kt + 1
+                // slice kt + 1 has to have landed; younger than it: the stores (kt = 0 of a later tile), slice kt + 2
+                const bool two = kt + 2 < KC;
+                if (kt == 0 && stores_in_flight) {
+                    if (two) wait_vm<G::NDMA + kStores>(); else wait_vm<kStores>();
+                } else {
+                    if (two) wait_vm<G::NDMA>(); else wait_vm<0>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's reads of slice kt are complete
+                __builtin_amdgcn_s_barrier();
+                roll_step(std::true_type{}, lds + nxt * G::BUF, kt + 3 < KC, kt + 3, cur);
+                cur = nxt;
+            }
+            // the last slice (peeled: one MFMA body per path -- as two arms of a branch inside the loop the two bodies' accumulators met in
+            // phi nodes the register allocator could not coalesce, 110 dwords of scratch)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const int nxt = cur == 0 ? 2 : cur - 1;                      // (cur + 2) % 3: the buffer step kt - 1 read
-            step(cur, kt + 2 < KC, kt + 2, nxt);
+            roll_step(std::false_type{}, lds, false, 0, 0);
             cur = cur == 2 ? 0 : cur + 1;
+            blast = cur == 0 ? 2 : cur - 1;                              // the buffer of the last slice: free (see above)
+        } else {
+            for (int kt = 0; kt < KC; kt++) {
+                const bool ahead = kt + 1 < KC;                             // slice kt + 1 is in flight behind slice kt
+                // (slice 1 of a following tile is older than the previous tile's stores as well, so step 1 could leave them outstanding too:
+                //  measured in round 4, no difference -- 0.498-0.506 against 0.495-0.501 ms per grouped MARL pass)
+                if (kt == 0 && stores_in_flight) {
+                    if (ahead) wait_vm<G::NDMA + kStores>(); else wait_vm<kStores>();
+                } else {
+                    if (ahead) wait_vm<G::NDMA>(); else wait_vm<0>();
+                }
+                __builtin_amdgcn_s_barrier();
+                const int nxt = cur == 0 ? 2 : cur - 1;                      // (cur + 2) % 3: the buffer step kt - 1 read
+                step(cur, kt + 2 < KC, kt + 2, nxt);
+                cur = cur == 2 ? 0 : cur + 1;
+            }
+            blast = cur == 0 ? 2 : cur - 1;                              // the buffer the last k-step read
+            __builtin_amdgcn_s_barrier();                                // ... which becomes the waves' epilogue scratch
         }
-        const int blast = cur == 0 ? 2 : cur - 1;                        // the buffer the last k-step read
-        __builtin_amdgcn_s_barrier();                                    // ... which becomes the waves' epilogue scratch
 
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));                                // (tile-independent epilogue addresses are re-derived, not kept live across the k-loop)
@@ -563,11 +724,20 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
                 }
             }
         }
+#if MMS_S16_STAMP
+        if (!has_next && blockIdx.x == 0 && t == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint64_t* dbg = reinterpret_cast<uint64_t*>(a.y[0]);
+            dbg[0] = __builtin_readcyclecounter() - stamp_c0;
+            dbg[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        }
+#endif
         if (!has_next) break;
         v = vnext;
         cur = nb0;
         stores_in_flight = true;
     }
+#endif
 }
 
 static hipError_t allow_lds16(const void* kernel, int slot, size_t bytes) {
