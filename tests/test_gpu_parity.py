@@ -1409,6 +1409,7 @@ def test_split16_layers_error(torch_cuda):
     for (M, N, K, act, G, planes_out, wscale) in ((4096, 1024, 388, 1, 2, 1, 1.0), (4096, 1024, 1024, 1, 2, 1, 1.0), (4096, 512, 1024, 1, 2, 0, 1.0),
                                                   (4096, 1024, 1024, 1, 1, 0, 1.0), (128, 128, 32, 0, 1, 1, 1.0), (256, 384, 100, 2, 2, 1, 1.0),
                                                   (384, 128, 1028, 3, 3, 0, 1.0), (8192, 256, 256, 2, 1, 1, 1.0), (2560, 512, 64, 1, 20, 1, 1.0),
+                                                  (2560, 512, 32, 1, 32, 1, 1.0), (2560, 512, 96, 1, 32, 0, 1.0),     # one / three k-steps, five tiles per CU (the rolling loop's short ends)
                                                   (512, 256, 512, 2, 2, 1, 1e4), (512, 256, 512, 0, 2, 1, 1e-5)):    # weights (and the bound chain) far from 1
         x = [torch.randn(M, K, device="cuda") for _ in range(G)]
         x = [torch.where(t > 0, t, torch.expm1(t)).contiguous() for t in x]                      # ELU-shaped activations
@@ -1500,7 +1501,8 @@ def test_split16_layers_repeatable(torch_cuda):
     """Race screen for the three-stage LDS-DMA pipeline of linear_split16_kernel (counted vmcnt + raw barriers, persistent tiles with
     the next tile's slices prefetched under the epilogue): the kernel has no atomics, so every launch on the same operands must
     reproduce the first one BIT FOR BIT -- 300 launches each of a one-tile-per-CU shape, a five-tiles-per-CU grouped shape (stores in
-    flight across tiles), a short-K shape (K = 64: two k-steps, the prefetch path dominates) and K = 32 (one step), planes and fp32 out."""
+    flight across tiles), a short-K shape (K = 64: two k-steps, the prefetch path dominates) and K = 32 (one step), planes and fp32 out;
+    one and three k-steps at five tiles per CU (the rolling k-loop's first / last-slice paths with stores in flight) and the PPO first layer."""
     torch = torch_cuda
     from massive_marl_benchmark_amd import _lib
     L = _lib.lib()
@@ -1508,7 +1510,8 @@ def test_split16_layers_repeatable(torch_cuda):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     torch.manual_seed(11)
     f32 = lambda *sh: torch.empty(*sh, device="cuda")
-    for (G, M, N, K, planes_out) in ((2, 4096, 1024, 1024, 1), (20, 4096, 512, 512, 1), (20, 2560, 512, 64, 0), (6, 1024, 256, 32, 1), (3, 384, 128, 96, 0)):
+    for (G, M, N, K, planes_out) in ((2, 4096, 1024, 1024, 1), (20, 4096, 512, 512, 1), (20, 2560, 512, 64, 0), (6, 1024, 256, 32, 1), (3, 384, 128, 96, 0),
+                                   (32, 2560, 512, 32, 1), (32, 2560, 512, 96, 0), (2, 4096, 1024, 388, 1)):
         x = [torch.randn(M, K, device="cuda") for _ in range(G)]
         w = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(G)]
         b = [torch.randn(N, device="cuda") * 0.1 for _ in range(G)]
