@@ -40,6 +40,7 @@ namespace mms {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_16 __attribute__((ext_vector_type(4)));
 
 // cache policy of the operand DMA (aux of global_load_lds: 0 default, 2 = nt); A/B knobs, the defaults are what measured fastest
 #ifndef MMS_S16_AUX_X
@@ -273,6 +274,41 @@ __device__ __forceinline__ float act16_apply(float v, int act) {
     return v;
 }
 
+// ELU on four accumulator values with as few vector instructions as the ISA allows (the epilogue is VALU-issue bound: 64 outputs per
+// lane, two waves per SIMD): x log2(e) as a packed multiply (the factor in a register: a packed instruction takes no literal), v_exp_f32
+// per element, the -1 as a packed add, and the select as ONE v_med3_f32 -- exp(x) - 1 >= x for every x, so x > 0 orders 0 < x <= e - 1 and
+// x <= 0 orders x <= e - 1 <= 0: the median of (x, 0, e - 1) is ELU(x).  (Where fp32 rounding puts e - 1 below a tiny negative x, |x| <
+// 6e-8, the median returns x itself, which is the more accurate value -- torch's expm1-based ELU returns x there too.)
+__device__ __forceinline__ f32x4 elu16_4(f32x4 x) {
+    float l2e = 1.44269504088896340736f;
+    asm volatile("" : "+s"(l2e));
+    const f32x4 t = x * l2e;
+    f32x4 e;
+#pragma unroll
+    for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(t[r]);
+    e = e - 1.f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = __builtin_amdgcn_fmed3f(x[r], 0.f, e[r]);
+    return x;
+}
+
+// Four outputs -> their two planes: hi = f16(x), lo = f16((x - hi) 2^11) with x = v ys.  x - hi is exact in fp32 and so is every
+// scaling by a power of two, hence lo = f16(fma(hi, -2^11, v (ys 2^11))) is the same number -- ONE v_fma_mix{lo,hi}_f16 per element
+// (f16 source read in place, f32 result rounded to f16 into one half of the destination) instead of convert back + subtract + multiply +
+// convert.  Returns {hi[0..1], hi[2..3], lo[0..1], lo[2..3]} as four dwords.
+__device__ __forceinline__ void planes16_4(f32x4 v, float ys, float ys2k, uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
+    const f32x4 x = v * ys, x2 = v * ys2k;
+    const f16x4 hi = __builtin_convertvector(x, f16x4);
+    h01 = reinterpret_cast<const uint32_t*>(&hi)[0];
+    h23 = reinterpret_cast<const uint32_t*>(&hi)[1];
+    float c = -kLoScale;
+    asm volatile("" : "+s"(c));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(l01) : "v"(h01), "s"(c), "v"(x2[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "s"(c), "v"(x2[1]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(l23) : "v"(h23), "s"(c), "v"(x2[2]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "s"(c), "v"(x2[3]));
+}
+
 typedef const __attribute__((address_space(1))) void* gptr16_t;
 typedef __attribute__((address_space(3))) void* lptr16_t;
 
@@ -292,6 +328,7 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 #if MMS_S16_STAMP   // clock probe (timing experiments only: overwrites the first 16 bytes of the first output): shader clocks and 100-MHz ticks of block 0
     const uint64_t stamp_c0 = __builtin_readcyclecounter(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t stamp_r12[2] = {0, 0};                  // ... first slice landed, k-loop done (last tile of the block)
 #endif
     const int wm = wave >> 1, wn = wave & 1;
     const int KC = a.KC, N = a.N;
@@ -493,6 +530,9 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
                 if (KC > 1) wait_vm<G::NDMA + kStores>(); else wait_vm<kStores>();
             }
             __builtin_amdgcn_s_barrier();                                // slice 0 is there for everyone; everyone has left the previous epilogue
+#if MMS_S16_STAMP
+            const uint64_t stamp_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
             {
                 const int b2 = cur == 0 ? 2 : cur - 1;                   // (cur + 2) % 3
                 if (stores_in_flight && KC > 2) dma_slice(2, b2);
@@ -522,6 +562,11 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
             __builtin_amdgcn_s_barrier();
             roll_step(std::false_type{}, lds, false, 0, 0);
             cur = cur == 2 ? 0 : cur + 1;
+#if MMS_S16_STAMP
+            asm volatile("s_nop 0" ::: "memory");
+            stamp_r12[0] = stamp_r1 - stamp_r0;
+            stamp_r12[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+#endif
             blast = cur == 0 ? 2 : cur - 1;                              // the buffer of the last slice: free (see above)
         } else {
             for (int kt = 0; kt < KC; kt++) {
@@ -610,8 +655,11 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
                 f32x4 raw = ((acc[mt][nt] + lo[mt][nt] * (1.f / kLoScale)) * w4) * xi[mt];
                 if constexpr (LN == 0) {
                     raw += f32x4{bias[nt].x, bias[nt].y, bias[nt].z, bias[nt].w};
+                    if constexpr (ELU) raw = elu16_4(raw);
+                    else {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) raw[r] = act16_apply(raw[r], ELU ? 1 : act);
+                        for (int r = 0; r < 4; r++) raw[r] = act16_apply(raw[r], act);
+                    }
                 }
                 acc[mt][nt] = raw;
             }
@@ -625,8 +673,7 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
                 for (int nt = 0; nt < 4; nt++) {
                     const f32x4 s4 = f32x4{sv[nt].x, sv[nt].y, sv[nt].z, sv[nt].w}, b4 = f32x4{bias[nt].x, bias[nt].y, bias[nt].z, bias[nt].w};
                     f32x4 x = (acc[mt][nt] - s4 * st[mt].x) * st[mt].y + b4;        // rstd (W~ h - mean s) + c, four wide (packed fp32)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) x[r] = (x[r] > 0.f) ? x[r] : (expf(x[r]) - 1.f);
+                    x = elu16_4(x);
                     acc[mt][nt] = x;
                     sum4 += x;
                 }
@@ -682,35 +729,38 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
         } else if constexpr (OUT == 1) {
             constexpr int RS = 2 * kChunk16 + 16;                        // scratch row: this wave's two chunks (64 n) of one m, padded
             uint8_t* scr = scr_base + wave * (16 * RS);
-            uint8_t* __restrict__ Y = reinterpret_cast<uint8_t*>(a.y[e_gi]);
-            const size_t ypitch = (size_t)(N / 32) * kChunk16;
+            const int ypitch = (N / 32) * kChunk16;
+            // this wave's 64 MT rows x 256 bytes of the output through a buffer descriptor of their own: a store's address is then one
+            // lane offset (row-in-group x pitch + piece) + a scalar offset per store, no 64-bit vector arithmetic (1.7 VALU per output before)
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<uint8_t*>(a.y[e_gi]) + (size_t)mbase * ypitch + (size_t)(nbase / 32) * kChunk16, (short)0, 16 * MT * ypitch, 0x00020000);
+            const int yoff = (lane_e >> 4) * ypitch + (lane_e & 15) * 16;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
+                const float ys2k = ys[mt] * kLoScale;
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
-                    f16x4 hi, lw;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float x = acc[mt][nt][r] * ys[mt];
-                        hi[r] = (_Float16)x;
-                        lw[r] = (_Float16)((x - (float)hi[r]) * kLoScale);
-                    }
+                    uint32_t h01, h23, l01, l23;
+                    planes16_4(acc[mt][nt], ys[mt], ys2k, h01, h23, l01, l23);
                     uint8_t* d = scr + r16 * RS + (nt >> 1) * kChunk16 + (nt & 1) * 32 + g4 * 8;
-                    *reinterpret_cast<f16x4*>(d) = hi;
-                    *reinterpret_cast<f16x4*>(d + 64) = lw;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(d + 64) = make_uint2(l01, l23);
                 }
                 // 16 rows x 256 bytes back out as 16-byte pieces: 16 per row, contiguous in HBM
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int idx = lane_e + 64 * j, row = idx >> 4, off = (idx & 15) * 16;
-                    const uint4 d = *reinterpret_cast<const uint4*>(scr + row * RS + off);
-                    *reinterpret_cast<uint4*>(Y + (size_t)(mbase + 16 * mt + row) * ypitch + (size_t)(nbase / 32) * kChunk16 + off) = d;
+                    const u32x4_16 d = *reinterpret_cast<const u32x4_16*>(scr + row * RS + off);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, yr, yoff, (16 * mt + 4 * j) * ypitch, 0);
                 }
             }
         } else {
             constexpr int RS = 256 + 16;
             uint8_t* scr = scr_base + wave * (16 * RS);
-            float* __restrict__ Y = reinterpret_cast<float*>(a.y[e_gi]);
+            const int ypitch = N * 4;
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<uint8_t*>(a.y[e_gi]) + (size_t)mbase * ypitch + (size_t)nbase * 4, (short)0, 16 * MT * ypitch, 0x00020000);
+            const int yoff = (lane_e >> 4) * ypitch + (lane_e & 15) * 16;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
@@ -719,8 +769,8 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int idx = lane_e + 64 * j, row = idx >> 4, off = (idx & 15) * 16;
-                    const uint4 d = *reinterpret_cast<const uint4*>(scr + row * RS + off);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(Y + (size_t)(mbase + 16 * mt + row) * N + nbase) + off) = d;
+                    const u32x4_16 d = *reinterpret_cast<const u32x4_16*>(scr + row * RS + off);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, yr, yoff, (16 * mt + 4 * j) * ypitch, 0);
                 }
             }
         }
@@ -730,6 +780,8 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
             uint64_t* dbg = reinterpret_cast<uint64_t*>(a.y[0]);
             dbg[0] = __builtin_readcyclecounter() - stamp_c0;
             dbg[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+            dbg[2] = stamp_r12[0];
+            dbg[3] = stamp_r12[1];
         }
 #endif
         if (!has_next) break;

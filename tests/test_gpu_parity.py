@@ -1714,6 +1714,7 @@ def test_ppo_training_loop_on_the_hip_path(torch_cuda):
     base = ["--task", "OneAnt", "--num-envs", "1024", "--iterations", "90", "--hidden", "256", "128", "128", "--split-min-tiles", "0", "--log-every", "1000"]
     control = train_ppo_demo.train(train_ppo_demo.parse(base + ["--lr", "0", "--fixed-lr"]), log=lambda m: None)
     control_late = sum(c for _, c in control["episodes"][60:])
+    control_total = sum(c for _, c in control["episodes"])
     control["env"].task.engine.close()
     for use_planes in (False, True):
         args = train_ppo_demo.parse(base + (["--obs-planes"] if use_planes else []))
@@ -1722,12 +1723,17 @@ def test_ppo_training_loop_on_the_hip_path(torch_cuda):
         assert ac._split_bufs and ac._h16 is not None, "the split path did not run"
         assert all(np.isfinite(hist)) and bool(torch.isfinite(obs).all())
         # learning: against a CONTROL run of the same loop from the same seed with a learning rate of zero (the initial policy, whose
-        # ants keep falling at a steady rate: 426 episodes lost in the last third of the run) the trained policy loses fewer than half as
-        # many (measured: none); the mean return of the episodes that end -- the quantity the reference logs, ppo.py:196-201 -- does not
-        # fall (second half of the ended episodes against the first; late in the run hardly any episode ends, so this half-split is a
-        # weak signal and only guarded against a drop)
+        # ants keep falling at a steady rate: ~420 episodes lost in every third of the run) the trained policy loses fewer episodes --
+        # over the whole run fewer than 0.6 x the control's (measured over three seeds x both observation paths x two builds of the
+        # layer kernel whose outputs differ in the last bit: 0.06-0.42 x), in the last third fewer than the control (0-0.72 x: WHICH
+        # gait a run finds, and how many ants it still drops late, moves with the arithmetic's last bits and with the seed -- 0 to 304
+        # lost late across those twelve runs -- so the late figure alone is a weak gate; tools/scratch/train_ab.py prints the spread);
+        # the mean return of the episodes that end -- the quantity the reference logs, ppo.py:196-201 -- does not fall (second half of
+        # the ended episodes against the first; only guarded against a drop)
         ended_late = sum(c for _, c in eps[60:])
-        assert control_late > 10 and ended_late < 0.5 * control_late, (ended_late, control_late)
+        ended_total = sum(c for _, c in eps)
+        assert control_late > 10 and ended_late < control_late, (ended_late, control_late)
+        assert ended_total < 0.6 * control_total, (ended_total, control_total)
         ended = [(r / c, c) for r, c in eps if c > 0]
         total = sum(c for _, c in ended)
         assert total >= 20, total
@@ -1746,7 +1752,7 @@ def test_ppo_training_loop_on_the_hip_path(torch_cuda):
         rel = lambda a, b: float((a - b).abs().max() / (1.0 + b.abs().max()))
         assert rel(mu, mu_t) < 1e-5 and rel(v, v_t) < 1e-5, (rel(mu, mu_t), rel(v, v_t))
         parity.record("gpu/ppo_training_loop/%s" % ("obs_planes" if use_planes else "own_split"), mean_return_first_half_of_ended_episodes=first, mean_return_second_half=last, episodes_lost_last_third=ended_late,
-                      episodes_lost_last_third_untrained_control=control_late,
+                      episodes_lost_last_third_untrained_control=control_late, episodes_lost=ended_total, episodes_lost_untrained_control=control_total,
                       act_vs_torch_after_last_update=max(rel(mu, mu_t), rel(v, v_t)))
         out["env"].task.engine.close()
 

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from massive_marl_benchmark_amd import _lib  # noqa: E402
 L, d, stream = _lib.for_device(torch.device("cuda"))
-M, N, K = 4096, 1024, 1024
+M, N, K = 4096, 1024, int(os.environ.get("PROBE_K", "1024"))
 arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 nb = lambda r, K: r * ((K + 31) // 32) * 128
 f32 = lambda n: torch.empty(n, device="cuda")
@@ -25,6 +25,12 @@ for i in range(60):
     assert fn() == 0
     if i >= 50:
         torch.cuda.synchronize()
-        c, r = y[0][:16].view(torch.int64).tolist()
-        out.append("%.0f cyc / %.2f us = %.2f GHz" % (c, r / 100.0, c / (r * 10.0)))
-print(os.environ.get("MMS_LIB", "default").split("/")[-1], "|", "; ".join(out[-3:]))
+        c, r, r1, r2 = y[0][:32].view(torch.int64).tolist()
+        out.append("%.0f cyc / %.2f us = %.2f GHz; first slice landed at %.2f us, k-loop done at %.2f us, block done at %.2f us" % (c, r / 100.0, c / (r * 10.0), r1 / 100.0, r2 / 100.0, r / 100.0))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(100):
+    fn()
+e1.record()
+torch.cuda.synchronize()
+print(os.environ.get("MMS_LIB", "default").split("/")[-1], "K", K, "| launch to launch %.2f us |" % (e0.elapsed_time(e1) * 10), " || ".join(out[-2:]))
