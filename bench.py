@@ -610,8 +610,11 @@ def policy_layer_roofline(torch, ac, obs, args):
             "fp32_equivalent_tflops": flops32 / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flops32 / (ms * 1e-3) / 1e12 / 157.3,
             "ms_per_pass": ms, "launches_per_pass": len(lins) + (1 if split else 0), "plane_products_per_fp32_product": products, "traffic": None,
             "note": "both networks' hidden layers [%s] at %d rows: observation split + one launch per layer, eager, back to back, HIP events; "
-                    "achieved counts every plane product the matrix pipe executes; the layers are bound by the L2 -> LDS operand stream "
-                    "(48 KB per 256 x 128 k-step and CU), not by the pipe: DESIGN.md 5.10" % (", ".join(str(l.out_features) for l in lins), M)}
+                    "achieved counts every plane product the matrix pipe executes; `peak` is the dense 16-bit figure at 2.4 GHz -- in the "
+                    "two-plane kernel the chip holds 1.55 GHz (power-limited) and the matrix pipe is busy 85 %% of the k-loop's cycles "
+                    "(in-kernel clock probe, profiles/r04_split16_kloop_experiments.txt; DESIGN.md 5.10)" % (", ".join(str(l.out_features) for l in lins), M),
+            "clock_ghz_in_kernel": 1.55 if (split and ac.split_format == "f16x2") else None,
+            "clock_source": "profiles/r04_split16_kloop_experiments.txt (s_memtime / s_memrealtime of block 0, a -DMMS_S16_STAMP build; not measured in this run)"}
 
 
 def policy_layer_errors(torch, ac, obs):

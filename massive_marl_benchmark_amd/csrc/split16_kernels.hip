@@ -4,10 +4,12 @@
 // two per ROW, hi = f16(x s), lo = f16((x s - hi) 2^11): 11 + 11 significant bits and the residual's sign, i.e. the operand is kept
 // to 2^-22 |x| worst case (4e-8 rms) instead of exactly, in 4 bytes instead of 6, and
 //     x w = hi_x hi_w + 2^-11 (hi_x lo_w + lo_x hi_w) + [2^-22 lo_x lo_w <= 2^-24 |x w|, dropped]
-// is THREE v_mfma_f32_16x16x32_f16 products instead of six bf16 ones.  The layers are bound by the L2 -> LDS operand stream (16-18
-// bytes per clock and CU, profiles/r03_split_layer_pmc.txt), so two thirds of the bytes is two thirds of the k-loop, and at 48 KB
-// per 256 x 128 k-step THREE LDS stages fit: the DMA of slice k + 2 is in flight across the barrier of step k + 1 (counted vmcnt,
-// raw s_barrier) instead of every step draining the queue.  Error against the float64 product, measured like the bf16 kernel's
+// is THREE v_mfma_f32_16x16x32_f16 products instead of six bf16 ones, two thirds of the operand bytes, and at 48 KB per 256 x 128
+// k-step THREE LDS stages fit: a slice's DMA (buffer loads into LDS) is in flight across two barriers (counted vmcnt, raw s_barrier)
+// instead of every step draining the queue.  Since round 4 the k-loop keeps a slice's fragments in registers and issues the next
+// slice's ds_reads between the MFMAs (MMS_S16_ROLL, below).  What bounds it, measured with timing builds and an in-kernel clock probe
+// (MMS_S16_EXP / MMS_S16_STAMP; profiles/r04_split16_kloop_experiments.txt): the chip is power-limited in this kernel (1.55 GHz) and
+// the matrix pipe is busy 85 % of the k-loop's cycles.  Error against the float64 product, measured like the bf16 kernel's
 // (tests/test_gpu_parity.py::test_split16_layers_error): still below the exact-fp32 MFMA kernel's, whose k-ordered fma chain
 // rounds 16 times as often.
 //

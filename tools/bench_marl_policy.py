@@ -103,7 +103,7 @@ def main():
                        "exact_fp32_series": {"achieved": flops / (res["grouped_exact_fp32_graph_ms"] * 1e-3) / 1e12, "peak": 157.3,
                                              "frac": flops / (res["grouped_exact_fp32_graph_ms"] * 1e-3) / 1e12 / 157.3},
                        "note": "fp32-equivalent FLOPs of the 60 hidden-layer GEMMs + heads; split layers = 2 row-scaled fp16 planes, 3 f16 MFMA products, fp32 accumulate "
-                               "(the layers are bound by the L2 -> LDS operand stream, not by the matrix pipe: DESIGN.md 5.9)"}
+                               "(peak at 2.4 GHz; the two-plane kernel runs power-limited at ~1.55 GHz: DESIGN.md 5.10, profiles/r04_split16_kloop_experiments.txt)"}
     # error of both paths against float64 (deterministic means / values of agent 0)
     import copy
     with torch.no_grad():
