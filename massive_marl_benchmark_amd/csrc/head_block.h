@@ -5,6 +5,9 @@
 //   ppo_head_block   actor's last Linear layer on the matrix cores (module.py:29-30), critic's last layer as a dot product (:49), sampling
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef MMS_HEAD_STAMP
+#define MMS_HEAD_STAMP 0
+#endif
 #include <stdint.h>
 
 #include "mms_lane.h"
@@ -71,6 +74,13 @@ __device__ __forceinline__ void ppo_head_block(float* s_part, const int tid, con
                                                int64_t row_offset, int ref_scale, const PpoActOut& o, int64_t N, int A) {
     constexpr int AP = NCT * 16, ROWS = 16 * RT;
     constexpr int RPW = ROWS / WAVES;                                        // rows sampled per wave (WAVES in 1, 2, 4, 8)
+#if MMS_HEAD_STAMP   // phase probe (timing experiments only): 100-MHz ticks of block 0 / wave 0 into sigma_slot[0..5]
+    uint64_t st[6];
+    st[0] = __builtin_amdgcn_s_memrealtime();
+#define MMS_HEAD_ST(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MMS_HEAD_ST(i) do { } while (0)
+#endif
     const int lane = tid & 63, wave = active ? (tid >> 6) : 0;
     const int i = lane & 15, g = lane >> 4;
     float v_rows[RPW];
@@ -111,6 +121,7 @@ __device__ __forceinline__ void ppo_head_block(float* s_part, const int tid, con
                 v_rows[q] = part + vbias[0];
             }
         }
+        MMS_HEAD_ST(1);                                                      // the critic's dot products are done
         const int kq = H / WAVES;
         const int kbeg = wave * kq;
         // 64 k per trip (the launcher picks WAVES so that H / WAVES is a multiple of 64): the 4 x (RT + NCT) float4 loads of a
@@ -141,6 +152,7 @@ __device__ __forceinline__ void ppo_head_block(float* s_part, const int tid, con
                     }
             }
         }
+        MMS_HEAD_ST(2);                                                      // operands loaded, MFMAs issued
         // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
         float* mine = s_part + (size_t)wave * ROWS * AP;
 #pragma unroll
@@ -152,6 +164,7 @@ __device__ __forceinline__ void ppo_head_block(float* s_part, const int tid, con
             }
     }
     __syncthreads();
+    MMS_HEAD_ST(3);
     float* s_mean = s_part + (size_t)WAVES * ROWS * AP;
     if (active)
         for (int e = tid; e < ROWS * AP; e += 64 * WAVES) {
@@ -162,6 +175,7 @@ __device__ __forceinline__ void ppo_head_block(float* s_part, const int tid, con
             s_mean[e] = sum + bias[j < A ? j : 0];
         }
     __syncthreads();
+    MMS_HEAD_ST(4);
     if (active) {
 #pragma unroll
         for (int q = 0; q < RPW; q++) {
@@ -171,6 +185,11 @@ __device__ __forceinline__ void ppo_head_block(float* s_part, const int tid, con
             ppo_sample_row(s_mean + r * AP, value, log_std, seed, counters, row_offset, ref_scale, o, row, A, lane, vhidden != nullptr, v_rows[q]);
         }
     }
+#if MMS_HEAD_STAMP
+    MMS_HEAD_ST(5);
+    if (r0 == 0 && tid == 0 && o.sigma_slot)
+        for (int i = 1; i < 6; i++) o.sigma_slot[i] = 0.01f * (float)(st[i] - st[0]);
+#endif
 }
 
 }  // namespace mms
