@@ -603,6 +603,40 @@ def policy_layer_roofline(torch, ac, obs, args):
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
+    # the clock the chip holds inside the layer launches, measured live (mms_layer_clock_probe: workgroup 0 of every two-plane layer
+    # launch stores its life in shader cycles and in 100-MHz ticks), in the last of eight back-to-back passes, eight times; and the matrix pipe's share of
+    # those cycles: a 32-wide k-step is 48 v_mfma_f32_16x16x32_f16 of 16 cycles for each of a SIMD's two waves on 256-row tiles, 24 on
+    # 128-row tiles (one tile per CU at these shapes)
+    clock = None
+    if split and ac.split_format == "f16x2":
+        import ctypes
+        from massive_marl_benchmark_amd import _lib
+        L = _lib.lib()
+        nl = len(lins)
+        probe = torch.zeros(nl, 2, dtype=torch.int64, device=obs.device)
+        acc = torch.zeros(nl, 2, dtype=torch.float64)
+        reps = 8
+        with torch.no_grad():
+            _lib.check(L.mms_layer_clock_probe(obs.device.index or 0, ctypes.c_void_p(probe.data_ptr()), nl), None, "mms_layer_clock_probe")
+            try:
+                for _ in range(reps):
+                    _lib.check(L.mms_layer_clock_probe(obs.device.index or 0, ctypes.c_void_p(probe.data_ptr()), nl), None, "mms_layer_clock_probe")   # slot 0 = first layer
+                    for _ in range(8):                                   # back to back: the slots keep the last pass (the clock of a busy chip)
+                        ac._fused_hidden(obs, obs)
+                    torch.cuda.synchronize()
+                    acc += probe.cpu().double()
+            finally:
+                L.mms_layer_clock_probe(obs.device.index or 0, None, 0)
+        tiles256 = 2 * (M // 256) if M % 256 == 0 else 0
+        per_layer = []
+        for i, l in enumerate(lins):
+            cyc, ticks = float(acc[i, 0]) / reps, float(acc[i, 1]) / reps
+            big = tiles256 * (l.out_features // 128) >= 256                      # (launch_linear_split16's choice on a 256-CU part)
+            mfma_cycles = ((l.in_features + 31) // 32) * (2 * 48 if big else 2 * 24) * 16
+            per_layer.append({"layer": "%d -> %d" % (l.in_features, l.out_features), "clock_ghz": cyc / max(ticks, 1.0) * 0.1, "workgroup0_us": ticks * 0.01,
+                              "matrix_pipe_busy_of_cycles": mfma_cycles / max(cyc, 1.0)})
+        clock = {"per_layer": per_layer, "note": "workgroup 0 of each launch: s_memtime / s_memrealtime deltas over its life (prologue, k-loop, epilogue), the last of 8 back-to-back passes, %d such runs averaged; "
+                                                 "matrix_pipe_busy_of_cycles = the launch's MFMA cycles per SIMD / the workgroup's cycles" % reps}
     peak = 2500.0 if split else 157.3
     achieved = flops32 * products / (ms * 1e-3) / 1e12
     kernel = ("mms::linear_split16_kernel (2 fp16 planes)" if ac.split_format == "f16x2" else "mms::linear_split_kernel (3 bf16 planes)") if split else "mms::linear_act_fast_kernel (fp32 MFMA)"
@@ -610,11 +644,10 @@ def policy_layer_roofline(torch, ac, obs, args):
             "fp32_equivalent_tflops": flops32 / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flops32 / (ms * 1e-3) / 1e12 / 157.3,
             "ms_per_pass": ms, "launches_per_pass": len(lins) + (1 if split else 0), "plane_products_per_fp32_product": products, "traffic": None,
             "note": "both networks' hidden layers [%s] at %d rows: observation split + one launch per layer, eager, back to back, HIP events; "
-                    "achieved counts every plane product the matrix pipe executes; `peak` is the dense 16-bit figure at 2.4 GHz -- in the "
-                    "two-plane kernel the chip holds 1.55 GHz (power-limited) and the matrix pipe is busy 85 %% of the k-loop's cycles "
-                    "(in-kernel clock probe, profiles/r04_split16_kloop_experiments.txt; DESIGN.md 5.10)" % (", ".join(str(l.out_features) for l in lins), M),
-            "clock_ghz_in_kernel": 1.55 if (split and ac.split_format == "f16x2") else None,
-            "clock_source": "profiles/r04_split16_kloop_experiments.txt (s_memtime / s_memrealtime of block 0, a -DMMS_S16_STAMP build; not measured in this run)"}
+                    "achieved counts every plane product the matrix pipe executes; `peak` is the dense 16-bit figure at 2.4 GHz -- the two-plane "
+                    "kernel runs power-limited: `clock_in_kernel` is the clock the chip holds in each launch of this run and the matrix pipe's share "
+                    "of the launch's cycles (85 %% of the k-loop's: profiles/r04_split16_kloop_experiments.txt; DESIGN.md 5.10)" % (", ".join(str(l.out_features) for l in lins), M),
+            "clock_in_kernel": clock}
 
 
 def policy_layer_errors(torch, ac, obs):

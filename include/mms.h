@@ -223,6 +223,15 @@ int mms_gae_ppo_normalized(int device, const float* rewards, const uint8_t* done
                            float* returns, float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam,
                            void* hip_stream);
 
+/* Diagnostics: the clock the chip holds inside the two-plane layer kernel (mms_linear_group_act_split16).  With `out` (device memory,
+ * 2 x slots uint64, 8-byte aligned) every such launch issued after this call stores, by its workgroup 0, {shader cycles, 100-MHz ticks}
+ * of that workgroup's life into out[2 (n % slots)], n = 0, 1, ... counting launches from this call: cycles / ticks x 0.1 = GHz.  The
+ * reference has no counterpart (torch modules, agents/algorithms/rl/ppo/module.py:27-52); bench.py reports the figure beside
+ * `roofline_policy_layers` because the kernel runs power-limited: its MFMA rate has to be read against the clock it is granted, not
+ * against the 2.4 GHz the dense peak is quoted at.  out = NULL switches the probe off (the default).  Process-wide, not thread-safe;
+ * launches captured in a hipGraph keep the slot they were captured with.  The CPU build accepts the call and stores nothing. */
+int mms_layer_clock_probe(int device, uint64_t* out, int32_t slots);
+
 /* MARL GAE (separated_buffer.py:153-164, use_proper_time_limits=False): value_preds [T+1,N]
  * (row T already holds next_value), masks [T+1,N], rewards [T,N], returns [T+1,N];
  * denormalisation x*sqrt(var)+mean when use_norm (PopArt / ValueNorm). */

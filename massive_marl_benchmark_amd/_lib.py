@@ -17,7 +17,7 @@ _lib_cpu = None
 
 # every symbol include/mms.h declares (tests check that the library exports all of them)
 SYMBOLS = ["mms_create", "mms_destroy", "mms_get_tensor", "mms_step", "mms_post_step", "mms_reset_all", "mms_set_state",
-           "mms_bind_obs_out", "mms_bind_obs_planes16", "mms_bind_actions", "mms_bind_policy_head", "mms_set_dr", "mms_set_obs_outputs", "mms_bind_rollout_out", "mms_ppo_act", "mms_ppo_heads_act", "mms_linear2_act", "mms_linear_group_act", "mms_split_planes", "mms_split_planes_group", "mms_linear_group_act_split", "mms_split_planes16_group", "mms_weight_planes16_group", "mms_chain_refresh16", "mms_fold_planes16_group", "mms_fold_scales16_group", "mms_linear_group_act_split16", "mms_row_stats_chan_group", "mms_marl_heads_finish", "mms_row_stats_group", "mms_row_moments_group", "mms_layernorm_group", "mms_marl_heads_act", "mms_marl_views", "mms_gae_ppo", "mms_adv_normalize", "mms_gae_ppo_normalized", "mms_gae_marl", "mms_gae_marl_agents",
+           "mms_bind_obs_out", "mms_bind_obs_planes16", "mms_bind_actions", "mms_bind_policy_head", "mms_set_dr", "mms_set_obs_outputs", "mms_bind_rollout_out", "mms_ppo_act", "mms_ppo_heads_act", "mms_linear2_act", "mms_linear_group_act", "mms_split_planes", "mms_split_planes_group", "mms_linear_group_act_split", "mms_split_planes16_group", "mms_weight_planes16_group", "mms_chain_refresh16", "mms_fold_planes16_group", "mms_fold_scales16_group", "mms_linear_group_act_split16", "mms_row_stats_chan_group", "mms_marl_heads_finish", "mms_row_stats_group", "mms_row_moments_group", "mms_layernorm_group", "mms_marl_heads_act", "mms_marl_views", "mms_gae_ppo", "mms_adv_normalize", "mms_gae_ppo_normalized", "mms_layer_clock_probe", "mms_gae_marl", "mms_gae_marl_agents",
            "mms_last_error", "mms_abi_version"]
 
 
@@ -68,6 +68,7 @@ def _bind(path):
     L.mms_gae_ppo.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, c64, cf, cf, vp]
     L.mms_adv_normalize.argtypes = [ci, vp, vp, c64, vp]
     L.mms_gae_ppo_normalized.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, c64, cf, cf, vp]
+    L.mms_layer_clock_probe.argtypes = [ci, vp, ctypes.c_int32]
     L.mms_gae_marl.argtypes = [ci, vp, vp, vp, vp, ctypes.c_int32, c64, cf, cf, ctypes.c_int32, vp, vp, vp]
     L.mms_gae_marl_agents.argtypes = [ci, vp, vp, vp, vp, ctypes.c_int32, c64, ctypes.c_int32, cf, cf, ctypes.c_int32, vp, vp, vp]
     L.mms_last_error.argtypes = [vp]

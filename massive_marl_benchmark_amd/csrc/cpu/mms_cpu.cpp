@@ -327,6 +327,13 @@ MMS_API int mms_adv_normalize(int device, float* advantages, const double* stats
     for (int64_t i = 0; i < count; i++) advantages[i] = (advantages[i] - fm) * inv;
     return 0;
 }
+MMS_API int mms_layer_clock_probe(int device, uint64_t* out, int32_t slots) {
+    (void)device;
+    if (out && slots < 1) { g_error = "mms_layer_clock_probe: slots must be >= 1 with an output buffer"; return 1; }
+    if (out && (reinterpret_cast<uintptr_t>(out) & 7) != 0) { g_error = "mms_layer_clock_probe: the buffer must be 8-byte aligned"; return 1; }
+    return 0;                                     // (no shader clock on this build: nothing is stored)
+}
+
 MMS_API int mms_gae_ppo_normalized(int device, const float* rewards, const uint8_t* dones, const float* values, const float* last_values, float* returns,
                                    float* advantages, double* stats, int32_t T, int64_t N, float gamma, float lam, void*) {
     if (cpu_only(device)) return 1;

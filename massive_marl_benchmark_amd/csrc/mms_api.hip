@@ -769,6 +769,14 @@ __attribute__((visibility("default"))) int mms_linear_group_act_split16(int devi
     return 0;
 }
 
+__attribute__((visibility("default"))) int mms_layer_clock_probe(int device, uint64_t* out, int32_t slots) {
+    (void)device;
+    if (out && slots < 1) { g_create_error = "mms_layer_clock_probe: slots must be >= 1 with an output buffer"; return 1; }
+    if (out && (reinterpret_cast<uintptr_t>(out) & 7) != 0) { g_create_error = "mms_layer_clock_probe: the buffer must be 8-byte aligned"; return 1; }
+    mms::set_split16_clock_probe(out, out ? slots : 0);
+    return 0;
+}
+
 __attribute__((visibility("default"))) int mms_row_stats_chan_group(int device, int32_t groups, int64_t M, int32_t slots, const float* const* part,
                                                                     float* const* stat, float eps, void* s) {
     MMS_DEV(device)

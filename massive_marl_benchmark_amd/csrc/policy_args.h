@@ -145,6 +145,7 @@ struct Split16LinearArgs {
     float* head_part[kMaxGroups];
     int hdims[kMaxGroups];
     int tiles;
+    uint64_t* clock_probe;          // optional (mms_layer_clock_probe): block 0 stores its life in shader cycles and in 100-MHz ticks
 };
 
 // H32 planes of `groups` matrices of the same shape (x_g rows at pitch x_pitch floats) with a power-of-two scale per row taken from the
@@ -223,6 +224,7 @@ hipError_t launch_fold_scales16(const FoldScalesArgs& a, int groups, hipStream_t
 hipError_t launch_split16_planes_group(const Split16PlanesArgs& a, int groups, hipStream_t s);
 hipError_t launch_chain_refresh16(const ChainRefreshArgs& a, hipStream_t s);
 hipError_t launch_linear_split16(const Split16LinearArgs& a, int groups, hipStream_t s);
+void set_split16_clock_probe(uint64_t* out, int slots);   // mms_layer_clock_probe
 hipError_t launch_linear_act(const LinearArgs& a, int groups, hipStream_t s);
 hipError_t launch_row_stats_chan(const RowStatsArgs& a, int groups, hipStream_t s);
 hipError_t launch_marl_heads_finish(const HeadsFinishArgs& a, int groups, hipStream_t s);

@@ -328,7 +328,10 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
     using G = Geom16<MT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-#if MMS_S16_STAMP   // clock probe (timing experiments only: overwrites the first 16 bytes of the first output): shader clocks and 100-MHz ticks of block 0
+    // mms_layer_clock_probe: block 0 reports the clock the chip holds while this launch runs (shader cycles and 100-MHz ticks of its life)
+    uint64_t probe_c0 = 0, probe_r0 = 0;
+    if (a.clock_probe) { probe_c0 = __builtin_readcyclecounter(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
+#if MMS_S16_STAMP   // phase stamps (timing experiments only: overwrites the first 32 bytes of the first output): shader clocks and 100-MHz ticks of block 0
     const uint64_t stamp_c0 = __builtin_readcyclecounter(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
     uint64_t stamp_r12[2] = {0, 0};                  // ... first slice landed, k-loop done (last tile of the block)
 #endif
@@ -786,6 +789,11 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
             dbg[3] = stamp_r12[1];
         }
 #endif
+        if (!has_next && a.clock_probe && blockIdx.x == 0 && t == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the block's own stores have left
+            a.clock_probe[0] = __builtin_readcyclecounter() - probe_c0;
+            a.clock_probe[1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+        }
         if (!has_next) break;
         v = vnext;
         cur = nb0;
@@ -805,6 +813,16 @@ static hipError_t allow_lds16(const void* kernel, int slot, size_t bytes) {
         if (dev >= 0 && dev < 64) done[slot][dev] = true;
     }
     return hipSuccess;
+}
+
+// mms_layer_clock_probe: launches from here on report into out[2 (n % slots)], n counting from this call (out = nullptr: off)
+static uint64_t* g_probe_out = nullptr;
+static int g_probe_slots = 0;
+static long g_probe_next = 0;
+void set_split16_clock_probe(uint64_t* out, int slots) {
+    g_probe_out = (out && slots > 0) ? out : nullptr;
+    g_probe_slots = slots;
+    g_probe_next = 0;
 }
 
 // M a multiple of 128, N of 128 (checked by the caller).  256-row tiles when they still give every CU a block.
@@ -833,6 +851,7 @@ hipError_t launch_linear_split16(const Split16LinearArgs& a, int groups, hipStre
         if (hipError_t e = allow_lds16(reinterpret_cast<const void*>(kern), SLOT + ((LNF != 0 || a.act == 1) ? 0 : 8), Geom16<MT>::LDS); e != hipSuccess) return e; \
         Split16LinearArgs b = a;                                                                                               \
         b.tiles = (int)((int64_t)groups * (a.M / (64 * MT)) * (a.N / 128));                                                    \
+        b.clock_probe = g_probe_out ? g_probe_out + 2 * (g_probe_next++ % g_probe_slots) : nullptr;                           \
         const unsigned grid = (unsigned)(b.tiles < cus ? b.tiles : cus);        /* persistent: at most one block per CU */      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Geom16<MT>::LDS, s, b);                                                \
     }

@@ -143,6 +143,9 @@ def check_abi_error_paths(L, device):
     fails(L.mms_marl_heads_act(device, 1, 8, 8, one, one, one, one, one, (ctypes.c_int32 * 1)(17), None, one, None, None, None, 0, 0, 1e-5, None))
     fails(L.mms_gae_ppo_normalized(device, zp, zp, zp, zp, zp, zp, zp, 0, 1, 0.9, 0.9, None), contains="T < 1")
     fails(L.mms_gae_ppo_normalized(device, zp, zp, zp, None, zp, zp, zp, 1, 1, 0.9, 0.9, None), contains="null")
+    fails(L.mms_layer_clock_probe(device, zp, 0), contains="slots")
+    fails(L.mms_layer_clock_probe(device, ctypes.c_void_p(zp.value + 4), 1), contains="aligned")
+    assert L.mms_layer_clock_probe(device, None, 0) == 0                              # off: always accepted
     other = 0 if device < 0 else -1
     fails(L.mms_gae_ppo(other, zp, zp, zp, zp, zp, zp, zp, 1, 1, 0.9, 0.9, None))       # the other library's device
     return n_checked[0]

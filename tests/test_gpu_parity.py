@@ -1538,6 +1538,61 @@ def test_split16_layers_repeatable(torch_cuda):
         assert int(bad) == 0, (G, M, N, K, planes_out, int(bad))
 
 
+def test_layer_clock_probe(torch_cuda):
+    """mms_layer_clock_probe: with a buffer bound, workgroup 0 of every two-plane layer launch stores {shader cycles, 100-MHz ticks} of its
+    life into the launch's slot (n % slots, counting from the call); the ratio is a plausible shader clock (the kernel runs power-limited,
+    1.4-1.7 GHz at the PPO shape, higher on short launches: DESIGN.md 5.10), the ticks agree with the launch's HIP-event duration, the
+    layer's output does not depend on the probe, and after switching it off nothing is stored."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd import _lib
+    L = _lib.lib()
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(3)
+    G, M, N, K = 2, 4096, 1024, 1024
+    f32 = lambda *sh: torch.empty(*sh, device="cuda")
+    x = [torch.randn(M, K, device="cuda") for _ in range(G)]
+    w = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(G)]
+    b = [torch.randn(N, device="cuda") * 0.1 for _ in range(G)]
+    xp = [torch.empty(_h32_bytes(M, K), dtype=torch.uint8, device="cuda") for _ in range(G)]
+    wp = [torch.empty(_h32_bytes(N, K), dtype=torch.uint8, device="cuda") for _ in range(G)]
+    xs, xi, ws, wi = [[f32(n) for _ in range(G)] for n in (M, M, N, N)]
+    _lib.check(L.mms_split_planes16_group(0, G, M, K, 0, arr(x), arr(xp), arr(xs), arr(xi), 0, 0, None, None, None, None, 0.0, stream), None, "split16 x")
+    _lib.check(L.mms_split_planes16_group(0, G, N, K, 0, arr(w), arr(wp), arr(ws), arr(wi), 0, 0, None, None, None, None, 0.0, stream), None, "split16 w")
+    ys = [torch.zeros(M * N * 4, dtype=torch.uint8, device="cuda") for _ in range(G)]
+    run = lambda: L.mms_linear_group_act_split16(0, G, M, N, K, arr(xp), arr(wp), arr(b), arr(ys), arr(xi), arr(wi), None, 1, 0, None, None, None, None, None, 0, stream)
+    for _ in range(4):
+        assert run() == 0, _lib.last_error(None)
+    torch.cuda.synchronize()
+    want = [t.clone() for t in ys]
+    probe = torch.zeros(3, 2, dtype=torch.int64, device="cuda")
+    assert L.mms_layer_clock_probe(0, ctypes.c_void_p(probe.data_ptr()), 3) == 0
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        assert run() == 0 and run() == 0                                # slots 0 and 1
+        e0.record()
+        assert run() == 0                                               # slot 2
+        e1.record()
+        assert run() == 0                                               # slot 0 again
+        torch.cuda.synchronize()
+    finally:
+        assert L.mms_layer_clock_probe(0, None, 0) == 0
+    got = probe.cpu().tolist()
+    for cyc, ticks in got:
+        assert cyc > 0 and ticks > 0, got
+        ghz = cyc / ticks * 0.1
+        assert 0.8 < ghz < 2.6, got
+    us_events = e0.elapsed_time(e1) * 1e3
+    assert 0.5 * us_events < got[2][1] * 0.01 < 1.1 * us_events, (got, us_events)   # workgroup 0 lives most of the launch, never longer
+    for a, b_ in zip(want, ys):
+        assert torch.equal(a, b_)
+    probe.zero_()
+    assert run() == 0
+    torch.cuda.synchronize()
+    assert int(probe.abs().sum()) == 0                                   # off: nothing stored
+    parity.record("gpu/layer_clock_probe", clock_ghz=[c / t * 0.1 for c, t in got], workgroup0_us=[t * 0.01 for _, t in got], launch_us_events=us_events)
+
+
 def test_obs_planes_from_the_step_kernel(torch_cuda):
     """mms_bind_obs_planes16 on the HIP build, every ant layout of the step kernel's write-out (TenAnt packed 4 / 16 envs per block and
     one env per block at 6 ants, OneAnt, MultiAntCircle): tests/obs_planes_check.py."""
