@@ -144,7 +144,7 @@ struct Split16LinearArgs {
     const float* head_w[kMaxGroups];
     float* head_part[kMaxGroups];
     int hdims[kMaxGroups];
-    int tiles;
+    int tiles, grid;                // (set by the launcher)
     uint64_t* clock_probe;          // optional (mms_layer_clock_probe): block 0 stores its life in shader cycles and in 100-MHz ticks
 };
 

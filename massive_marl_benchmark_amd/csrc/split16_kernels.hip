@@ -329,8 +329,8 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     // mms_layer_clock_probe: block 0 reports the clock the chip holds while this launch runs (shader cycles and 100-MHz ticks of its life)
-    uint64_t probe_c0 = 0, probe_r0 = 0;
-    if (a.clock_probe) { probe_c0 = __builtin_readcyclecounter(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
+    // (both counters read unconditionally: a branch on a.clock_probe here would put a kernel-argument round trip in front of everything else)
+    const uint64_t probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #if MMS_S16_STAMP   // phase stamps (timing experiments only: overwrites the first 32 bytes of the first output): shader clocks and 100-MHz ticks of block 0
     const uint64_t stamp_c0 = __builtin_readcyclecounter(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
     uint64_t stamp_r12[2] = {0, 0};                  // ... first slice landed, k-loop done (last tile of the block)
@@ -338,6 +338,9 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
     const int wm = wave >> 1, wn = wave & 1;
     const int KC = a.KC, N = a.N;
     const int tiles_n = N / G::TN, tiles_m = a.M / G::TM, total = a.tiles;
+    // (the grid size rides in the argument block beside `tiles`, and the test is branch-free: as `(total & 7) == 0 && (gridDim.x & 7) == 0`
+    //  it cost a dependent scalar load of the hidden grid-size argument behind a branch -- one more round trip in front of the first DMA)
+    const bool xcd_aware = (((total | a.grid) & 7) == 0);
     const size_t pitch = (size_t)KC * kChunk16;
 
     // LDS-DMA: instruction c of a k-step fills image bytes [1024 c, + 1024) = eight rows; lane s of it owns the physical 16-byte
@@ -352,18 +355,25 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
         goff[i] = (uint32_t)((i < G::NX ? row : row - G::TM) * (int)pitch + (c8 >> 2) * 64 + (c8 & 3) * 16);
     }
     int gi, m0, n0, tn;
+    uint64_t x01[2] = {reinterpret_cast<uint64_t>(a.x[0]), reinterpret_cast<uint64_t>(a.x[1])};
+    uint64_t w01[2] = {reinterpret_cast<uint64_t>(a.w[0]), reinterpret_cast<uint64_t>(a.w[1])};
+    asm volatile("" : "+s"(x01[0]), "+s"(x01[1]), "+s"(w01[0]), "+s"(w01[1]));       // (loaded HERE, with the other scalars -- not sunk into the tile setup)
     __amdgpu_buffer_rsrc_t xr, wr;                                      // the current tile's X rows / W rows (raw buffers: [TM or TN rows][pitch] bytes)
     auto setup_tile = [&](int v) {
         int L = v;
-        if ((total & 7) == 0 && (gridDim.x & 7) == 0) L = (v & 7) * (total >> 3) + (v >> 3);       // XCD-aware: as linear_split_kernel
+        if (xcd_aware) L = (v & 7) * (total >> 3) + (v >> 3);                                      // XCD-aware: as linear_split_kernel
         tn = L % tiles_n;
         const int rest = L / tiles_n;
         const int tm = rest % tiles_m;
         gi = rest / tiles_m;
         m0 = tm * G::TM;
         n0 = tn * G::TN;
-        const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x[gi]) + (size_t)m0 * pitch;
-        const uint8_t* wb = reinterpret_cast<const uint8_t*>(a.w[gi]) + (size_t)n0 * pitch;
+        // (the first two networks' operand pointers come with the kernel's first batch of scalar loads -- x01 / w01 above: the PPO pair's
+        //  tiles then need no second, tile-dependent argument round trip before their first DMA; further networks load theirs here)
+        const uint64_t xg = gi == 0 ? x01[0] : (gi == 1 ? x01[1] : reinterpret_cast<uint64_t>(a.x[gi]));
+        const uint64_t wg = gi == 0 ? w01[0] : (gi == 1 ? w01[1] : reinterpret_cast<uint64_t>(a.w[gi]));
+        const uint8_t* xb = reinterpret_cast<const uint8_t*>(xg) + (size_t)m0 * pitch;
+        const uint8_t* wb = reinterpret_cast<const uint8_t*>(wg) + (size_t)n0 * pitch;
         xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(xb), (short)0, (int)(G::TM * pitch), 0x00020000);
         wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wb), (short)0, (int)(G::TN * pitch), 0x00020000);
     };
@@ -634,7 +644,7 @@ __global__ void __launch_bounds__(512, 2) linear_split16_kernel(Split16LinearArg
             asm volatile("" : "+v"(xi[mt]), "+v"(ys[mt]));
             if constexpr (LN != 0) asm volatile("" : "+v"(st[mt].x), "+v"(st[mt].y));
         }
-        const int vnext = v + (int)gridDim.x;
+        const int vnext = v + a.grid;
         const bool has_next = vnext < total;
         const int nb0 = blast == 2 ? 0 : blast + 1, nb1 = nb0 == 2 ? 0 : nb0 + 1;
         // (the next tile's first wait counts the vmcnt entries issued from here on: exactly these DMAs, then the kStores output stores --
@@ -853,6 +863,7 @@ hipError_t launch_linear_split16(const Split16LinearArgs& a, int groups, hipStre
         b.tiles = (int)((int64_t)groups * (a.M / (64 * MT)) * (a.N / 128));                                                    \
         b.clock_probe = g_probe_out ? g_probe_out + 2 * (g_probe_next++ % g_probe_slots) : nullptr;                           \
         const unsigned grid = (unsigned)(b.tiles < cus ? b.tiles : cus);        /* persistent: at most one block per CU */      \
+        b.grid = (int)grid;                                                                                                    \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Geom16<MT>::LDS, s, b);                                                \
     }
     if (ln) {
