@@ -288,6 +288,9 @@ typedef struct mms_policy_head {
     uint64_t seed;
     int64_t row_offset;
     int32_t H, VH, A, reference_scale;
+    const float* weight_tiles;   /* optional (NULL: `weight` is read): the actor's last layer once more, stored [ceil(A / 16)][H / 4][16][4] --
+                                  * element ((ct (H / 4) + k / 4) 16 + i) 4 + k % 4 = weight[16 ct + i][k], zero for outputs >= A; 16-byte aligned.
+                                  * One operand load of the head's matrix phase then reads 1 KB of contiguous memory (csrc/head_block.h). */
 } mms_policy_head;
 int mms_bind_policy_head(mms_handle h, const mms_policy_head* head);   /* NULL: unbind */
 

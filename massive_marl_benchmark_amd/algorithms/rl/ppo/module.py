@@ -70,9 +70,10 @@ class ActorCritic(nn.Module):
         self._sample_calls = None
         self._qualify = None
         self._step_engine = None
+        self._head_wt = None                 # (padded rows, tiles): the actor's last layer stored for coalesced operand loads (_head_tiles)
 
     _DERIVED = ("_counters", "_side", "_trunk", "_act_bufs", "_value_bufs", "_one_bufs", "_wplanes", "_split_bufs", "_nets", "_h16", "_addr_tag",
-                "_ver_tag", "_calls", "_sample_calls", "_qualify", "_bound", "_step_engine")
+                "_ver_tag", "_calls", "_sample_calls", "_qualify", "_bound", "_step_engine", "_head_wt")
 
     def __deepcopy__(self, memo):
         """A copy starts without derived state: the caches hold device addresses of THIS module's parameters and buffers."""
@@ -256,7 +257,10 @@ class ActorCritic(nn.Module):
         if self._addr_tag is not None and self._addr_tag != (addrs, str(dev)):
             # the parameters moved (.to(device), a new storage): every cached address is void
             self._h16, self._wplanes, self._split_bufs, self._calls, self._sample_calls = None, None, None, None, None
+            self._head_wt = None
         self._addr_tag, self._ver_tag = (addrs, str(dev)), vers
+        if self._head_wt is not None:
+            self._fill_head_tiles()
         st = self._h16
         if st is not None:
             stream = _lib.for_device(st["dev"])[2]
@@ -286,6 +290,31 @@ class ActorCritic(nn.Module):
                     self._weight_planes(lin, *_lib.for_device(lin.weight.device), force=True)
                 else:
                     self._wplanes[key] = (None, planes, lin)    # not in use now: re-split at their next use
+
+    def _head_tiles(self):
+        """The actor's last layer once more, stored [ceil(A / 16)][H / 4][16][4] (struct mms_policy_head.weight_tiles, csrc/head_block.h:
+        one operand load of the fused head's matrix phase then reads 1 KB of contiguous memory instead of 16 rows x 64 B): a derived
+        buffer at a stable address, rebuilt by refresh() with two device copies."""
+        if self._head_wt is None:
+            last = self.actor[-1]
+            A, H = last.out_features, last.in_features
+            nct = (A + 15) // 16
+            pad = torch.zeros(nct * 16, H, device=last.weight.device, dtype=torch.float32)
+            tiles = torch.empty(nct * (H // 4) * 64, device=last.weight.device, dtype=torch.float32)
+            self._head_wt = (pad, tiles)
+            self._fill_head_tiles()
+        return self._head_wt[1]
+
+    def _fill_head_tiles(self):
+        pad, tiles = self._head_wt
+        last = self.actor[-1]
+        A, H = last.out_features, last.in_features
+        with torch.no_grad():
+            if A % 16 == 0:                                          # one strided copy (TenAnt: 80 outputs = five whole column tiles)
+                tiles.view(-1, H // 4, 16, 4).copy_(last.weight.detach().view(-1, 16, H // 4, 4).permute(0, 2, 1, 3))
+            else:
+                pad[:A].copy_(last.weight.detach())
+                tiles.view(-1, H // 4, 16, 4).copy_(pad.view(-1, 16, H // 4, 4).permute(0, 2, 1, 3))
 
     def _ensure_fresh(self):
         """refresh() when a parameter's version counter or address has moved since the derived buffers were built (see refresh for what
@@ -584,7 +613,7 @@ class ActorCritic(nn.Module):
                 a_ = lambda t: None if t is None else t.data_ptr()
                 head = MmsPolicyHead(a_(hidden), a_(last.weight), a_(last.bias), a_(vh), a_(vlast.weight), a_(vlast.bias), a_(log_std), a_(self._counters),
                                      a_(actions_out), a_(act), a_(logp), a_(val), a_(mu), a_(sigma), self.seed, self.row_offset, last.in_features,
-                                     vlast.in_features, A, 1)
+                                     vlast.in_features, A, 1, a_(self._head_tiles()) if last.weight.dtype == torch.float32 else None)
             if head is not None:
                 eng.bind_policy_head(head)
             else:

@@ -201,7 +201,16 @@ static int do_step(mms_handle h, int physics) {
         const mms_policy_head& p = h->head;
         float* dst = p.actions_out ? p.actions_out : buf<float>(h, "actions");
         h->head_on = 0;
-        if (mms_ppo_heads_act(-1, p.hidden, p.weight, p.bias, p.H, nullptr, p.vhidden, p.vweight, p.vbias, p.VH, p.log_std, p.seed, p.counters, p.row_offset,
+        // (with the tiled copy of the actor's last layer bound, THAT is what is read -- as on the device; element
+        //  ((ct (H / 4) + k / 4) 16 + i) 4 + k % 4 = weight[16 ct + i][k] -- so a stale or mis-laid copy shows up in the host tests too)
+        std::vector<float> untiled;
+        if (p.weight_tiles) {
+            untiled.resize((size_t)p.A * p.H);
+            for (int j = 0; j < p.A; j++)
+                for (int k = 0; k < p.H; k++)
+                    untiled[(size_t)j * p.H + k] = p.weight_tiles[((size_t)((j >> 4) * (p.H / 4) + (k >> 2)) * 16 + (j & 15)) * 4 + (k & 3)];
+        }
+        if (mms_ppo_heads_act(-1, p.hidden, p.weight_tiles ? untiled.data() : p.weight, p.bias, p.H, nullptr, p.vhidden, p.vweight, p.vbias, p.VH, p.log_std, p.seed, p.counters, p.row_offset,
                               p.reference_scale, dst, p.act_slot, p.logp_slot, p.value_slot, p.mu_slot, p.sigma_slot, h->cfg.num_envs, p.A, nullptr))
             return fail(h, "mms_step: the bound policy head failed: " + g_error);
         head_actions = dst;

@@ -64,14 +64,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // false and only join the two block barriers.  s_part: LDS, (WAVES + 1) * 16 RT * 16 NCT floats.
 // UB = float4 operand groups loaded ahead of their MFMAs per trip (4: all of a 64-k trip, the stand-alone kernel; 2: half a trip at a
 // time -- 48 fewer live registers for the step kernel's 168-VGPR budget; every accumulator sees the same sequence of products either way).
-template <int NCT, int WAVES, int RT, int UB = 4>
+// TILED: the head's weights are read from `weight_tiles` = the same matrix stored [column tile ct][k / 4][16 outputs][4 consecutive k]
+// (zero rows for outputs >= A): the 64 lanes of one operand load -- lane (i, g) wants output 16 ct + i, k-group g -- then read 1 KB of
+// CONTIGUOUS memory.  From the row-major [A][H] matrix the same load touches 16 rows x 64 B with the four lanes of a row 16 lanes apart:
+// 64 separate cache-line accesses per instruction, and the 160 KB every workgroup needs of it arrive at ~40 GB/s (measured: the fused
+// step kernel 38.4-39.2 us against 40.4-41.4, the rollout step 0.1391 against 0.1410 ms).  The values and their order are the same.
+template <int NCT, int WAVES, int RT, int UB = 4, bool TILED = false>
 __device__ __forceinline__ void ppo_head_block(float* s_part, const int tid, const bool active, const int64_t r0,
                                                const float* __restrict__ hidden, const float* __restrict__ weight,
                                                const float* __restrict__ bias, int H, const float* __restrict__ value,
                                                const float* __restrict__ vhidden, const float* __restrict__ vweight,
                                                const float* __restrict__ vbias, int VH,
                                                const float* __restrict__ log_std, uint64_t seed, int64_t* __restrict__ counters,
-                                               int64_t row_offset, int ref_scale, const PpoActOut& o, int64_t N, int A) {
+                                               int64_t row_offset, int ref_scale, const PpoActOut& o, int64_t N, int A,
+                                               const float* __restrict__ weight_tiles = nullptr) {
     constexpr int AP = NCT * 16, ROWS = 16 * RT;
     constexpr int RPW = ROWS / WAVES;                                        // rows sampled per wave (WAVES in 1, 2, 4, 8)
 #if MMS_HEAD_STAMP   // phase probe (timing experiments only): 100-MHz ticks of block 0 / wave 0 into sigma_slot[0..5]
@@ -135,7 +141,9 @@ __device__ __forceinline__ void ppo_head_block(float* s_part, const int tid, con
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) a[rt][u] = *reinterpret_cast<const float4*>(hrow[rt] + kc + 16 * (u0 + u));
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ct++) b[u][ct] = *reinterpret_cast<const float4*>(wrow[ct] + kc + 16 * (u0 + u));
+                    for (int ct = 0; ct < NCT; ct++)
+                        b[u][ct] = TILED ? *reinterpret_cast<const float4*>(weight_tiles + ((size_t)(ct * (H / 4) + (kc / 4 + 4 * (u0 + u) + g)) * 16 + i) * 4)
+                                         : *reinterpret_cast<const float4*>(wrow[ct] + kc + 16 * (u0 + u));
                 }
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++)

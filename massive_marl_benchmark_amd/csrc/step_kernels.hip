@@ -194,9 +194,14 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 64 ? MMS_WAVES_PER_EU : ((BLOC
         PpoActOut o{a.head.actions_out, a.head.act_slot, a.head.logp_slot, a.head.value_slot, a.head.mu_slot, a.head.sigma_slot};
         o.lds_actions = s_head_actions;
         o.lds_row0 = (int64_t)blockIdx.x * 16;
-        ppo_head_block<5, 8, 1, 4>(s_head, (int)threadIdx.x, threadIdx.x < 512, (int64_t)blockIdx.x * 16, a.head.hidden, a.head.weight, a.head.bias, a.head.H, nullptr,
-                                   a.head.vhidden, a.head.vweight, a.head.vbias, a.head.VH, a.head.log_std, a.head.seed, a.head.counters, a.head.row_offset,
-                                   a.head.reference_scale, o, a.num_envs, 8 * AT);
+        if (a.head.weight_tiles)                                     // (uniform: the tiled copy of the head's weights, head_block.h)
+            ppo_head_block<5, 8, 1, 4, true>(s_head, (int)threadIdx.x, threadIdx.x < 512, (int64_t)blockIdx.x * 16, a.head.hidden, a.head.weight, a.head.bias, a.head.H, nullptr,
+                                             a.head.vhidden, a.head.vweight, a.head.vbias, a.head.VH, a.head.log_std, a.head.seed, a.head.counters, a.head.row_offset,
+                                             a.head.reference_scale, o, a.num_envs, 8 * AT, a.head.weight_tiles);
+        else
+            ppo_head_block<5, 8, 1, 4>(s_head, (int)threadIdx.x, threadIdx.x < 512, (int64_t)blockIdx.x * 16, a.head.hidden, a.head.weight, a.head.bias, a.head.H, nullptr,
+                                       a.head.vhidden, a.head.vweight, a.head.vbias, a.head.VH, a.head.log_std, a.head.seed, a.head.counters, a.head.row_offset,
+                                       a.head.reference_scale, o, a.num_envs, 8 * AT);
         __syncthreads();                                             // the sampled actions are in LDS
         if (threadIdx.x < 16 * 4 * AT) ac_head = reinterpret_cast<const float2*>(s_head_actions)[threadIdx.x];   // lane (env e, ant lane t) = thread 40 e + t: actions 80 e + 2 t
         // (no barrier behind the reads: nothing writes the parking space before the first substep's inward pass, which sits behind the

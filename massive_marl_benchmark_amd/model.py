@@ -79,7 +79,8 @@ class MmsPolicyHead(ctypes.Structure):
                 ("actions_out", ctypes.c_void_p), ("act_slot", ctypes.c_void_p), ("logp_slot", ctypes.c_void_p), ("value_slot", ctypes.c_void_p),
                 ("mu_slot", ctypes.c_void_p), ("sigma_slot", ctypes.c_void_p),
                 ("seed", ctypes.c_uint64), ("row_offset", ctypes.c_int64),
-                ("H", ctypes.c_int32), ("VH", ctypes.c_int32), ("A", ctypes.c_int32), ("reference_scale", ctypes.c_int32)]
+                ("H", ctypes.c_int32), ("VH", ctypes.c_int32), ("A", ctypes.c_int32), ("reference_scale", ctypes.c_int32),
+                ("weight_tiles", ctypes.c_void_p)]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -30,9 +30,17 @@ def check_head_fusion(device, num_envs, hidden=(256, 512), steps=6):
         for t in range(T):
             obs_t = storage.observations[t]
             obs_t.copy_(eng.tensor("obs_clipped"))
+            if t == T // 2:
+                # a parameter update in the middle of the rollout (version counters move): the derived copies -- among them the tiled copy
+                # of the actor's last layer the fused head reads (mms_policy_head.weight_tiles) -- have to follow it in both forms
+                gen = torch.Generator().manual_seed(99)
+                with torch.no_grad():
+                    for q in (ac.actor[-1].weight, ac.actor[-1].bias, ac.critic[-1].weight, ac.actor[0].weight):
+                        q.add_((0.05 * torch.randn(q.shape, generator=gen)).to(dev))
             if dev.type == "cuda":
                 act, logp, value, mu, sigma = ac.act(obs_t, states)
             else:                                                    # (on the CPU build `act` keeps to the torch modules: drive the fused tail directly)
+                ac._ensure_fresh()
                 with torch.no_grad():
                     ha, hc = ac.actor[:-1](obs_t), ac.critic[:-1](obs_t)
                 act, logp, value, mu, sigma = ac._sample(None, None, hidden=ha.contiguous(), vhidden=hc.contiguous())
@@ -52,4 +60,5 @@ def check_head_fusion(device, num_envs, hidden=(256, 512), steps=6):
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert float(a["actions"].abs().max()) > 0.1 and int(a["counters"].min()) == steps
+    # (the unfused form reads the row-major weight itself: a stale or mis-laid tiled copy in the fused form fails the equality above)
     return True
