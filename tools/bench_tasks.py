@@ -63,11 +63,16 @@ def measure(task, N, A, steps, seed=0, env_spacing=None):
         # the kernel alone: eager launches back to back, no action copies in between
         for _ in range(8):
             eng.step()
-        e0.record(s)
-        for _ in range(256):
-            eng.step()
-        e1.record(s); s.synchronize()
-        ms_kernel = e0.elapsed_time(e1) / 256
+        # (eight batches of 32, the median batch: a one-off ~35-ms runtime stall -- DESIGN.md section 6 -- inside a single 256-launch
+        #  interval once made this read 319 us "per launch")
+        batches = []
+        for _ in range(8):
+            e0.record(s)
+            for _ in range(32):
+                eng.step()
+            e1.record(s); s.synchronize()
+            batches.append(e0.elapsed_time(e1) / 32)
+        ms_kernel = sorted(batches)[len(batches) // 2]
     resets = int(eng.tensor("reset_count").sum())
     total_steps = 64 + 16 + reps * 16 + 8 + 256
     finite = bool(torch.isfinite(eng.tensor("obs")).all())
