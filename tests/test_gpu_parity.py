@@ -1820,6 +1820,88 @@ def test_policy_head_fused_into_the_step(torch_cuda):
     assert head_fusion_check.check_head_fusion("cuda", 4096, hidden=(1024, 1024, 512))
 
 
+def test_fused_head_graph_follows_parameter_updates(torch_cuda):
+    """The captured form of the fused policy head (bench.py's graph: refresh at the head of a rollout, `act` binds the head, the step kernel
+    evaluates it) after an optimizer step and after a `.data` write: a replay leaves in the rollout slots, bit for bit, what the UNFUSED
+    path (mms_ppo_heads_act reading the row-major weight itself) leaves for the updated parameters -- so the tiled copy of the actor's last
+    layer (mms_policy_head.weight_tiles) is rebuilt inside the graph like every other derived buffer."""
+    torch = torch_cuda
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.module import ActorCritic
+    from massive_marl_benchmark_amd.algorithms.rl.ppo.storage import RolloutStorage
+    from massive_marl_benchmark_amd.engine import Engine
+    torch.manual_seed(1)
+    n = 4096
+    eng = Engine("TenAnt", num_envs=n, device=0, seed=5, clip_obs=5.0)
+    assert eng.takes_policy_head()
+    ac = ActorCritic((eng.obs_dim,), (0,), (eng.num_actions,), 0.8, {"pi_hid_sizes": [256, 512], "vf_hid_sizes": [256, 512], "activation": "elu"}, seed=9).cuda()
+    ac.split_min_tiles = 0
+    obs = torch.randn(n, eng.obs_dim, device="cuda").clamp(-5, 5)
+    states = torch.zeros(n, 0, device="cuda")
+    storage = RolloutStorage(n, 2, (eng.obs_dim,), (0,), (eng.num_actions,), device="cuda")
+    actions = eng.tensor("actions")
+
+    def slots():
+        torch.cuda.synchronize()
+        return [t[0].clone() for t in (storage.actions, storage.actions_log_prob, storage.values, storage.mu, storage.sigma)] + [actions.clone()]
+
+    def unfused():
+        ac.bind_rollout(storage, actions, step_engine=None)
+        storage.clear()
+        ac._counters.zero_()
+        act, logp, value, mu, sigma = ac.act(obs, states)
+        storage.add_transitions(obs, states, act, storage.rewards[0], storage.dones[0], value, logp, mu, sigma)
+        out = slots()
+        ac.bind_rollout(storage, actions, step_engine=eng)
+        storage.clear()
+        return out
+
+    ac.bind_rollout(storage, actions, step_engine=eng)
+    assert ac._step_engine is not None
+    ac.act(obs, states)                                             # warm-up: buffers (among them the tiled copy) are allocated outside the capture
+    eng.step()
+    storage.clear()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ac.act(obs, states)                                     # storage.step == 0: refresh() is inside; the head is bound ...
+            eng.step()                                              # ... and evaluated in this launch's prologue
+    torch.cuda.current_stream().wait_stream(side)
+
+    def replay():
+        ac._counters.zero_()
+        graph.replay()
+        return slots()
+
+    want = unfused()
+    for a, b in zip(want, replay()):
+        assert torch.equal(a, b)
+    before_mu = want[3]
+    opt = torch.optim.SGD(ac.parameters(), lr=0.3)
+    for q in ac.parameters():
+        q.grad = torch.randn_like(q) * 0.1
+    opt.step()
+    got = replay()                                                  # (BEFORE any eager call could refresh for it)
+    want = unfused()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert float((want[3] - before_mu).abs().max()) > 1e-3          # the means moved with the parameters
+    with torch.no_grad():
+        for q in ac.parameters():
+            q.data.copy_(q.data + 0.05 * torch.randn_like(q))        # no version counter moves
+    got = replay()
+    want = unfused()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        rel = float((got[3] - ac.actor(obs)).abs().max() / (1.0 + ac.actor(obs).abs().max()))
+    assert rel < 1e-5, rel
+    parity.record("gpu/fused_head_graph_after_updates", mean_vs_torch=rel)
+    ac.bind_rollout(None, None)
+    eng.close()
+
+
 def test_abi_error_paths_and_indexed_set_state(torch_cuda):
     """The status-code contract of include/mms.h on the HIP build (the list of tests/abi_errors.py, as on the CPU build), and
     mms_set_state with more than 16 env ids: one scatter launch (the reference's indexed setters take thousands of ids,
