@@ -1566,24 +1566,27 @@ def test_layer_clock_probe(torch_cuda):
     torch.cuda.synchronize()
     want = [t.clone() for t in ys]
     probe = torch.zeros(3, 2, dtype=torch.int64, device="cuda")
-    assert L.mms_layer_clock_probe(0, ctypes.c_void_p(probe.data_ptr()), 3) == 0
-    try:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        assert run() == 0 and run() == 0                                # slots 0 and 1
-        e0.record()
-        assert run() == 0                                               # slot 2
-        e1.record()
-        assert run() == 0                                               # slot 0 again
-        torch.cuda.synchronize()
-    finally:
-        assert L.mms_layer_clock_probe(0, None, 0) == 0
-    got = probe.cpu().tolist()
-    for cyc, ticks in got:
-        assert cyc > 0 and ticks > 0, got
-        ghz = cyc / ticks * 0.1
-        assert 0.8 < ghz < 2.6, got
-    us_events = e0.elapsed_time(e1) * 1e3
-    assert 0.5 * us_events < got[2][1] * 0.01 < 1.1 * us_events, (got, us_events)   # workgroup 0 lives most of the launch, never longer
+    tries = []
+    for _ in range(3):                                                  # (the event interval of ONE launch can catch a runtime stall: best of three)
+        assert L.mms_layer_clock_probe(0, ctypes.c_void_p(probe.data_ptr()), 3) == 0
+        try:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            assert run() == 0 and run() == 0                            # slots 0 and 1
+            e0.record()
+            assert run() == 0                                           # slot 2
+            e1.record()
+            assert run() == 0                                           # slot 0 again
+            torch.cuda.synchronize()
+        finally:
+            assert L.mms_layer_clock_probe(0, None, 0) == 0
+        got = probe.cpu().tolist()
+        for cyc, ticks in got:
+            assert cyc > 0 and ticks > 0, got
+            ghz = cyc / ticks * 0.1
+            assert 0.8 < ghz < 2.6, got
+        tries.append((got, e0.elapsed_time(e1) * 1e3))
+    got, us_events = min(tries, key=lambda t: t[1])
+    assert 0.5 * us_events < got[2][1] * 0.01 < 1.1 * us_events, tries   # workgroup 0 lives most of the launch, never longer
     for a, b_ in zip(want, ys):
         assert torch.equal(a, b_)
     probe.zero_()
