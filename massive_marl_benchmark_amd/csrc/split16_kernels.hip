@@ -311,7 +311,6 @@ __device__ __forceinline__ void planes16_4(f32x4 v, float ys, float ys2k, uint32
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "s"(c), "v"(x2[3]));
 }
 
-typedef const __attribute__((address_space(1))) void* gptr16_t;
 typedef __attribute__((address_space(3))) void* lptr16_t;
 
 template <int N>
