@@ -284,6 +284,9 @@ MMS_API int mms_bind_policy_head(mms_handle h, const mms_policy_head* head) {
         return fail(h, "mms_bind_policy_head: null pointer (hidden, weight, bias, vhidden, vweight, vbias, log_std, counters are required)");
     if (head->A != 8 * h->cfg.num_agents || head->H <= 0 || head->H % 512 != 0 || head->VH <= 0 || head->VH % 4 != 0)
         return fail(h, "mms_bind_policy_head: A must be 8 x num_agents, H a multiple of 512, VH a multiple of 4");
+    uintptr_t bits = reinterpret_cast<uintptr_t>(head->hidden) | reinterpret_cast<uintptr_t>(head->weight) | reinterpret_cast<uintptr_t>(head->vhidden) |
+                     reinterpret_cast<uintptr_t>(head->vweight) | reinterpret_cast<uintptr_t>(head->weight_tiles);
+    if ((bits & 15) != 0) return fail(h, "mms_bind_policy_head: hidden, weight, weight_tiles, vhidden, vweight must be 16-byte aligned");
     h->head = *head;
     h->head_on = 1;
     return 0;

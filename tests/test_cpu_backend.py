@@ -512,6 +512,7 @@ def test_policy_head_fused_into_the_step_on_cpu_build():
     refuses."""
     import head_fusion_check
     assert head_fusion_check.check_head_fusion("cpu", 32)
+    assert head_fusion_check.check_head_bind_errors("cpu", 32)
     from massive_marl_benchmark_amd.engine import Engine
     one = Engine("OneAnt", num_envs=16, device="cpu")
     assert not one.takes_policy_head()

@@ -1821,6 +1821,7 @@ def test_policy_head_fused_into_the_step(torch_cuda):
     bit, what mms_ppo_heads_act + mms_step leave (tests/head_fusion_check.py: rollout slots, draw counters, engine state)."""
     import head_fusion_check
     assert head_fusion_check.check_head_fusion("cuda", 4096, hidden=(1024, 1024, 512))
+    assert head_fusion_check.check_head_bind_errors("cuda", 4096)
 
 
 def test_fused_head_graph_follows_parameter_updates(torch_cuda):
